@@ -1,0 +1,158 @@
+"""ctypes front-end to the CPU oracle (oracle/vof_oracle.c, oracle/pix2uv_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from octane_amd/.  "parity unpinned" for the
+whole solver -- see the header of vof_oracle.c for what is and is not pinned.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_F = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_S = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+
+
+class Params(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("lambda_", C.c_double), ("lambdac", C.c_double),
+                ("scaleF", C.c_double), ("kiters", C.c_int), ("liters", C.c_int),
+                ("cgiters", C.c_int), ("dozim", C.c_int)]
+
+
+class Nav(C.Structure):
+    _fields_ = [("pph", C.c_double), ("req", C.c_double), ("rpol", C.c_double), ("lam0", C.c_double),
+                ("xScale", C.c_float), ("xOffset", C.c_float), ("yScale", C.c_float), ("yOffset", C.c_float),
+                ("g2xOffset", C.c_float), ("g2yOffset", C.c_float),
+                ("lat1", C.c_float), ("lon1", C.c_float), ("lon0", C.c_float), ("R", C.c_float),
+                ("minX", C.c_int), ("minY", C.c_int), ("nx", C.c_int), ("ny", C.c_int)]
+
+
+_TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                        C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int)
+
+
+class _Trace(C.Structure):
+    _fields_ = [("cb", _TRACE_FN), ("user", C.c_void_p)]
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle (and, when /root/reference is present, oracle/_ref)."""
+    need = force or not all(os.path.exists(os.path.join(_HERE, n))
+                            for n in ("liboct_oracle.so", "liboct_oracle_fma.so"))
+    if need:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    ref = os.environ.get("OCT_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref, "src")) and (force or not os.path.exists(ref_helpers_path())):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref", f"REF={ref}"])
+
+
+def ref_helpers_path() -> str:
+    return os.path.join(_HERE, "_ref", "liboct_ref_helpers.so")
+
+
+_libs: dict[str, C.CDLL] = {}
+
+
+def lib(flavour: str = "strict") -> C.CDLL:
+    """flavour: 'strict' (no FMA contraction) or 'fma'."""
+    if flavour in _libs:
+        return _libs[flavour]
+    build()
+    name = "liboct_oracle.so" if flavour == "strict" else "liboct_oracle_fma.so"
+    L = C.CDLL(os.path.join(_HERE, name))
+    L.oct_oracle_vof.restype = C.c_int
+    L.oct_oracle_vof.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, _F, _F, C.POINTER(Params), C.c_void_p]
+    L.oct_oracle_level_dims.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.oct_oracle_level_factor.restype = C.c_float
+    L.oct_oracle_level_factor.argtypes = [C.c_float, C.c_int, C.c_int]
+    L.oct_oracle_blur_halfwidth.restype = C.c_int
+    L.oct_oracle_blur_halfwidth.argtypes = [C.c_float]
+    L.oct_oracle_gauss_taps.argtypes = [C.c_float, C.c_int, _F]
+    L.oct_oracle_blur_rows.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.oct_oracle_blur_cols.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.oct_oracle_bicubic.restype = C.c_float
+    L.oct_oracle_bicubic.argtypes = [_F, C.c_float, C.c_float, C.c_int, C.c_int]
+    L.oct_oracle_decimate.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.oct_oracle_gradient.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int]
+    L.oct_oracle_upsample_flow.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.oct_oracle_nnz_before.restype = C.c_long
+    L.oct_oracle_nnz_before.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.oct_oracle_pix2uv.restype = C.c_int
+    L.oct_oracle_pix2uv.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, _F, _F, C.c_int, C.c_int,
+                                    _S, _S, _S, _S, C.POINTER(C.c_float)]
+    _libs[flavour] = L
+    return L
+
+
+@dataclass
+class FlowParams:
+    """The OFFlags fields the solver reads (ref include/offlags.h, .cu:1229-1241),
+    with the CLI defaults of ref src/main.cc:78-96."""
+    alpha: float = 5.0
+    lambda_: float = 1.0
+    lambdac: float = 0.0
+    scaleF: float = 0.5
+    kiters: int = 4
+    liters: int = 3
+    cgiters: int = 30
+    dozim: int = 1
+
+    def c(self) -> Params:
+        return Params(self.alpha, self.lambda_, self.lambdac, self.scaleF,
+                      self.kiters, self.liters, self.cgiters, self.dozim)
+
+
+def flow(img1: np.ndarray, img2: np.ndarray, prm: FlowParams | None = None,
+         u0: np.ndarray | None = None, v0: np.ndarray | None = None,
+         trace: dict | None = None, flavour: str = "strict"):
+    """Run the oracle solver.  Images are [nc, ny, nx] or [ny, nx] float32
+    (x fastest, channel-planar: Image.data[i + nx*j + nx*ny*c]).
+    Returns (u, v, total_pcg_iterations).  If `trace` is a dict it is filled with
+    {(tag, level, gnc, l): array[nplanes, ny, nx]}."""
+    prm = prm or FlowParams()
+    a = np.ascontiguousarray(img1, dtype=np.float32)
+    b = np.ascontiguousarray(img2, dtype=np.float32)
+    if a.ndim == 2:
+        a = a[None]
+        b = b[None]
+    nc, ny, nx = a.shape
+    u = np.zeros((ny, nx), np.float32) if u0 is None else np.array(u0, dtype=np.float32, order="C", copy=True)
+    v = np.zeros((ny, nx), np.float32) if v0 is None else np.array(v0, dtype=np.float32, order="C", copy=True)
+    L = lib(flavour)
+    tr_ptr = None
+    keep = None
+    if trace is not None:
+        def _cb(user, tag, k, gnc, l, data, tnx, tny, npl):
+            arr = np.ctypeslib.as_array(data, shape=(npl, tny, tnx)).copy()
+            trace[(tag.decode(), k, gnc, l)] = arr
+        keep = _TRACE_FN(_cb)
+        t = _Trace(keep, None)
+        tr_ptr = C.cast(C.pointer(t), C.c_void_p)
+    p = prm.c()
+    its = L.oct_oracle_vof(a, b, nx, ny, nc, u, v, C.byref(p), tr_ptr)
+    if its < 0:
+        raise RuntimeError(f"oracle failed with code {its}")
+    return u, v, its
+
+
+def level_dims(nx: int, ny: int, factor: float):
+    lx, ly = C.c_int(), C.c_int()
+    lib().oct_oracle_level_dims(nx, ny, factor, C.byref(lx), C.byref(ly))
+    return lx.value, ly.value
+
+
+def pix2uv(nav: Nav, t1: float, t2: float, u: np.ndarray, v: np.ndarray, pixuv: int = 0, mode: int = 0):
+    """Returns (ur, vr, ur2, vr2, dT, sector_moved)."""
+    u = np.ascontiguousarray(u, np.float32)
+    v = np.ascontiguousarray(v, np.float32)
+    n = u.size
+    ur, vr, ur2, vr2 = (np.zeros(n, np.int16) for _ in range(4))
+    dT = C.c_float()
+    moved = lib().oct_oracle_pix2uv(C.byref(nav), t1, t2, u.ravel(), v.ravel(), pixuv, mode, ur, vr, ur2, vr2, C.byref(dT))
+    shp = u.shape
+    return ur.reshape(shp), vr.reshape(shp), ur2.reshape(shp), vr2.reshape(shp), dT.value, moved

@@ -1,0 +1,635 @@
+/*
+ * vof_oracle.c -- CPU restatement of OCTANE's dense variational optical-flow solver.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker for the HIP path in
+ * octane_amd/csrc; nothing under octane_amd/ may link, import or call it.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * PARITY STATUS: "parity unpinned" for the whole solver.  The reference
+ * (JasonApke/OCTANE) ships no tests, golden vectors or sample data, and its
+ * solver translation unit (src/oct_variational_optical_flow.cu) needs the CUDA
+ * toolkit headers (cooperative_groups.h, cuda runtime), which this image lacks;
+ * building it would need stand-in headers, so it is treated as unbuildable.
+ * Partial pins that DO exist (see tests/test_oracle_pins.py):
+ *   - the Catmull-Rom bicubic, the Gaussian taps and the dropped-tap blur are
+ *     cross-checked against the reference's own CPU helpers (oct_bicubic.cc,
+ *     oct_gaussian.cc) compiled unmodified into oracle/_ref/ (oracle/Makefile);
+ *   - the interior-mean flows the survey recorded from the reference on the
+ *     synthetic S1 scene are reproduced.
+ *
+ * What is restated: one sequential schedule (one "thread") of the reference's
+ * persistent kernel octConjugateGradient (.cu:468-1211) and its host wrapper
+ * (.cu:1213-1473), operation for operation, with the same float/double
+ * promotion points, the same explicitly assembled CSR matrix, the same
+ * Jacobi-preconditioned CG including its redundant products.  Every function
+ * cites the reference lines it follows ("ref .cu:a-b" means
+ * src/oct_variational_optical_flow.cu in /root/reference).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; a second flavour with
+ * -mfma -ffp-contract=fast estimates the FMA-contraction noise floor).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "vof_oracle.h"
+
+/* ---------------------------------------------------------------- helpers */
+
+/* ref .cu:26-41 oct_bc_cu: clamp (not reflect) to [0, n-1]; reports a hit. */
+static float clamp_coord(float x, int n, int *hit)
+{
+    *hit = 0;
+    if (x < 0) { x = 0; *hit = 1; }
+    if (x >= n) { x = (float)(n - 1); *hit = 1; }
+    return x;
+}
+
+static float sqf(float x) { return x * x; } /* ref .cu:43-47 jsq */
+
+/* ref .cu:49-54 zoom_size (factor is a float promoted to double at the call) */
+void oct_oracle_level_dims(int nx, int ny, float factor, int *lx, int *ly)
+{
+    double f = (double)factor;
+    *lx = (int)((double)nx * f + 0.5);
+    *ly = (int)((double)ny * f + 0.5);
+}
+
+/* ref .cu:488: factor = pow(scaleFactor, kiters-k-1), float <- double */
+float oct_oracle_level_factor(float scale, int kiters, int k)
+{
+    return (float)pow((double)scale, (double)(kiters - k - 1));
+}
+
+/* ref .cu:521-526: blur half-window for a level */
+int oct_oracle_blur_halfwidth(float factor)
+{
+    float sigma = (float)(1.0 / sqrt(2. * (double)factor));
+    int fs = (int)(2 * sigma);
+    if (fs < 5) fs = 5;
+    return fs;
+}
+
+/* ref .cu:207-228 fill_GK: 2*fs+1 taps normalised over all of them. */
+void oct_oracle_gauss_taps(float factor, int fs, float *gk)
+{
+    float sigma, r, s;
+    float sum = 0.0f;
+    sigma = (float)(0.6 * sqrt(1.0 / (double)(factor * factor) - 1.0));
+    s = (float)(2.0 * (double)sigma * (double)sigma);
+    for (int x = -fs; x <= fs; x++) {
+        r = (float)x;
+        gk[x + fs] = (float)((double)expf(-(r * r) / s) / (3.14159265358979323846 * (double)s));
+        sum += gk[x + fs];
+    }
+    for (int i = 0; i < 2 * fs + 1; ++i) gk[i] /= sum;
+}
+
+/* ref .cu:311-329 convh: taps -fs .. fs-1 (the last tap is never applied). */
+void oct_oracle_blur_rows(const float *in, float *out, const float *gk, int nx, int ny, int nc, int fs)
+{
+    long plane = (long)nx * ny;
+    for (long q = 0; q < plane * nc; q++) {
+        long within = q % plane;
+        int i = (int)(within % nx);
+        float acc = 0;
+        for (int t = -fs; t < fs; ++t) {
+            int hit;
+            int src = (int)clamp_coord((float)i + t, nx, &hit);
+            acc = acc + gk[t + fs] * in[q + (src - i)];
+        }
+        out[q] = acc;
+    }
+}
+
+/* ref .cu:331-351 convv */
+void oct_oracle_blur_cols(const float *in, float *out, const float *gk, int nx, int ny, int nc, int fs)
+{
+    long plane = (long)nx * ny;
+    for (long q = 0; q < plane * nc; q++) {
+        long within = q % plane;
+        int i = (int)(within % nx);
+        int j = (int)((within - i) / nx);
+        float acc = 0;
+        for (int t = -fs; t < fs; ++t) {
+            int hit;
+            int src = (int)clamp_coord((float)j + t, ny, &hit);
+            acc = acc + gk[t + fs] * in[q + (long)nx * (src - j)];
+        }
+        out[q] = acc;
+    }
+}
+
+/* ref .cu:230-239 oct_cell_cu: Catmull-Rom in double (double literals), float out */
+static float cubic1d(const float v[4], float x)
+{
+    double xd = (double)x;
+    double inner3 = 3.0 * (double)(v[1] - v[2]) + (double)v[3] - (double)v[0];
+    double inner2 = 2.0 * (double)v[0] - 5.0 * (double)v[1] + 4.0 * (double)v[2] - (double)v[3] + xd * inner3;
+    double inner1 = (double)(v[2] - v[0]) + xd * inner2;
+    return (float)((double)v[1] + 0.5 * xd * inner1);
+}
+
+/* ref .cu:257-309 oct_bicubic_cu (+ .cu:241-255): indices truncate toward zero
+ * and are then clamped; the fraction is taken against the clamped index. */
+float oct_oracle_bicubic(const float *src, float uu, float vv, int nx, int ny)
+{
+    int hit;
+    int xs[4], ys[4];
+    xs[1] = (int)clamp_coord((float)((int)uu), nx, &hit);
+    ys[1] = (int)clamp_coord((float)((int)vv), ny, &hit);
+    xs[0] = (int)clamp_coord((float)((int)(uu - 1)), nx, &hit);
+    ys[0] = (int)clamp_coord((float)((int)(vv - 1)), ny, &hit);
+    xs[2] = (int)clamp_coord((float)((int)(uu + 1)), nx, &hit);
+    ys[2] = (int)clamp_coord((float)((int)(vv + 1)), ny, &hit);
+    xs[3] = (int)clamp_coord((float)((int)(uu + 2)), nx, &hit);
+    ys[3] = (int)clamp_coord((float)((int)(vv + 2)), ny, &hit);
+    float col[4];
+    for (int a = 0; a < 4; a++) {
+        float along_y[4];
+        for (int b = 0; b < 4; b++) along_y[b] = src[xs[a] + nx * ys[b]];
+        col[a] = cubic1d(along_y, vv - ys[1]);
+    }
+    return cubic1d(col, uu - xs[1]);
+}
+
+/* ref .cu:353-408 zoom_out: sample the blurred full-res image at integer
+ * coordinates (int)(ii/factor) through the bicubic. */
+void oct_oracle_decimate(const float *blurred, float *out, int nx, int ny, int nc, float factor)
+{
+    int lx = (int)((double)nx * factor + 0.5);
+    int ly = (int)((double)ny * factor + 0.5);
+    long lplane = (long)lx * ly;
+    for (long q = 0; q < lplane * nc; q++) {
+        int c = (int)(q / lplane);
+        long within = q - c * lplane;
+        int ii = (int)(within % lx);
+        int jj = (int)((within - ii) / lx);
+        int i2 = (int)(ii / factor);
+        int j2 = (int)(jj / factor);
+        /* QUIRK kept on purpose: ref .cu:406 passes the base of the blurred
+         * array, not channel c's plane, so every channel of a decimated level
+         * is a sample of channel 0.  (c is computed at ref .cu:365 and unused.) */
+        (void)c;
+        out[q] = oct_oracle_bicubic(blurred, (float)i2, (float)j2, nx, ny);
+    }
+}
+
+/* ref .cu:410-449 oct_compgrad_cu: 4th-order central differences, clamp BC,
+ * evaluated in double because of the 8. and 12.0 literals. */
+void oct_oracle_gradient(const float *f, float *gx, float *gy, int xi, int yi, int nc)
+{
+    long plane = (long)xi * yi;
+    for (long q = 0; q < plane * nc; q++) {
+        int c = (int)(q / plane);
+        long within = q - c * plane;
+        int i = (int)(within % xi);
+        int j = (int)((within - i) / xi);
+        long base = plane * c;
+        long row = (long)xi * j;
+        int hit;
+        int jp1 = (int)clamp_coord((float)j + 1, yi, &hit);
+        int jp2 = (int)clamp_coord((float)j + 2, yi, &hit);
+        int jm1 = (int)clamp_coord((float)j - 1, yi, &hit);
+        int jm2 = (int)clamp_coord((float)j - 2, yi, &hit);
+        int ip1 = (int)clamp_coord((float)i + 1, xi, &hit);
+        int ip2 = (int)clamp_coord((float)i + 2, xi, &hit);
+        int im1 = (int)clamp_coord((float)i - 1, xi, &hit);
+        int im2 = (int)clamp_coord((float)i - 2, xi, &hit);
+        gx[q] = (float)(((double)(-f[ip2 + row + base]) + 8. * (double)f[ip1 + row + base]
+                         - 8. * (double)f[im1 + row + base] + (double)f[im2 + row + base]) / 12.0);
+        gy[q] = (float)(((double)(-f[i + (long)xi * jp2 + base]) + 8. * (double)f[i + (long)xi * jp1 + base]
+                         - 8. * (double)f[i + (long)xi * jm1 + base] + (double)f[i + (long)xi * jm2 + base]) / 12.0);
+    }
+}
+
+/* ref .cu:452-466 zoom_in: bicubic up-sample of a flow component, divided by sf */
+void oct_oracle_upsample_flow(const float *coarse, float *fine, int nx, int ny, int nxx, int nyy, float sf)
+{
+    const float fx = ((float)nxx / nx);
+    const float fy = ((float)nyy / ny);
+    for (long q = 0; q < (long)nxx * nyy; q++) {
+        int ii = (int)(q % nxx);
+        int jj = (int)((q - ii) / nxx);
+        float i2 = (float)((double)(ii / fx) - (0.5 - 0.5 / (double)fx));
+        float j2 = (float)((double)(jj / fy) - (0.5 - 0.5 / (double)fy));
+        fine[q] = oct_oracle_bicubic(coarse, i2, j2, nx, ny) / sf;
+    }
+}
+
+/* ref .cu:73-86 oct_PSI_smooth_cu with doq==0 */
+static float psi_smooth(float x)
+{
+    return (float)(1. / (double)sqrtf((float)((double)x + 1E-6)));
+}
+
+/* ref .cu:96-108 oct_PSI_data_cu with doq==0 */
+static float psi_data(float x)
+{
+    return (float)(1. / sqrt((double)x + 1E-6));
+}
+
+/* Number of stored non-zeros in all matrix rows that precede the u-row of
+ * pixel n=(ii,jj).  Restates the closed form of ref .cu:868-913 by counting,
+ * per preceding pixel, which of the six possible entries each of its two rows
+ * holds: south (j>0), west (i>0), the 2 block entries, east (i<xi-1), north
+ * (j<yi-1). */
+long oct_oracle_nnz_before(long n, int ii, int jj, int xi, int yi)
+{
+    long south = (jj > 0) ? n - xi : 0;
+    long west = n - jj - (ii > 0 ? 1 : 0);
+    long block = 2 * n;
+    long east = n - jj;
+    long north = (jj < yi - 1) ? n : (long)xi * yi - xi;
+    return 2 * (south + west + block + east + north);
+}
+
+/* One linearisation: fills the CSR matrix, the Jacobi diagonal and the rhs for
+ * the flow (u,v) at GNC weight al1.  ref .cu:611-1097 (dodiscrete == false). */
+void oct_oracle_assemble(const oct_oracle_level *L, const float *u, const float *v,
+                         const float *ut, const float *vt, double al1, double alpha,
+                         double lambda_over_alpha, float lambdac, int dozim,
+                         oct_oracle_system *S, oct_oracle_planes *P)
+{
+    const int xi = L->xi, yi = L->yi, nc = L->nc;
+    const long npix = (long)xi * yi;
+    const int xi2 = 2 * xi;
+    for (long n = 0; n < npix; n++) {
+        int ii = (int)(n % xi);
+        int jj = (int)((n - ii) / xi);
+        /* neighbour indices with the mirror fix-up of ref .cu:613-652 */
+        long e = n + 1, w = n - 1;
+        long ne = e + xi, se = e - xi, no = n + xi, so = n - xi, nw = w + xi, sw = w - xi;
+        if (ii == 0) { w += 2; nw += 2; sw += 2; }
+        if (ii == xi - 1) { e -= 2; ne -= 2; se -= 2; }
+        if (jj == 0) { se += xi2; so += xi2; sw += xi2; }
+        if (jj == yi - 1) { ne -= xi2; no -= xi2; nw -= xi2; }
+
+        float ue = u[e], uc = u[n], une = u[ne], use = u[se], un = u[no], us = u[so];
+        float unw = u[nw], uw = u[w], usw = u[sw];
+        float ve = v[e], vc = v[n], vne = v[ne], vse = v[se], vn = v[no], vs = v[so];
+        float vnw = v[nw], vw = v[w], vsw = v[sw];
+
+        /* ref .cu:680-683 */
+        float Ue = sqf(ue - uc) + sqf((float)(0.25 * (double)((une - use) + (un - us))))
+                 + sqf(ve - vc) + sqf((float)(0.25 * (double)((vne - vse) + (vn - vs))));
+        float Uw = sqf(uc - uw) + sqf((float)(0.25 * (double)((unw - usw) + (un - us))))
+                 + sqf(vc - vw) + sqf((float)(0.25 * (double)((vnw - vsw) + (vn - vs))));
+        float Un = sqf(un - uc) + sqf((float)(0.25 * (double)((une - unw) + (ue - uw))))
+                 + sqf(vn - vc) + sqf((float)(0.25 * (double)((vne - vnw) + (ve - vw))));
+        float Us = sqf(uc - us) + sqf((float)(0.25 * (double)((use - usw) + (ue - uw))))
+                 + sqf(vc - vs) + sqf((float)(0.25 * (double)((vse - vsw) + (ve - vw))));
+
+        /* ref .cu:714-724 */
+        float ps1 = psi_smooth(Uw), ps2 = psi_smooth(Us), ps3 = psi_smooth(Ue), ps4 = psi_smooth(Un);
+        float pstot = ps1 + ps2 + ps3 + ps4;
+        float pstotq = 4.f;
+        float snu = ps1 * uw + ps2 * us + ps3 * ue + ps4 * un;
+        float snv = ps1 * vw + ps2 * vs + ps3 * ve + ps4 * vn;
+        float snuq = uw + us + ue + un;
+        float snvq = vw + vs + ve + vn;
+
+        /* ref .cu:727-747 warped sampling position */
+        float t1 = 0, t2 = 0, t4 = 0, t5 = 0, t6 = 0, e1 = 0;
+        float g1 = 0, g2s = 0, g4 = 0, g5 = 0, g6 = 0, e2 = 0;
+        int hitx, hity;
+        float xw = clamp_coord((float)(ii + uc), xi, &hitx);
+        float yw = clamp_coord((float)(jj + vc), yi, &hity);
+        int x0 = (int)xw, y0 = (int)yw;
+        if (x0 == xi - 1) x0 = xi - 2;
+        if (y0 == yi - 1) y0 = yi - 2;
+        long rowbase = (long)xi * y0;
+
+        for (int c = 0; c < nc; c++) {
+            long cb = npix * c;
+            long here = ii + (long)xi * jj + cb;
+            long c1 = x0 + rowbase + cb, c2 = c1 + 1, c3 = c1 + xi, c4 = c3 + 1;
+            /* ref .cu:56-71 bilinear weights */
+            float fx1 = (float)x0, fx2 = (float)(x0 + 1), fy1 = (float)y0, fy2 = (float)(y0 + 1);
+            float p1 = (fx2 - xw) / (fx2 - fx1);
+            float p2 = (xw - fx1) / (fx2 - fx1);
+            float p3 = ((fy2 - yw) / (fy2 - fy1));
+            float p4 = ((yw - fy1) / (fy2 - fy1));
+#define BIL(F) (p3 * ((p1) * (F)[c1] + (p2) * (F)[c2]) + p4 * ((p1) * (F)[c3] + (p2) * (F)[c4]))
+            float w2 = BIL(L->img2);
+            float Ix = BIL(L->gx2);
+            float Iy = BIL(L->gy2);
+            float Ixx = BIL(L->gxx);
+            float Ixy = BIL(L->gxy);
+            float Iyy = BIL(L->gyy);
+#undef BIL
+            if (hitx) { Ix = 0.f; Ixx = 0.f; Ixy = 0.f; }
+            if (hity) { Iy = 0.f; Ixy = 0.f; Iyy = 0.f; }
+            /* ref .cu:782-828 */
+            float It = w2 - L->img1[here];
+            float Ixt = Ix - L->gx1[here];
+            float Iyt = Iy - L->gy1[here];
+            float IxIx = Ix * Ix, IyIy = Iy * Iy, IxxIxx = Ixx * Ixx, IxyIxy = Ixy * Ixy, IyyIyy = Iyy * Iyy;
+            float na, nb, ncc;
+            if (dozim) {
+                na = (float)(1. / ((double)(IxIx + IyIy) + 1.));
+                nb = (float)(1. / ((double)(IxxIxx + IxyIxy) + 1.));
+                ncc = (float)(1. / ((double)(IxyIxy + IyyIyy) + 1.));
+            } else {
+                na = 1.f; nb = 1.f; ncc = 1.f;
+            }
+            e1 += na * It * It;
+            e2 += (nb * Ixt * Ixt + ncc * Iyt * Iyt);
+            t1 += (na * IxIx);
+            g1 += (nb * IxxIxx + ncc * IxyIxy);
+            t2 += na * Ix * Iy;
+            g2s += (nb * Ixx * Ixy + ncc * Iyy * Ixy);
+            t4 += (na * IyIy);
+            g4 += ((nb * IxyIxy + ncc * IyyIyy));
+            float naIt = -na * It;
+            float nbIxt = nb * Ixt;
+            float ncIyt = ncc * Iyt;
+            t5 += naIt * Ix;
+            g5 += -(nbIxt * Ixx + ncIyt * Ixy);
+            t6 += naIt * Iy;
+            g6 += -(nbIxt * Ixy + ncIyt * Iyy);
+        }
+        /* ref .cu:831-864 */
+        float pd = (float)((double)psi_data(e1) / alpha);
+        float pd2 = (float)(lambda_over_alpha * (double)psi_data(e2));
+        float a1 = (float)((al1) * ((double)t1 / alpha + lambda_over_alpha * (double)g1 + (double)lambdac + (double)pstotq)
+                           + (1 - al1) * (double)(pd * t1 + pd2 * g1 + lambdac + pstot));
+        float a2 = (float)((al1) * ((double)t2 / alpha + lambda_over_alpha * (double)g2s)
+                           + (1 - al1) * (double)(pd * t2 + pd2 * g2s));
+        float a4 = (float)((al1) * ((double)t4 / alpha + lambda_over_alpha * (double)g4 + (double)lambdac + (double)pstotq)
+                           + (1 - al1) * (double)(pd * t4 + pd2 * g4 + lambdac + pstot));
+        float a5 = (float)(-1 * (al1 + (1 - al1) * (double)ps1)); /* west  */
+        float a6 = (float)(-1 * (al1 + (1 - al1) * (double)ps2)); /* south */
+        float a7 = (float)(-1 * (al1 + (1 - al1) * (double)ps3)); /* east  */
+        float a8 = (float)(-1 * (al1 + (1 - al1) * (double)ps4)); /* north */
+
+        /* CSR fill, ref .cu:868-1077 */
+        long pos = oct_oracle_nnz_before(n, ii, jj, xi, yi);
+        long ru = 2 * n; /* unknown index of du at this pixel; dv is ru+1 */
+        long cw = ru - 2, cs = ru - xi2, ce = ru + 2, cn = ru + xi2;
+        if (ii == 0) cw += 4;
+        if (jj == 0) cs += (xi2 + xi2);
+        if (ii == xi - 1) ce -= 4;
+        if (jj == yi - 1) cn -= (xi2 + xi2);
+        for (int comp = 0; comp < 2; comp++) {
+            long r = ru + comp;
+            int started = 0;
+            if (jj > 0) {
+                S->val[pos] = (jj < yi - 1) ? a6 : a6 + a8;
+                S->row[pos] = (int)r; S->col[pos] = (int)(cs + comp);
+                S->rowptr[r] = (int)pos; started = 1; pos++;
+            }
+            if (ii > 0) {
+                S->val[pos] = (ii < xi - 1) ? a5 : a5 + a7;
+                S->row[pos] = (int)r; S->col[pos] = (int)(cw + comp);
+                if (!started) { S->rowptr[r] = (int)pos; started = 1; }
+                pos++;
+            }
+            /* the 2x2 block: (a1 a2) for the du row, (a2 a4) for the dv row */
+            if (!started) { S->rowptr[r] = (int)pos; started = 1; }
+            if (comp == 0) {
+                S->val[pos] = a1; S->row[pos] = (int)r; S->col[pos] = (int)ru; pos++;
+                S->val[pos] = a2; S->row[pos] = (int)r; S->col[pos] = (int)(ru + 1); pos++;
+                S->diag[ru] = a1;
+            } else {
+                S->val[pos] = a2; S->row[pos] = (int)r; S->col[pos] = (int)ru; pos++;
+                S->val[pos] = a4; S->row[pos] = (int)r; S->col[pos] = (int)(ru + 1); pos++;
+                S->diag[ru + 1] = a4;
+            }
+            if (ii < xi - 1) {
+                S->val[pos] = (ii > 0) ? a7 : a7 + a5;
+                S->row[pos] = (int)r; S->col[pos] = (int)(ce + comp); pos++;
+            }
+            if (jj < yi - 1) {
+                S->val[pos] = (jj > 0) ? a8 : a8 + a6;
+                S->row[pos] = (int)r; S->col[pos] = (int)(cn + comp); pos++;
+            }
+        }
+        /* rhs, ref .cu:1087-1092 */
+        float hint = lambdac * (u[n] - ut[n]);
+        S->rhs[ru] = (float)(al1 * ((double)t5 / alpha + lambda_over_alpha * (double)g5 - (double)hint + (double)snuq - (double)(pstotq * u[n]))
+                             + (1. - al1) * (double)(pd * t5 + pd2 * g5 - hint + snu - pstot * u[n]));
+        hint = lambdac * (v[n] - vt[n]);
+        S->rhs[ru + 1] = (float)(al1 * ((double)t6 / alpha + lambda_over_alpha * (double)g6 - (double)hint + (double)snvq - (double)(pstotq * v[n]))
+                                 + (1 - al1) * (double)(pd * t6 + pd2 * g6 - hint + snv - pstot * v[n]));
+        if (P) { /* per-pixel coefficient planes, for the matrix-free HIP path's tests */
+            P->a1[n] = a1; P->a2[n] = a2; P->a4[n] = a4;
+            P->a5[n] = a5; P->a6[n] = a6; P->a7[n] = a7; P->a8[n] = a8;
+            P->bu[n] = S->rhs[ru]; P->bv[n] = S->rhs[ru + 1];
+        }
+    }
+}
+
+/* ref .cu:111-139 multiply_row + jMatXVec */
+void oct_oracle_spmv(const float *val, const int *rowptr, const int *col, const float *x,
+                     long nnz, int nrows, float *y)
+{
+    for (int k = 0; k < nrows; k++) {
+        int b = rowptr[k];
+        int e = (k < nrows - 1) ? rowptr[k + 1] : (int)nnz;
+        float sum = 0;
+        for (int i = b; i < e; i++) sum += val[i] * x[col[i]];
+        y[k] = sum;
+    }
+}
+
+/* ref .cu:151-186 jVecXVec under a one-thread schedule: plain running sum */
+static float dotf(const float *a, const float *b, int n)
+{
+    float s = 0.0f;
+    for (int i = 0; i < n; i++) s += (float)(a[i] * b[i]);
+    return s;
+}
+
+/* ref .cu:198-205 jVecPVec: c = d*a + b */
+static void axpy(const float *a, const float *b, float *c, float d, int n)
+{
+    for (int k = 0; k < n; k++) c[k] = d * a[k] + b[k];
+}
+
+/* Jacobi-PCG exactly as ref .cu:1105-1182, including the product with x0 (all
+ * zeros), the duplicated A*p and the five dot products.  Returns iterations. */
+int oct_oracle_pcg(oct_oracle_system *S, float *x, float tol, int maxit, oct_oracle_cgwork *W)
+{
+    const int n = S->nrows;
+    float *b = S->rhs, *M = S->diag, *z = W->z, *p = W->p, *rk = W->rk, *tmp = W->tmp;
+    int *ident = W->ident;
+    oct_oracle_spmv(S->val, S->rowptr, S->col, x, S->nnz, n, tmp);
+    for (int i = 0; i < n; i++) b[i] = b[i] - tmp[i];
+    for (int k = 0; k < n; k++) M[k] = (float)(1. / (double)M[k]);       /* ref .cu:141-149 */
+    for (int k = 0; k < n; k++) ident[k] = k;                           /* Mrow, ref .cu:973,1052 */
+    oct_oracle_spmv(M, ident, ident, b, n, n, z);                       /* ref .cu:1117 */
+    for (int j = 0; j < n; j++) p[j] = z[j];
+    float resid = dotf(b, b, n);
+    int ki = 0;
+    while ((resid > tol) && (ki < maxit)) {
+        if (ki > 0) {
+            float zr_old = dotf(z, b, n);
+            oct_oracle_spmv(M, ident, ident, rk, n, n, z);
+            float zr_new = dotf(z, rk, n);
+            float beta = zr_new / zr_old;
+            axpy(p, z, p, beta, n);
+            for (int j = 0; j < n; j++) b[j] = rk[j];
+        }
+        float rz = dotf(b, z, n);
+        oct_oracle_spmv(S->val, S->rowptr, S->col, p, S->nnz, n, tmp);
+        float pAp = dotf(p, tmp, n);
+        float a = rz / pAp;
+        oct_oracle_spmv(S->val, S->rowptr, S->col, p, S->nnz, n, tmp);
+        axpy(p, x, x, a, n);
+        axpy(tmp, b, rk, (float)(-1. * (double)a), n);
+        resid = dotf(rk, rk, n);
+        ki++;
+    }
+    return ki;
+}
+
+/* ------------------------------------------------------------ full solver */
+
+static void emit(const oct_oracle_trace *tr, const char *tag, int k, int gnc, int l,
+                 const float *data, int nx, int ny, int nplanes)
+{
+    if (tr && tr->cb) tr->cb(tr->user, tag, k, gnc, l, data, nx, ny, nplanes);
+}
+
+/* ref .cu:1213-1473 (host wrapper) driving ref .cu:468-1211 (kernel body). */
+int oct_oracle_vof(const float *img1, const float *img2, int nx, int ny, int nc,
+                   float *uio, float *vio, const oct_oracle_params *prm, const oct_oracle_trace *tr)
+{
+    const long n0 = (long)nx * ny;
+    const double alpha = prm->alpha;
+    const double loa = prm->lambda / alpha;                 /* ref .cu:1230 */
+    const float lambdaco = (float)(prm->lambdac / alpha);   /* ref .cu:1236 */
+    const float scale = (float)prm->scaleF;                 /* ref .cu:1241 */
+    const int kiters = prm->kiters, liters = prm->liters, cgiters = prm->cgiters;
+    const float tol = (float)(0.0001 * 0.0001);             /* ref .cu:1353 */
+    if (nx < 1 || ny < 1 || nc < 1 || kiters < 1) return -1;
+
+    float *lev1 = malloc(sizeof(float) * n0 * nc), *lev2 = malloc(sizeof(float) * n0 * nc);
+    float *scratch = malloc(sizeof(float) * n0 * (nc < 2 ? 2 : nc));
+    float *gx1 = malloc(sizeof(float) * n0 * nc), *gy1 = malloc(sizeof(float) * n0 * nc);
+    float *gx2 = malloc(sizeof(float) * n0 * nc), *gy2 = malloc(sizeof(float) * n0 * nc);
+    float *gxx = malloc(sizeof(float) * n0 * nc), *gxy = malloc(sizeof(float) * n0 * nc);
+    float *gyy = malloc(sizeof(float) * n0 * nc);
+    float *u = malloc(sizeof(float) * n0), *v = malloc(sizeof(float) * n0);
+    float *ut = malloc(sizeof(float) * n0), *vt = malloc(sizeof(float) * n0);
+    float *uh = malloc(sizeof(float) * n0), *vh = malloc(sizeof(float) * n0);
+    long nnz0 = 12 * n0 - 4 * nx - 4 * ny;
+    if (nnz0 < 12) nnz0 = 12;
+    oct_oracle_system S;
+    S.val = malloc(sizeof(float) * nnz0); S.row = malloc(sizeof(int) * nnz0); S.col = malloc(sizeof(int) * nnz0);
+    S.rowptr = malloc(sizeof(int) * 2 * n0); S.diag = malloc(sizeof(float) * 2 * n0); S.rhs = malloc(sizeof(float) * 2 * n0);
+    oct_oracle_cgwork W;
+    W.z = malloc(sizeof(float) * 2 * n0); W.p = malloc(sizeof(float) * 2 * n0); W.rk = malloc(sizeof(float) * 2 * n0);
+    W.tmp = malloc(sizeof(float) * 2 * n0); W.ident = malloc(sizeof(int) * 2 * n0);
+    float *x = calloc(2 * n0, sizeof(float));
+    float gk[2 * 512 + 1];
+    long total_cg = 0;
+
+    /* ref .cu:1330-1352 */
+    memcpy(u, uio, sizeof(float) * n0); memcpy(v, vio, sizeof(float) * n0);
+    memcpy(uh, uio, sizeof(float) * n0); memcpy(vh, vio, sizeof(float) * n0);
+
+    int xi = 0, yi = 0, xio = 0, yio = 0;
+    for (int k = 0; k < kiters; k++) {
+        float factor = oct_oracle_level_factor(scale, kiters, k);
+        oct_oracle_level_dims(nx, ny, factor, &xi, &yi);
+        if (xi < 2 || yi < 2) { total_cg = -2; break; }  /* reference indexes out of bounds here */
+        long npix = (long)xi * yi;
+        float lambdac = (float)((double)lambdaco * pow(0.5, (double)k));   /* ref .cu:494 */
+
+        if (k > 0) { /* ref .cu:498-503: previous level's flow lives in ut/vt */
+            oct_oracle_upsample_flow(ut, u, xio, yio, xi, yi, scale);
+            oct_oracle_upsample_flow(vt, v, xio, yio, xi, yi, scale);
+        }
+        if (k == kiters - 1) { /* ref .cu:504-517 */
+            memcpy(lev1, img1, sizeof(float) * n0 * nc);
+            memcpy(lev2, img2, sizeof(float) * n0 * nc);
+            memcpy(ut, uh, sizeof(float) * npix);
+            memcpy(vt, vh, sizeof(float) * npix);
+        } else { /* ref .cu:519-563 */
+            int fs = oct_oracle_blur_halfwidth(factor);
+            if (fs > 512) { total_cg = -3; break; }
+            oct_oracle_gauss_taps(factor, fs, gk);
+            oct_oracle_blur_rows(img1, lev1, gk, nx, ny, nc, fs);
+            oct_oracle_blur_cols(lev1, scratch, gk, nx, ny, nc, fs);
+            oct_oracle_decimate(scratch, lev1, nx, ny, nc, factor);
+            oct_oracle_blur_rows(img2, lev2, gk, nx, ny, nc, fs);
+            oct_oracle_blur_cols(lev2, scratch, gk, nx, ny, nc, fs);
+            oct_oracle_decimate(scratch, lev2, nx, ny, nc, factor);
+            oct_oracle_blur_rows(uh, ut, gk, nx, ny, 1, fs);
+            oct_oracle_blur_cols(ut, scratch, gk, nx, ny, 1, fs);
+            oct_oracle_decimate(scratch, ut, nx, ny, 1, factor);
+            oct_oracle_blur_rows(vh, vt, gk, nx, ny, 1, fs);
+            oct_oracle_blur_cols(vt, scratch, gk, nx, ny, 1, fs);
+            oct_oracle_decimate(scratch, vt, nx, ny, 1, factor);
+            for (long q = 0; q < npix; q++) { ut[q] *= factor; vt[q] *= factor; }
+        }
+        if (k == 0) { /* ref .cu:576-585 */
+            memcpy(u, ut, sizeof(float) * npix);
+            memcpy(v, vt, sizeof(float) * npix);
+        }
+        /* ref .cu:587-595; the fourth call overwrites gxy, so Ixy = d/dx(Iy) */
+        oct_oracle_gradient(lev1, gx1, gy1, xi, yi, nc);
+        oct_oracle_gradient(lev2, gx2, gy2, xi, yi, nc);
+        oct_oracle_gradient(gx2, gxx, gxy, xi, yi, nc);
+        oct_oracle_gradient(gy2, gxy, gyy, xi, yi, nc);
+
+        emit(tr, "img1", k, -1, -1, lev1, xi, yi, nc);
+        emit(tr, "img2", k, -1, -1, lev2, xi, yi, nc);
+        emit(tr, "gx1", k, -1, -1, gx1, xi, yi, nc);
+        emit(tr, "gy1", k, -1, -1, gy1, xi, yi, nc);
+        emit(tr, "gx2", k, -1, -1, gx2, xi, yi, nc);
+        emit(tr, "gy2", k, -1, -1, gy2, xi, yi, nc);
+        emit(tr, "gxx", k, -1, -1, gxx, xi, yi, nc);
+        emit(tr, "gxy", k, -1, -1, gxy, xi, yi, nc);
+        emit(tr, "gyy", k, -1, -1, gyy, xi, yi, nc);
+        emit(tr, "u0", k, -1, -1, u, xi, yi, 1);
+        emit(tr, "v0", k, -1, -1, v, xi, yi, 1);
+        emit(tr, "ut", k, -1, -1, ut, xi, yi, 1);
+        emit(tr, "vt", k, -1, -1, vt, xi, yi, 1);
+
+        oct_oracle_level L = { xi, yi, nc, lev1, lev2, gx1, gy1, gx2, gy2, gxx, gxy, gyy };
+        S.nrows = (int)(2 * npix);                       /* ref .cu:598 */
+        S.nnz = 12 * npix - 4 * xi - 4 * yi;             /* ref .cu:600 */
+        oct_oracle_planes P;
+        float *pl = NULL;
+        if (tr && tr->cb) {
+            pl = malloc(sizeof(float) * 9 * npix);
+            P.a1 = pl; P.a2 = pl + npix; P.a4 = pl + 2 * npix; P.a5 = pl + 3 * npix; P.a6 = pl + 4 * npix;
+            P.a7 = pl + 5 * npix; P.a8 = pl + 6 * npix; P.bu = pl + 7 * npix; P.bv = pl + 8 * npix;
+        }
+        for (int gnc = 0; gnc < 3; gnc++) {              /* ref .cu:604-606 */
+            double al1 = 1. - 0.5 * gnc;
+            for (int l = 0; l < liters; l++) {
+                oct_oracle_assemble(&L, u, v, ut, vt, al1, alpha, loa, lambdac, (prm->dozim != 0), &S, pl ? &P : NULL);
+                if (pl) emit(tr, "coef", k, gnc, l, pl, xi, yi, 9);
+                int its = oct_oracle_pcg(&S, x, tol, cgiters, &W);
+                total_cg += its;
+                if (pl) emit(tr, "dx", k, gnc, l, x, 2 * xi, yi, 1);
+                for (long q = 0; q < npix; q++) {        /* ref .cu:1185-1195 */
+                    u[q] = u[q] + x[2 * q];
+                    v[q] = v[q] + x[2 * q + 1];
+                    x[2 * q] = 0.f; x[2 * q + 1] = 0.f;
+                }
+                if (pl) { emit(tr, "u", k, gnc, l, u, xi, yi, 1); emit(tr, "v", k, gnc, l, v, xi, yi, 1); }
+            }
+        }
+        free(pl);
+        emit(tr, "ulev", k, -1, -1, u, xi, yi, 1);
+        emit(tr, "vlev", k, -1, -1, v, xi, yi, 1);
+        memcpy(ut, u, sizeof(float) * npix);             /* ref .cu:1201-1205 */
+        memcpy(vt, v, sizeof(float) * npix);
+        xio = xi; yio = yi;
+    }
+    if (total_cg >= 0) { /* ref .cu:1434-1438 */
+        memcpy(uio, u, sizeof(float) * n0);
+        memcpy(vio, v, sizeof(float) * n0);
+    }
+    free(lev1); free(lev2); free(scratch); free(gx1); free(gy1); free(gx2); free(gy2);
+    free(gxx); free(gxy); free(gyy); free(u); free(v); free(ut); free(vt); free(uh); free(vh);
+    free(S.val); free(S.row); free(S.col); free(S.rowptr); free(S.diag); free(S.rhs);
+    free(W.z); free(W.p); free(W.rk); free(W.tmp); free(W.ident); free(x);
+    return (int)(total_cg > 2000000000L ? 2000000000L : total_cg);
+}
