@@ -1,0 +1,128 @@
+/*
+ * octane_vof.h -- C-ABI of the MI355X-native dense variational optical-flow core.
+ *
+ * This is the drop-in boundary for OCTANE's hot path.  Plain pointers and sizes
+ * only; no C++ types, no torch types, no exceptions cross it.  Every entry point
+ * returns 0 on success or a negative OCTANE_E_* code.  The library is
+ * liboctane_vof.so (octane_amd/csrc/Makefile).  The C++ shims that keep the
+ * reference's own signatures (Image / OFFlags / GOESVar by value or reference)
+ * live in include/octane_host.hpp and forward here.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   octane_vof_run            <- void oct_variational_optical_flow(Image,Image,float*,float*,float*,int,int,int,OFFlags)
+ *                                src/oct_variational_optical_flow.cu:1213 (declared by its caller at src/oct_optical_flow.cc:12)
+ *   octane_vof_plan_*         <- the per-call allocate / launch / free sequence of the same function
+ *                                (.cu:1268-1328 allocations, :1431 launch, :1441-1472 frees), split so that a
+ *                                caller can keep device state across image pairs
+ *   octane_vof_batch_run      <- (new) the reference is single-GPU: args.setdevice -> cudaSetDevice, .cu:1251-1265
+ *   octane_pix2uv_run         <- void oct_pix2uv_cuda(GOESVar&,double,float*,float*,short*,short*,short*,short*,OFFlags)
+ *                                src/oct_pix2uv_cuda.cu:265 (declared at src/oct_optical_flow.cc:15)
+ */
+#ifndef OCTANE_VOF_H
+#define OCTANE_VOF_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCTANE_OK            0
+#define OCTANE_E_INVALID    (-1)   /* bad argument (null pointer, non-positive size, nchan not in 1..3, ...) */
+#define OCTANE_E_NODEVICE   (-2)   /* no GPU visible (the reference prints a message and exit(0)s, .cu:1255-1259) */
+#define OCTANE_E_HIP        (-3)   /* a HIP runtime call failed; octane_last_error() has the text */
+#define OCTANE_E_TOOSMALL   (-4)   /* some pyramid level would be narrower than 2 pixels (reference indexes out of bounds there) */
+#define OCTANE_E_NOMEM      (-5)
+
+/* The OFFlags fields the solver reads (include/offlags.h; read at .cu:1229-1254). */
+typedef struct octane_vof_params {
+    double alpha;     /* -alpha   smoothness weight; data terms are divided by it (.cu:831-833) */
+    double lambda;    /* -lambda  gradient-constancy weight */
+    double lambdac;   /* -lambdac first-guess hinting weight (scaled by 0.5^level, .cu:494) */
+    double scaleF;    /* pyramid scale factor (0.5; not CLI-settable in the reference) */
+    double scsig;     /* read by the reference (.cu:1238) but only used when dodiscrete, which is hard-wired false */
+    int kiters;       /* -kiters  pyramid levels */
+    int liters;       /* -liters  re-linearisations per GNC step */
+    int cgiters;      /* PCG iteration cap per solve (OFFlags.cgiters, default 30) */
+    int dozim;        /* 1 = Zimmer normalisation (default), 0 = -brox */
+    int device;       /* OFFlags.setdevice (0-based); out-of-range falls back to 0 as at .cu:1260-1264 */
+} octane_vof_params;
+
+/* Fills *p with the defaults of the reference CLI (src/main.cc:78-96,102). */
+void octane_vof_default_params(octane_vof_params *p);
+
+/* One-shot solve on host buffers: allocate device state, upload, solve, download, free.
+ * img1/img2: nchan planes of ny rows of nx floats (Image.data[i + nx*j + nx*ny*c]).
+ * u_inout/v_inout: nx*ny floats each; in = first guess, out = flow in pixels.
+ * Caller keeps ownership of every pointer; inputs are not modified. */
+int octane_vof_run(const float *img1, const float *img2, int nx, int ny, int nchan,
+                   float *u_inout, float *v_inout, const octane_vof_params *p);
+
+/* Plan API: device state sized for (nx, ny, nchan, params) and reused across pairs. */
+typedef struct octane_vof_plan octane_vof_plan;
+
+int octane_vof_plan_create(octane_vof_plan **plan, int nx, int ny, int nchan, const octane_vof_params *p);
+int octane_vof_plan_destroy(octane_vof_plan *plan);
+size_t octane_vof_plan_device_bytes(const octane_vof_plan *plan);
+
+#define OCTANE_MEM_HOST   0
+#define OCTANE_MEM_DEVICE 1
+/* Solve one pair.  mem says where img1/img2/u/v live.  hip_stream is a hipStream_t (NULL = the
+ * plan's own stream).  With OCTANE_MEM_DEVICE the call only enqueues work on the stream and
+ * returns; with OCTANE_MEM_HOST it synchronises before returning. */
+int octane_vof_plan_run(octane_vof_plan *plan, const float *img1, const float *img2,
+                        float *u_inout, float *v_inout, int mem, void *hip_stream);
+
+/* Number of PCG iterations the last completed run executed (sum over all solves); blocks on the stream. */
+long long octane_vof_plan_last_iterations(octane_vof_plan *plan);
+
+/* Debug tap (NULL = off, zero cost): called on the host after each stage with a copy of the stage's
+ * planes: data is nplanes planes of ny rows of nx floats.  Tags match oracle/vof_oracle.c's trace. */
+typedef void (*octane_vof_trace_fn)(void *user, const char *tag, int level, int gnc, int l,
+                                    const float *data, int nx, int ny, int nplanes);
+int octane_vof_plan_set_trace(octane_vof_plan *plan, octane_vof_trace_fn fn, void *user);
+
+/* Per-kernel timing of the finest pyramid level, measured with HIP events on the run's stream. */
+typedef struct octane_vof_profile {
+    double pass_a_ms;  long long pass_a_launches;   /* PCG pass A: p = z + beta p, Ap, p.Ap      */
+    double pass_b_ms;  long long pass_b_launches;   /* PCG pass B: x += a p, r -= a Ap, r.z, r.r */
+    double assemble_ms; long long assemble_launches;
+    double update_ms;  long long update_launches;
+    double setup_ms;                                  /* all level-setup kernels, every level */
+    double total_ms;                                  /* whole run, first launch to last       */
+    long long finest_pixels;
+} octane_vof_profile;
+int octane_vof_plan_set_profiling(octane_vof_plan *plan, int enable);
+int octane_vof_plan_get_profile(octane_vof_plan *plan, octane_vof_profile *out);
+
+/* Independent pairs sharded over GPUs: pair b runs on devices[b % ndevices]; one host thread per
+ * device; no collective.  Pointer arrays have npairs entries of host buffers laid out as above. */
+int octane_vof_batch_run(int npairs, const float *const *img1, const float *const *img2,
+                         int nx, int ny, int nchan, float *const *u_inout, float *const *v_inout,
+                         const octane_vof_params *p, int ndevices, const int *devices);
+
+/* ---- pix2uv: pixel displacement -> navigated wind (cm/s as short) ---- */
+typedef struct octane_nav {      /* the GOESNAVVar fields oct_pix2uv_cuda.cu reads (include/goesread.h) */
+    double pph, req, rpol, lam0;
+    float xScale, xOffset, yScale, yOffset, g2xOffset, g2yOffset;
+    float lat1, lon1, lon0, R;
+    int minX, minY;
+    int nx, ny;
+} octane_nav;
+
+#define OCTANE_NAV_GEOS  0   /* GOES-R fixed grid (default)   */
+#define OCTANE_NAV_POLAR 1   /* -Polar                         */
+#define OCTANE_NAV_MERC  2   /* -Merc                          */
+/* Host buffers.  pixuv != 0 reproduces -pd (ur/vr = (short)(100*u), ur2/vr2 untouched).
+ * *sector_moved is set to 1 when the x/yOffset guard (oct_pix2uv_cuda.cu:295) zeroed the outputs. */
+int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, const float *u, const float *v,
+                      int pixuv, int mode, short *ur, short *vr, short *ur2, short *vr2,
+                      float *dT, int *sector_moved, int device);
+
+const char *octane_last_error(void);
+int octane_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,256 @@
+"""ctypes binding of the C-ABI in include/octane_vof.h (liboctane_vof.so).
+
+This is the product path seen from Python: every call goes through the HIP library.  There is
+no CPU fallback -- if the library is missing or no GPU is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboctane_vof.so")
+
+OK, E_INVALID, E_NODEVICE, E_HIP, E_TOOSMALL, E_NOMEM = 0, -1, -2, -3, -4, -5
+MEM_HOST, MEM_DEVICE = 0, 1
+NAV_GEOS, NAV_POLAR, NAV_MERC = 0, 1, 2
+
+# every symbol include/octane_vof.h declares
+EXPORTS = (
+    "octane_vof_default_params", "octane_vof_run", "octane_vof_plan_create", "octane_vof_plan_destroy",
+    "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_last_iterations",
+    "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile",
+    "octane_vof_batch_run", "octane_pix2uv_run", "octane_last_error", "octane_device_count",
+)
+
+
+class VofParams(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("lambda_", C.c_double), ("lambdac", C.c_double),
+                ("scaleF", C.c_double), ("scsig", C.c_double), ("kiters", C.c_int), ("liters", C.c_int),
+                ("cgiters", C.c_int), ("dozim", C.c_int), ("device", C.c_int)]
+
+
+class VofProfile(C.Structure):
+    _fields_ = [("pass_a_ms", C.c_double), ("pass_a_launches", C.c_longlong),
+                ("pass_b_ms", C.c_double), ("pass_b_launches", C.c_longlong),
+                ("assemble_ms", C.c_double), ("assemble_launches", C.c_longlong),
+                ("update_ms", C.c_double), ("update_launches", C.c_longlong),
+                ("setup_ms", C.c_double), ("total_ms", C.c_double), ("finest_pixels", C.c_longlong)]
+
+
+class Nav(C.Structure):
+    _fields_ = [("pph", C.c_double), ("req", C.c_double), ("rpol", C.c_double), ("lam0", C.c_double),
+                ("xScale", C.c_float), ("xOffset", C.c_float), ("yScale", C.c_float), ("yOffset", C.c_float),
+                ("g2xOffset", C.c_float), ("g2yOffset", C.c_float),
+                ("lat1", C.c_float), ("lon1", C.c_float), ("lon0", C.c_float), ("R", C.c_float),
+                ("minX", C.c_int), ("minY", C.c_int), ("nx", C.c_int), ("ny", C.c_int)]
+
+
+TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                       C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int)
+
+_lib = None
+
+
+class OctaneError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        msg = ""
+        try:
+            msg = lib().octane_last_error().decode()
+        except Exception:  # pragma: no cover
+            pass
+        super().__init__(f"{where} failed with code {code}: {msg}")
+
+
+def lib() -> C.CDLL:
+    """Load liboctane_vof.so; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C octane_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.octane_vof_default_params.argtypes = [C.POINTER(VofParams)]
+    L.octane_vof_default_params.restype = None
+    L.octane_vof_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(VofParams)]
+    L.octane_vof_plan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(VofParams)]
+    L.octane_vof_plan_destroy.argtypes = [vp]
+    L.octane_vof_plan_device_bytes.argtypes = [vp]
+    L.octane_vof_plan_device_bytes.restype = C.c_size_t
+    L.octane_vof_plan_run.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+    L.octane_vof_plan_last_iterations.argtypes = [vp]
+    L.octane_vof_plan_last_iterations.restype = C.c_longlong
+    L.octane_vof_plan_set_trace.argtypes = [vp, TRACE_FN, vp]
+    L.octane_vof_plan_set_profiling.argtypes = [vp, C.c_int]
+    L.octane_vof_plan_get_profile.argtypes = [vp, C.POINTER(VofProfile)]
+    L.octane_vof_batch_run.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(vp), C.POINTER(vp), C.POINTER(VofParams), C.c_int,
+                                       C.POINTER(C.c_int)]
+    L.octane_pix2uv_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, C.c_int, C.c_int,
+                                    vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
+    L.octane_last_error.restype = C.c_char_p
+    L.octane_device_count.restype = C.c_int
+    _lib = L
+    return L
+
+
+@dataclass
+class FlowParams:
+    """The OFFlags fields the solver reads, CLI defaults of ref src/main.cc:78-96."""
+    alpha: float = 5.0
+    lambda_: float = 1.0
+    lambdac: float = 0.0
+    scaleF: float = 0.5
+    scsig: float = 400.0
+    kiters: int = 4
+    liters: int = 3
+    cgiters: int = 30
+    dozim: int = 1
+    device: int = 0
+
+    def c(self) -> VofParams:
+        return VofParams(self.alpha, self.lambda_, self.lambdac, self.scaleF, self.scsig,
+                         self.kiters, self.liters, self.cgiters, self.dozim, self.device)
+
+
+def default_params() -> FlowParams:
+    p = VofParams()
+    lib().octane_vof_default_params(C.byref(p))
+    return FlowParams(p.alpha, p.lambda_, p.lambdac, p.scaleF, p.scsig, p.kiters, p.liters, p.cgiters, p.dozim, p.device)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Plan:
+    """Device state for one (nx, ny, nchan, params); reuse it across image pairs."""
+
+    def __init__(self, nx: int, ny: int, nchan: int = 1, params: FlowParams | None = None):
+        self.nx, self.ny, self.nchan = nx, ny, nchan
+        self.params = params or FlowParams()
+        self._h = C.c_void_p()
+        self._keep = None
+        p = self.params.c()
+        rc = lib().octane_vof_plan_create(C.byref(self._h), nx, ny, nchan, C.byref(p))
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_plan_create")
+
+    def close(self):
+        if self._h:
+            lib().octane_vof_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return lib().octane_vof_plan_device_bytes(self._h)
+
+    def run_host(self, img1, img2, u0=None, v0=None):
+        """Host numpy buffers in, (u, v) numpy out.  img: [nchan, ny, nx] or [ny, nx]."""
+        a, b = _f32(img1), _f32(img2)
+        assert a.size == self.nchan * self.ny * self.nx and b.size == a.size
+        u = np.zeros((self.ny, self.nx), np.float32) if u0 is None else np.array(u0, np.float32, order="C", copy=True)
+        v = np.zeros((self.ny, self.nx), np.float32) if v0 is None else np.array(v0, np.float32, order="C", copy=True)
+        rc = lib().octane_vof_plan_run(self._h, _ptr(a), _ptr(b), _ptr(u), _ptr(v), MEM_HOST, None)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_plan_run")
+        return u, v
+
+    def run_device(self, img1_ptr: int, img2_ptr: int, u_ptr: int, v_ptr: int, stream: int = 0):
+        """Device pointers (dense [nchan, ny, nx] / [ny, nx] float32); enqueues on `stream`."""
+        rc = lib().octane_vof_plan_run(self._h, C.c_void_p(img1_ptr), C.c_void_p(img2_ptr), C.c_void_p(u_ptr),
+                                       C.c_void_p(v_ptr), MEM_DEVICE, C.c_void_p(stream) if stream else None)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_plan_run")
+
+    def last_iterations(self) -> int:
+        return int(lib().octane_vof_plan_last_iterations(self._h))
+
+    def set_trace(self, store: dict | None):
+        if store is None:
+            lib().octane_vof_plan_set_trace(self._h, C.cast(None, TRACE_FN), None)
+            self._keep = None
+            return
+
+        def _cb(user, tag, k, gnc, l, data, nx, ny, npl):
+            store[(tag.decode(), k, gnc, l)] = np.ctypeslib.as_array(data, shape=(npl, ny, nx)).copy()
+        self._keep = TRACE_FN(_cb)
+        lib().octane_vof_plan_set_trace(self._h, self._keep, None)
+
+    def set_profiling(self, on: bool):
+        lib().octane_vof_plan_set_profiling(self._h, 1 if on else 0)
+
+    def profile(self) -> VofProfile:
+        p = VofProfile()
+        lib().octane_vof_plan_get_profile(self._h, C.byref(p))
+        return p
+
+
+def flow(img1, img2, params: FlowParams | None = None, u0=None, v0=None):
+    """One-shot solve through octane_vof_run (allocate, upload, solve, download, free)."""
+    a, b = _f32(img1), _f32(img2)
+    if a.ndim == 2:
+        a, b = a[None], b[None]
+    nc, ny, nx = a.shape
+    u = np.zeros((ny, nx), np.float32) if u0 is None else np.array(u0, np.float32, order="C", copy=True)
+    v = np.zeros((ny, nx), np.float32) if v0 is None else np.array(v0, np.float32, order="C", copy=True)
+    p = (params or FlowParams()).c()
+    rc = lib().octane_vof_run(_ptr(a), _ptr(b), nx, ny, nc, _ptr(u), _ptr(v), C.byref(p))
+    if rc != OK:
+        raise OctaneError(rc, "octane_vof_run")
+    return u, v
+
+
+def batch_flow(pairs, params: FlowParams | None = None, devices=None):
+    """pairs: list of (img1, img2) host arrays of one shape.  Returns list of (u, v)."""
+    if not pairs:
+        return []
+    a0 = _f32(pairs[0][0])
+    if a0.ndim == 2:
+        a0 = a0[None]
+    nc, ny, nx = a0.shape
+    n = len(pairs)
+    ims1 = [_f32(p[0]) for p in pairs]
+    ims2 = [_f32(p[1]) for p in pairs]
+    us = [np.zeros((ny, nx), np.float32) for _ in range(n)]
+    vs = [np.zeros((ny, nx), np.float32) for _ in range(n)]
+    arr = C.c_void_p * n
+    devices = list(devices) if devices is not None else list(range(max(1, lib().octane_device_count())))
+    dv = (C.c_int * len(devices))(*devices)
+    p = (params or FlowParams()).c()
+    rc = lib().octane_vof_batch_run(n, arr(*[_ptr(x) for x in ims1]), arr(*[_ptr(x) for x in ims2]), nx, ny, nc,
+                                    arr(*[_ptr(x) for x in us]), arr(*[_ptr(x) for x in vs]), C.byref(p),
+                                    len(devices), dv)
+    if rc != OK:
+        raise OctaneError(rc, "octane_vof_batch_run")
+    return list(zip(us, vs))
+
+
+def pix2uv(nav: Nav, t1: float, t2: float, u, v, pixuv: int = 0, mode: int = NAV_GEOS, device: int = 0):
+    """Returns (ur, vr, ur2, vr2, dT, sector_moved) -- shorts in cm/s (x100)."""
+    uu, vv = _f32(u), _f32(v)
+    n = uu.size
+    ur, vr, ur2, vr2 = (np.zeros(n, np.int16) for _ in range(4))
+    dT, moved = C.c_float(), C.c_int()
+    rc = lib().octane_pix2uv_run(C.byref(nav), t1, t2, _ptr(uu), _ptr(vv), pixuv, mode, _ptr(ur), _ptr(vr),
+                                 _ptr(ur2), _ptr(vr2), C.byref(dT), C.byref(moved), device)
+    if rc != OK:
+        raise OctaneError(rc, "octane_pix2uv_run")
+    shp = uu.shape
+    return ur.reshape(shp), vr.reshape(shp), ur2.reshape(shp), vr2.reshape(shp), dT.value, moved.value

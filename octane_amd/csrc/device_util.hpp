@@ -1,0 +1,44 @@
+// device_util.hpp -- small wave64 / workgroup helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace octane {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Sum over the 64 lanes of a wavefront; every lane ends with the total, and the order of
+// additions is fixed (butterfly), so the result is run-to-run deterministic.
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over a 256-thread workgroup (4 waves); every thread gets the total.
+// `scratch` must hold at least 4 doubles; safe to call back-to-back.
+__device__ __forceinline__ double block_sum_256(double v, double *scratch)
+{
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                       // scratch may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+}
+
+// Every block folds the same `n` per-block partials (n <= 1024) in the same order, so all
+// blocks obtain bit-identical totals without atomics, fences or an extra launch: thread t
+// adds partials t, t+256, t+512, t+768, then the workgroup tree above.
+__device__ __forceinline__ double fold_partials_256(const double *__restrict__ part, int n, double *scratch)
+{
+    double v = 0.;
+    for (int i = threadIdx.x; i < n; i += 256) v += part[i];
+    return block_sum_256(v, scratch);
+}
+
+// Jacobi preconditioner entry exactly as the reference forms it: M = 1./M in double, stored
+// as float (ref .cu:141-149).
+__device__ __forceinline__ float jacobi_inv(float a) { return (float)(1. / (double)a); }
+
+}  // namespace octane

@@ -1,0 +1,279 @@
+// pcg_kernels.hip -- the inner linear solver: Jacobi-preconditioned CG, matrix-free, gfx950.
+//
+// Behavioural spec: ref src/oct_variational_optical_flow.cu:1105-1195 (PCG on an assembled CSR
+// matrix, 12 grid barriers and 5 atomics-based dot products per iteration, A*p computed
+// twice).  The iterates here are the same -- same operator, same preconditioner, same
+// recurrences, same iteration count, same stop test -- but one iteration is two streaming
+// kernels over row-pitched planes:
+//
+//   pass A(k):  beta = (r.z)_k / (r.z)_{k-1};  p <- M^-1 r + beta p;  q <- A p;  partials of p.q
+//   pass B(k):  alpha = (r.z)_k / (p.q);  x <- x + alpha p;  r <- r - alpha q;  partials of r.M^-1 r, r.r
+//
+// (the reference's z0.bcu and bcu.z0 products are the previous/current r.z, so three of its
+// five dot products are redundant).  A acts through five coefficient planes (see k_assemble).
+//
+// Reductions are two-stage and deterministic with no atomics, fences or extra launches: each
+// persistent block writes one double partial; every block of the NEXT kernel folds the (at most
+// 1024) partials in the same fixed order (device_util.hpp), so all blocks agree bitwise on
+// alpha/beta and on the stop decision.  The kernel boundary provides the visibility.
+//
+// Algorithmic HBM bytes per pixel per iteration: A reads r(2) p(2) a1 a2 a4 wx wy
+// = 36 B, writes p(2) q(2) = 16 B; B reads x(2) r(2) p(2) q(2) a1 a4 = 40 B, writes x(2) r(2)
+// = 16 B.  Halo re-reads of A are L2/MALL hits.
+#include "vof_kernels.hpp"
+#include "device_util.hpp"
+
+namespace octane {
+
+constexpr int kLRow = kTileX + 8;   // LDS row: [3 pad][west halo][kTileX interior][east halo][3 pad]
+constexpr int kLInt = 4;            // interior starts 16-byte aligned
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// p_new = z + beta * p_old with z = M^-1 r  (ref .cu:1117/1138 then jVecPVec(p0,z0,p0,Bk) at :1146)
+__device__ __forceinline__ float direction(float r, float pold, float diag, float beta, bool first)
+{
+    float z = jacobi_inv(diag) * r;
+    return first ? z : beta * pold + z;
+}
+
+__global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int nparts_prev, float tol)
+{
+    __shared__ __attribute__((aligned(16))) float s_pu[(kTileY + 2) * kLRow];
+    __shared__ __attribute__((aligned(16))) float s_pv[(kTileY + 2) * kLRow];
+    __shared__ double s_red[8];
+    const int tid = threadIdx.x;
+
+    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
+    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
+    const PcgState prev = L.st[k & 1];
+    // the reference's loop test: while (residc > tol && ki < iters)   (ref .cu:1131)
+    const bool active = (prev.stopped == 0) && (rr > tol);
+    if (!active) {
+        if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
+        return;
+    }
+    const bool first = (k == 0);
+    const float beta = first ? 0.f : rz_new / prev.rz;
+    if (blockIdx.x == 0 && tid == 0) {
+        PcgState n; n.rz = rz_new; n.stopped = 0; n.iters = prev.iters + 1; n.pad = 0;
+        L.st[(k + 1) & 1] = n;
+    }
+
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int tiles_x = (w + kTileX - 1) / kTileX, tiles_y = (h + kTileY - 1) / kTileY;
+    const int ntiles = tiles_x * tiles_y;
+    const int lx = tid & 31, ly = tid >> 5;
+    double acc = 0.;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx0 = (t % tiles_x) * kTileX, ty0 = (t / tiles_x) * kTileY;
+        const int x = tx0 + lx * 4, y = ty0 + ly;
+        const bool rowok = (y < h) && (x < w);
+        const size_t o = (size_t)y * pitch + x;
+
+        float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0}, a1[4] = {1, 1, 1, 1}, a4[4] = {1, 1, 1, 1};
+        float a2[4], wxc[4], wyc[4], wys[4] = {0, 0, 0, 0};
+        float npu[4], npv[4];
+        float wxw = 0.f;
+        if (rowok) {
+            *(float4 *)ru = ld4(L.ru + o);
+            *(float4 *)rv = ld4(L.rv + o);
+            *(float4 *)a1 = ld4(L.a1 + o);
+            *(float4 *)a4 = ld4(L.a4 + o);
+            *(float4 *)a2 = ld4(L.a2 + o);
+            *(float4 *)wxc = ld4(L.wx + o);
+            *(float4 *)wyc = ld4(L.wy + o);
+            if (y > 0) *(float4 *)wys = ld4(L.wy + o - pitch);
+            if (x > 0) wxw = L.wx[o - 1];
+            float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
+            if (!first) { *(float4 *)pu = ld4(L.pu + o); *(float4 *)pv = ld4(L.pv + o); }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool ok = (x + e) < w;
+                npu[e] = ok ? direction(ru[e], pu[e], a1[e], beta, first) : 0.f;
+                npv[e] = ok ? direction(rv[e], pv[e], a4[e], beta, first) : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { npu[e] = 0.f; npv[e] = 0.f; a2[e] = 0.f; wxc[e] = 0.f; wyc[e] = 0.f; }
+        }
+        st4(&s_pu[(ly + 1) * kLRow + kLInt + lx * 4], *(float4 *)npu);
+        st4(&s_pv[(ly + 1) * kLRow + kLInt + lx * 4], *(float4 *)npv);
+
+        // one-pixel halo of p_new, recomputed from r, p_old and the diagonal
+        if (tid < 64) {                                  // rows above and below the tile
+            const int hy = (tid < 32) ? ty0 - 1 : ty0 + kTileY;
+            const int hx = tx0 + (tid & 31) * 4;
+            const int lrow = (tid < 32) ? 0 : kTileY + 1;
+            float hu[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0};
+            if (hy >= 0 && hy < h && hx < w) {
+                const size_t ho = (size_t)hy * pitch + hx;
+                float r0[4], r1[4], d0[4], d1[4], q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
+                *(float4 *)r0 = ld4(L.ru + ho); *(float4 *)r1 = ld4(L.rv + ho);
+                *(float4 *)d0 = ld4(L.a1 + ho); *(float4 *)d1 = ld4(L.a4 + ho);
+                if (!first) { *(float4 *)q0 = ld4(L.pu + ho); *(float4 *)q1 = ld4(L.pv + ho); }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool ok = (hx + e) < w;
+                    hu[e] = ok ? direction(r0[e], q0[e], d0[e], beta, first) : 0.f;
+                    hv[e] = ok ? direction(r1[e], q1[e], d1[e], beta, first) : 0.f;
+                }
+            }
+            st4(&s_pu[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hu);
+            st4(&s_pv[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hv);
+        } else if (tid < 64 + 2 * kTileY) {              // columns left and right of the tile
+            const int side = (tid - 64) / kTileY, row = (tid - 64) % kTileY;
+            const int hy = ty0 + row;
+            const int hx = side ? tx0 + kTileX : tx0 - 1;
+            float hu = 0.f, hv = 0.f;
+            if (hy < h && hx >= 0 && hx < w) {
+                const size_t ho = (size_t)hy * pitch + hx;
+                const float q0 = first ? 0.f : L.pu[ho], q1 = first ? 0.f : L.pv[ho];
+                hu = direction(L.ru[ho], q0, L.a1[ho], beta, first);
+                hv = direction(L.rv[ho], q1, L.a4[ho], beta, first);
+            }
+            const int lcol = side ? kLInt + kTileX : kLInt - 1;
+            s_pu[(row + 1) * kLRow + lcol] = hu;
+            s_pv[(row + 1) * kLRow + lcol] = hv;
+        }
+        __syncthreads();
+
+        if (rowok) {
+            float su[4], sv[4], nu[4], nv[4];
+            *(float4 *)su = ld4(&s_pu[ly * kLRow + kLInt + lx * 4]);
+            *(float4 *)sv = ld4(&s_pv[ly * kLRow + kLInt + lx * 4]);
+            *(float4 *)nu = ld4(&s_pu[(ly + 2) * kLRow + kLInt + lx * 4]);
+            *(float4 *)nv = ld4(&s_pv[(ly + 2) * kLRow + kLInt + lx * 4]);
+            const float uwest = s_pu[(ly + 1) * kLRow + kLInt + lx * 4 - 1];
+            const float vwest = s_pv[(ly + 1) * kLRow + kLInt + lx * 4 - 1];
+            const float ueast = s_pu[(ly + 1) * kLRow + kLInt + lx * 4 + 4];
+            const float veast = s_pv[(ly + 1) * kLRow + kLInt + lx * 4 + 4];
+            float qu[4], qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = x + e;
+                const float pwu = (e == 0) ? uwest : npu[e - 1], pwv = (e == 0) ? vwest : npv[e - 1];
+                const float peu = (e == 3) ? ueast : npu[(e + 1) & 3], pev = (e == 3) ? veast : npv[(e + 1) & 3];
+                // row entries in the reference's storage order: south, west, block, east, north
+                // with the merged border weights of ref .cu:929-1001
+                const float a5 = (e == 0) ? wxw : wxc[(e + 3) & 3];
+                const float wS = (y == h - 1) ? wys[e] + wyc[e] : wys[e];
+                const float wW = (i == w - 1) ? a5 + wxc[e] : a5;
+                const float wE = (i == 0) ? wxc[e] + wxc[e] : wxc[e];
+                const float wN = (y == 0) ? wyc[e] + wyc[e] : wyc[e];
+                float sumu = 0.f, sumv = 0.f;
+                if (y > 0) { sumu += wS * su[e]; sumv += wS * sv[e]; }
+                if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
+                sumu += a1[e] * npu[e]; sumv += a2[e] * npu[e];
+                sumu += a2[e] * npv[e]; sumv += a4[e] * npv[e];
+                if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
+                if (y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
+                qu[e] = sumu; qv[e] = sumv;
+                if (i < w) acc += (double)(npu[e] * sumu) + (double)(npv[e] * sumv);
+            }
+            st4(L.pu + o, *(float4 *)npu);
+            st4(L.pv + o, *(float4 *)npv);
+            st4(L.qu + o, *(float4 *)qu);
+            st4(L.qv + o, *(float4 *)qv);
+        }
+        __syncthreads();
+    }
+    const double tot = block_sum_256(acc, s_red);
+    if (tid == 0) L.part_pq[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int nparts_a)
+{
+    __shared__ double s_red[8];
+    const PcgState st = L.st[(k + 1) & 1];
+    if (st.stopped) return;
+    const float pq = (float)fold_partials_256(L.part_pq, nparts_a, s_red);
+    const float alpha = st.rz / pq;                        // ref .cu:1169
+    const float nalpha = (float)(-1. * (double)alpha);     // ref .cu:1174
+    const bool first = (k == 0);
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int gw = (w + 3) / 4;
+    const long ngroups = (long)gw * h;
+    double acc_rz = 0., acc_rr = 0.;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
+        const int y = (int)(g / gw), x = (int)(g - (long)y * gw) * 4;
+        const size_t o = (size_t)y * pitch + x;
+        float xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0}, ru[4], rv[4], pu[4], pv[4], qu[4], qv[4], a1[4], a4[4];
+        *(float4 *)ru = ld4(L.ru + o); *(float4 *)rv = ld4(L.rv + o);
+        *(float4 *)pu = ld4(L.pu + o); *(float4 *)pv = ld4(L.pv + o);
+        *(float4 *)qu = ld4(L.qu + o); *(float4 *)qv = ld4(L.qv + o);
+        *(float4 *)a1 = ld4(L.a1 + o); *(float4 *)a4 = ld4(L.a4 + o);
+        if (!first) { *(float4 *)xu = ld4(L.xu + o); *(float4 *)xv = ld4(L.xv + o); }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            xu[e] = alpha * pu[e] + xu[e];                 // jVecPVec(p0,x0,x0,alphak), ref .cu:1172
+            xv[e] = alpha * pv[e] + xv[e];
+            ru[e] = nalpha * qu[e] + ru[e];                // jVecPVec(dummyvec,bcu,rk,-alphak), ref .cu:1174
+            rv[e] = nalpha * qv[e] + rv[e];
+            if (x + e < w) {
+                const float zu = jacobi_inv(a1[e]) * ru[e], zv = jacobi_inv(a4[e]) * rv[e];
+                acc_rz += (double)(ru[e] * zu) + (double)(rv[e] * zv);
+                acc_rr += (double)(ru[e] * ru[e]) + (double)(rv[e] * rv[e]);
+            }
+        }
+        st4(L.xu + o, *(float4 *)xu); st4(L.xv + o, *(float4 *)xv);
+        st4(L.ru + o, *(float4 *)ru); st4(L.rv + o, *(float4 *)rv);
+    }
+    const double trz = block_sum_256(acc_rz, s_red);
+    const double trr = block_sum_256(acc_rr, s_red);
+    if (threadIdx.x == 0) { L.part_rz[blockIdx.x] = trz; L.part_rr[blockIdx.x] = trr; }
+}
+
+// u += dx, v += dy after a solve (ref .cu:1185-1195).  x is only meaningful if at least one
+// iteration ran; the reference's x0 stays zero otherwise.
+__global__ __launch_bounds__(256) void k_flow_update(LevelPtrs L, int nlaunched)
+{
+    const PcgState st = L.st[nlaunched & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *L.iter_total += st.iters;
+    if (st.iters == 0) return;
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int gw = (w + 3) / 4;
+    const long ngroups = (long)gw * h;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
+        const int y = (int)(g / gw), x = (int)(g - (long)y * gw) * 4;
+        const size_t o = (size_t)y * pitch + x;
+        float4 u = ld4(L.u + o), v = ld4(L.v + o), dx = ld4(L.xu + o), dy = ld4(L.xv + o);
+        u.x = u.x + dx.x; u.y = u.y + dx.y; u.z = u.z + dx.z; u.w = u.w + dx.w;
+        v.x = v.x + dy.x; v.y = v.y + dy.y; v.z = v.z + dy.z; v.w = v.w + dy.w;
+        st4(L.u + o, u); st4(L.v + o, v);
+    }
+}
+
+int pcg_grid_size(int w, int h)
+{
+    int tiles = ((w + kTileX - 1) / kTileX) * ((h + kTileY - 1) / kTileY);
+    return tiles < kMaxParts ? tiles : kMaxParts;
+}
+
+static int stream_grid_size(int w, int h)
+{
+    long groups = (long)((w + 3) / 4) * h;
+    long blocks = (groups + 255) / 256;
+    return (int)(blocks < kMaxParts ? blocks : kMaxParts);
+}
+
+void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
+{
+    hipLaunchKernelGGL(k_pcg_pass_a, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+}
+
+void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid)
+{
+    hipLaunchKernelGGL(k_pcg_pass_b, dim3(grid), dim3(256), 0, s, L, k, nparts_a);
+}
+
+void launch_flow_update(hipStream_t s, const LevelPtrs &L, int nlaunched)
+{
+    hipLaunchKernelGGL(k_flow_update, dim3(stream_grid_size(L.w, L.h)), dim3(256), 0, s, L, nlaunched);
+}
+
+int pcg_b_grid_size(int w, int h) { return stream_grid_size(w, h); }
+
+}  // namespace octane

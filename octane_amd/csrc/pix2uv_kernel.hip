@@ -1,0 +1,129 @@
+// pix2uv_kernel.hip -- pixel displacement -> navigated wind (cm/s), one thread per pixel, fp64.
+//
+// Behavioural spec: ref src/oct_pix2uv_cuda.cu:13-221 ("ref p2u").  Memory-trivial (~20 B/px,
+// one pass); the point of this kernel is bit-exact `short` output, so this translation unit is
+// compiled with -ffp-contract=off and uses no fast-math: the base pixel position is formed in
+// float (int*float+float, ref p2u:40-41), the displaced one in double (ref p2u:43-44), and
+// latitude/longitude pass through float on their way into the haversine (ref p2u:13).
+#include "vof_kernels.hpp"
+
+namespace octane {
+
+__device__ static double great_circle(float lat1, float lon1, float lat2, float lon2, double rad, double rad2)
+{
+    const double earthrad = 6371000.00;
+    double dlon = lon2 - lon1;
+    double dlat = lat2 - lat1;
+    double a = (pow(sin(dlat * rad2), 2.0) + cos(lat1 * rad) * cos(lat2 * rad) * pow((sin(dlon * rad2)), 2.0));
+    double c = 2. * atan2(sqrt(a), sqrt(1 - a));
+    return earthrad * c;
+}
+
+__device__ static void navigate_pixel(const NavArgs &g, const double *rate, int xi, int yi, double dt,
+                                      double *r, double DTOR, double DTOR2, int mode)
+{
+    const double PI = 3.14159265359;
+    double xVal, yVal;
+    double latv[2], lonv[2], sds[2] = {0., 0.};
+    for (int iv = 0; iv < 2; ++iv) {
+        if (iv == 0) {
+            xVal = (xi)*g.xScale + g.xOffset;     // float arithmetic, as in the reference
+            yVal = (yi)*g.yScale + g.yOffset;
+        } else {
+            xVal = (rate[0] * dt + xi) * g.xScale + g.xOffset;
+            yVal = (rate[1] * dt + yi) * g.yScale + g.yOffset;
+        }
+        if (mode == 1) {                           // polar stereographic-like grid, ref p2u:34-66
+            double rho = sqrt(xVal * xVal + yVal * yVal);
+            double c = asin(rho / g.R);
+            if (g.lat1 > 89.9999) {
+                lonv[iv] = g.lon0 * DTOR + atan2(xVal, -yVal);
+            } else {
+                lonv[iv] = g.lon0 * DTOR + atan2(xVal * sin(c), (rho * cos(g.lat1 * DTOR) * cos(c) - yVal * sin(g.lat1 * DTOR) * sin(c)));
+            }
+            if (rho > 0.0000001) {
+                latv[iv] = asin(cos(c) * sin(g.lat1 * DTOR) + (yVal * sin(c) * cos(g.lat1 * DTOR) / rho));
+            } else {
+                latv[iv] = g.lat1 * DTOR;
+            }
+            latv[iv] = latv[iv] / DTOR;
+            lonv[iv] = lonv[iv] / DTOR;
+        } else if (mode == 2) {                    // mercator, ref p2u:70-87
+            latv[iv] = PI / 2. - 2. * atan(exp(-yVal / g.R));
+            lonv[iv] = xVal / g.R + g.lon1;
+            latv[iv] = latv[iv] / DTOR;
+            lonv[iv] = lonv[iv] / DTOR;
+        } else {                                   // GOES-R fixed grid, ref p2u:90-139
+            double H = g.pph + g.req;
+            sds[iv] = xVal * xVal + yVal * yVal;
+            double a = pow((sin(xVal)), 2.0) + pow(cos(xVal), 2.0) * (pow((cos(yVal)), 2.0) + (pow(g.req, 2.0)) / (pow(g.rpol, 2.0)) * pow((sin(yVal)), 2.0));
+            double b = -2. * H * cos(xVal) * cos(yVal);
+            double c = pow(H, 2.0) - pow(g.req, 2.0);
+            double d = (pow(b, 2.0) - 4. * a * c);
+            if (d >= 0) {
+                double rs = (-b - sqrt(d)) / (2. * a);
+                double sx = rs * cos(xVal) * cos(yVal);
+                double sy = -rs * sin(xVal);
+                double sz = rs * cos(xVal) * sin(yVal);
+                double e = (pow((H - sx), 2.0) + pow(sy, 2.0));
+                if (sz == 0 || e <= 0 || H - sx == 0) {
+                    latv[iv] = -999.; lonv[iv] = -999.;
+                } else {
+                    latv[iv] = atan((pow(g.req, 2.0)) / (pow(g.rpol, 2.0)) * (sz / sqrt(e)));
+                    lonv[iv] = g.lam0 - atan(sy / (H - sx));
+                    latv[iv] = latv[iv] / DTOR;
+                    lonv[iv] = lonv[iv] / DTOR;
+                }
+            } else {
+                latv[iv] = -999.; lonv[iv] = -999.;
+            }
+        }
+    }
+    if ((latv[0] < -998) || (latv[1] < -998) || (sds[0] > 0.021)) {   // ref p2u:144-148
+        r[0] = 0.; r[1] = 0.;
+    } else {
+        double dist = great_circle((float)latv[0], (float)lonv[0], (float)latv[0], (float)lonv[1], DTOR, DTOR2);
+        r[0] = (lonv[1] >= lonv[0]) ? dist / dt : -dist / dt;
+        dist = great_circle((float)latv[0], (float)lonv[0], (float)latv[1], (float)lonv[0], DTOR, DTOR2);
+        r[1] = (latv[1] >= latv[0]) ? dist / dt : -dist / dt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pix2uv(NavArgs nav, double t1, double t2,
+                                                const float *__restrict__ u, const float *__restrict__ v, int mode,
+                                                short *__restrict__ ur, short *__restrict__ vr,
+                                                short *__restrict__ ur2, short *__restrict__ vr2, long n)
+{
+    const double pi = 3.14159265;
+    const double rad = pi / 180.;
+    const double rad2 = rad / 2.;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+        const int ii = (int)(k % nav.nx), jj = (int)(k / nav.nx);
+        const float uf = u[k], vf = v[k];
+        const double u1 = uf, v1 = vf;
+        if (u1 > -9998.) {
+            double rate[2], wind[2];
+            rate[0] = u1 / (t2 - t1);
+            rate[1] = v1 / (t2 - t1);
+            navigate_pixel(nav, rate, ii + nav.minX, jj + nav.minY, t2 - t1, wind, rad, rad2, mode);
+            ur[k] = (short)(100 * (wind[0]));
+            vr[k] = (short)(100 * (wind[1]));
+        } else {
+            ur[k] = (short)(-32768);
+            vr[k] = (short)(-32768);
+        }
+        ur2[k] = (short)(100 * uf);   // ref p2u:335-336 (done on the host there)
+        vr2[k] = (short)(100 * vf);
+    }
+}
+
+void launch_pix2uv(hipStream_t s, const NavArgs &nav, double t1, double t2, const float *u, const float *v,
+                   int mode, short *ur, short *vr, short *ur2, short *vr2, long n)
+{
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_pix2uv, dim3((unsigned)blocks), dim3(256), 0, s, nav, t1, t2, u, v, mode, ur, vr, ur2, vr2, n);
+}
+
+}  // namespace octane

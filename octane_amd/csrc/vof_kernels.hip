@@ -1,0 +1,365 @@
+// vof_kernels.hip -- level-setup and assembly kernels of the variational flow solver, gfx950.
+//
+// Behavioural spec: src/oct_variational_optical_flow.cu of the reference ("ref .cu:a-b").
+// Nothing here is a translation of that file's structure: the reference runs one
+// cooperative mega-kernel with grid-stride loops over a flat index and a grid barrier between
+// phases; here every phase is its own stream-ordered launch over 2-D tiles of row-pitched
+// planes, the blur is evaluated only where the decimation samples it, and the linear
+// operator is kept as five coefficient planes instead of a CSR matrix.
+#include "vof_kernels.hpp"
+#include "device_util.hpp"
+
+namespace octane {
+
+// ---------------------------------------------------------------------------------------
+// plain 2-D copies (pitch conversion, level bookkeeping: ref .cu:506-516, 578-582)
+// ---------------------------------------------------------------------------------------
+__global__ void k_copy2d(const float *__restrict__ src, int spitch, float *__restrict__ dst, int dpitch,
+                         int w, int h, float scale, int do_scale)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float v = src[(size_t)y * spitch + x];
+    if (do_scale) v = v * scale;
+    dst[(size_t)y * dpitch + x] = v;
+}
+
+void launch_copy2d(hipStream_t s, const float *src, int spitch, float *dst, int dpitch, int w, int h)
+{
+    dim3 b(64, 4), g((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_copy2d, g, b, 0, s, src, spitch, dst, dpitch, w, h, 1.0f, 0);
+}
+
+void launch_scale_copy2d(hipStream_t s, const float *src, int spitch, float *dst, int dpitch, int w, int h, float scale)
+{
+    dim3 b(64, 4), g((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_copy2d, g, b, 0, s, src, spitch, dst, dpitch, w, h, scale, 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// Gaussian blur + decimation (ref .cu:311-408, 521-563)
+//
+// The reference blurs the whole full-resolution image (rows, then columns) and then samples
+// it at integer coordinates ((int)(ii/f), (int)(jj/f)) -- its bicubic collapses to a point
+// sample there.  Only those samples are needed, so the row pass is evaluated at the sampled
+// columns only (output dw x sh) and the column pass at the sampled rows only (dw x dh).
+// Tap order (-fs .. fs-1, last tap dropped) and the running-sum order are the reference's.
+// ---------------------------------------------------------------------------------------
+__global__ void k_blur_rows_sampled(const float *__restrict__ src, int sw, int sh, int spitch,
+                                    float *__restrict__ dst, int dw, int dpitch,
+                                    const float *__restrict__ gk, int fs, float factor)
+{
+    int ii = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y;
+    if (ii >= dw || j >= sh) return;
+    int xc = clampi((int)((float)ii / factor), 0, sw - 1);
+    const float *row = src + (size_t)j * spitch;
+    float acc = 0.f;
+    for (int t = -fs; t < fs; ++t) {
+        int sx = clampi(xc + t, 0, sw - 1);
+        acc = acc + gk[t + fs] * row[sx];
+    }
+    dst[(size_t)j * dpitch + ii] = acc;
+}
+
+__global__ void k_blur_cols_sampled(const float *__restrict__ src, int sw, int sh, int spitch,
+                                    float *__restrict__ dst, int dh, int dpitch,
+                                    const float *__restrict__ gk, int fs, float factor,
+                                    float postscale, int do_scale)
+{
+    int ii = blockIdx.x * blockDim.x + threadIdx.x;
+    int jj = blockIdx.y;
+    if (ii >= sw || jj >= dh) return;
+    int yc = clampi((int)((float)jj / factor), 0, sh - 1);
+    float acc = 0.f;
+    for (int t = -fs; t < fs; ++t) {
+        int sy = clampi(yc + t, 0, sh - 1);
+        acc = acc + gk[t + fs] * src[(size_t)sy * spitch + ii];
+    }
+    if (do_scale) acc = acc * postscale;   // ref .cu:559-563, a separate multiply
+    dst[(size_t)jj * dpitch + ii] = acc;
+}
+
+void launch_blur_rows_sampled(hipStream_t s, const float *src, int sw, int sh, int spitch,
+                              float *dst, int dw, int dpitch, const float *gk, int fs, float factor)
+{
+    dim3 b(64), g((dw + 63) / 64, sh);
+    hipLaunchKernelGGL(k_blur_rows_sampled, g, b, 0, s, src, sw, sh, spitch, dst, dw, dpitch, gk, fs, factor);
+}
+
+void launch_blur_cols_sampled(hipStream_t s, const float *src, int sw, int sh, int spitch,
+                              float *dst, int dh, int dpitch, const float *gk, int fs, float factor,
+                              float postscale, int do_scale)
+{
+    dim3 b(64), g((sw + 63) / 64, dh);
+    hipLaunchKernelGGL(k_blur_cols_sampled, g, b, 0, s, src, sw, sh, spitch, dst, dh, dpitch, gk, fs, factor,
+                       postscale, do_scale);
+}
+
+// ---------------------------------------------------------------------------------------
+// 4th-order central differences with clamped indices (ref .cu:410-449), fp64 intermediate
+// ---------------------------------------------------------------------------------------
+__global__ void k_gradient(const float *__restrict__ f, float *__restrict__ gx, float *__restrict__ gy,
+                           int w, int h, int pitch, size_t cstride)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const float *fc = f + cstride * blockIdx.z;
+    const float *row = fc + (size_t)y * pitch;
+    int xp1 = min(x + 1, w - 1), xp2 = min(x + 2, w - 1), xm1 = max(x - 1, 0), xm2 = max(x - 2, 0);
+    int yp1 = min(y + 1, h - 1), yp2 = min(y + 2, h - 1), ym1 = max(y - 1, 0), ym2 = max(y - 2, 0);
+    double dx = ((double)(-row[xp2]) + 8. * (double)row[xp1] - 8. * (double)row[xm1] + (double)row[xm2]) / 12.0;
+    double dy = ((double)(-fc[(size_t)yp2 * pitch + x]) + 8. * (double)fc[(size_t)yp1 * pitch + x]
+                 - 8. * (double)fc[(size_t)ym1 * pitch + x] + (double)fc[(size_t)ym2 * pitch + x]) / 12.0;
+    size_t o = cstride * blockIdx.z + (size_t)y * pitch + x;
+    gx[o] = (float)dx;
+    if (gy) gy[o] = (float)dy;   // the caller passes null when d/dy is dead (ref .cu:591-594)
+}
+
+void launch_gradient(hipStream_t s, const float *f, float *gx, float *gy, int w, int h, int pitch, int nc, size_t cstride)
+{
+    dim3 b(64, 4), g((w + 63) / 64, (h + 3) / 4, nc);
+    hipLaunchKernelGGL(k_gradient, g, b, 0, s, f, gx, gy, w, h, pitch, cstride);
+}
+
+// ---------------------------------------------------------------------------------------
+// Catmull-Rom bicubic flow up-sampling (ref .cu:230-309, 452-466)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float cubic1d(float v0, float v1, float v2, float v3, float x)
+{
+    double xd = (double)x;
+    double inner3 = 3.0 * (double)(v1 - v2) + (double)v3 - (double)v0;
+    double inner2 = 2.0 * (double)v0 - 5.0 * (double)v1 + 4.0 * (double)v2 - (double)v3 + xd * inner3;
+    double inner1 = (double)(v2 - v0) + xd * inner2;
+    return (float)((double)v1 + 0.5 * xd * inner1);
+}
+
+// Index rule of the reference: truncate toward zero, THEN clamp; the fraction is taken
+// against the clamped centre index (so -1 < uu < 0 gives a degenerate stencil).
+__device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, int pitch, float uu, float vv, int nx, int ny)
+{
+    int xs[4], ys[4];
+    xs[1] = clampi((int)uu, 0, nx - 1);
+    ys[1] = clampi((int)vv, 0, ny - 1);
+    xs[0] = clampi((int)(uu - 1), 0, nx - 1);
+    ys[0] = clampi((int)(vv - 1), 0, ny - 1);
+    xs[2] = clampi((int)(uu + 1), 0, nx - 1);
+    ys[2] = clampi((int)(vv + 1), 0, ny - 1);
+    xs[3] = clampi((int)(uu + 2), 0, nx - 1);
+    ys[3] = clampi((int)(vv + 2), 0, ny - 1);
+    float fy = vv - (float)ys[1];
+    float fx = uu - (float)xs[1];
+    float col[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        float t0 = src[(size_t)ys[0] * pitch + xs[a]];
+        float t1 = src[(size_t)ys[1] * pitch + xs[a]];
+        float t2 = src[(size_t)ys[2] * pitch + xs[a]];
+        float t3 = src[(size_t)ys[3] * pitch + xs[a]];
+        col[a] = cubic1d(t0, t1, t2, t3, fy);
+    }
+    return cubic1d(col[0], col[1], col[2], col[3], fx);
+}
+
+__global__ void k_upsample(const float *__restrict__ coarse, int cw, int ch, int cpitch,
+                           float *__restrict__ fine, int fw, int fh, int fpitch, float sf)
+{
+    int ii = blockIdx.x * blockDim.x + threadIdx.x;
+    int jj = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ii >= fw || jj >= fh) return;
+    const float fx = ((float)fw / (float)cw);
+    const float fy = ((float)fh / (float)ch);
+    float i2 = (float)((double)((float)ii / fx) - (0.5 - 0.5 / (double)fx));
+    float j2 = (float)((double)((float)jj / fy) - (0.5 - 0.5 / (double)fy));
+    fine[(size_t)jj * fpitch + ii] = bicubic_sample(coarse, cpitch, i2, j2, cw, ch) / sf;
+}
+
+void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpitch,
+                     float *fine, int fw, int fh, int fpitch, float sf)
+{
+    dim3 b(64, 4), g((fw + 63) / 64, (fh + 3) / 4);
+    hipLaunchKernelGGL(k_upsample, g, b, 0, s, coarse, cw, ch, cpitch, fine, fw, fh, fpitch, sf);
+}
+
+// ---------------------------------------------------------------------------------------
+// Assembly (ref .cu:611-1097): one thread per pixel.
+//
+// Produces, instead of the reference's 12 CSR entries per pixel, five planes
+//   a1, a2, a4     the 2x2 diagonal block  [a1 a2; a2 a4]
+//   wx = a7        coupling to the pixel at i+1 (east);  the west coupling a5(i,j) == wx(i-1,j)
+//   wy = a8        coupling to the pixel at j+1 (north); the south coupling a6(i,j) == wy(i,j-1)
+// (both identities are bit-exact consequences of the reference's formulas and are asserted on
+// the oracle's planes in tests/test_oracle_structure.py) plus the right-hand side, written
+// straight into r (r0 = b because x0 = 0).  It also emits the block partials of b.b and
+// b.(M^-1 b) and resets the solve's state, so the first PCG pass needs no separate init.
+// ---------------------------------------------------------------------------------------
+constexpr int kAsmTX = 64, kAsmTY = 4;
+
+__device__ __forceinline__ float psi_smooth(float x)
+{
+    return (float)(1. / (double)sqrtf((float)((double)x + 1E-6)));
+}
+__device__ __forceinline__ float psi_data(float x)
+{
+    return (float)(1. / sqrt((double)x + 1E-6));
+}
+__device__ __forceinline__ float sq(float x) { return x * x; }
+
+__global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
+{
+    __shared__ double s_red[8];
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int tiles_x = (w + kAsmTX - 1) / kAsmTX, tiles_y = (h + kAsmTY - 1) / kAsmTY;
+    const int ntiles = tiles_x * tiles_y;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const double al1 = P.al1, alpha = P.alpha, loa = P.loa;
+    const float lambdac = P.lambdac;
+    double acc_rr = 0., acc_rz = 0.;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int ii = (t % tiles_x) * kAsmTX + lx;
+        const int jj = (t / tiles_x) * kAsmTY + ly;
+        if (ii >= w || jj >= h) continue;
+        // mirrored neighbour coordinates (ref .cu:629-652)
+        const int xe = (ii == w - 1) ? ii - 1 : ii + 1;
+        const int xw = (ii == 0) ? ii + 1 : ii - 1;
+        const int yn = (jj == h - 1) ? jj - 1 : jj + 1;
+        const int ys = (jj == 0) ? jj + 1 : jj - 1;
+        const size_t rc = (size_t)jj * pitch, rn = (size_t)yn * pitch, rs = (size_t)ys * pitch;
+        const float *U = L.u, *V = L.v;
+        float ue = U[rc + xe], uc = U[rc + ii], une = U[rn + xe], use = U[rs + xe], un = U[rn + ii], us = U[rs + ii];
+        float unw = U[rn + xw], uw = U[rc + xw], usw = U[rs + xw];
+        float ve = V[rc + xe], vc = V[rc + ii], vne = V[rn + xe], vse = V[rs + xe], vn = V[rn + ii], vs = V[rs + ii];
+        float vnw = V[rn + xw], vw = V[rc + xw], vsw = V[rs + xw];
+
+        float Ue = sq(ue - uc) + sq((float)(0.25 * (double)((une - use) + (un - us))))
+                 + sq(ve - vc) + sq((float)(0.25 * (double)((vne - vse) + (vn - vs))));
+        float Uw = sq(uc - uw) + sq((float)(0.25 * (double)((unw - usw) + (un - us))))
+                 + sq(vc - vw) + sq((float)(0.25 * (double)((vnw - vsw) + (vn - vs))));
+        float Un = sq(un - uc) + sq((float)(0.25 * (double)((une - unw) + (ue - uw))))
+                 + sq(vn - vc) + sq((float)(0.25 * (double)((vne - vnw) + (ve - vw))));
+        float Us = sq(uc - us) + sq((float)(0.25 * (double)((use - usw) + (ue - uw))))
+                 + sq(vc - vs) + sq((float)(0.25 * (double)((vse - vsw) + (ve - vw))));
+        float ps1 = psi_smooth(Uw), ps2 = psi_smooth(Us), ps3 = psi_smooth(Ue), ps4 = psi_smooth(Un);
+        float pstot = ps1 + ps2 + ps3 + ps4;
+        const float pstotq = 4.f;
+        float snu = ps1 * uw + ps2 * us + ps3 * ue + ps4 * un;
+        float snv = ps1 * vw + ps2 * vs + ps3 * ve + ps4 * vn;
+        float snuq = uw + us + ue + un;
+        float snvq = vw + vs + ve + vn;
+
+        // warped sampling position (ref .cu:732-747)
+        float xwp = (float)ii + uc;
+        float ywp = (float)jj + vc;
+        bool hitx = false, hity = false;
+        if (xwp < 0) { xwp = 0; hitx = true; }
+        if (xwp >= w) { xwp = (float)(w - 1); hitx = true; }
+        if (ywp < 0) { ywp = 0; hity = true; }
+        if (ywp >= h) { ywp = (float)(h - 1); hity = true; }
+        int x0 = (int)xwp, y0 = (int)ywp;
+        if (x0 == w - 1) x0 = w - 2;
+        if (y0 == h - 1) y0 = h - 2;
+        const float fx1 = (float)x0, fx2 = (float)(x0 + 1), fy1 = (float)y0, fy2 = (float)(y0 + 1);
+        const float p1 = (fx2 - xwp) / (fx2 - fx1);
+        const float p2 = (xwp - fx1) / (fx2 - fx1);
+        const float p3 = ((fy2 - ywp) / (fy2 - fy1));
+        const float p4 = ((ywp - fy1) / (fy2 - fy1));
+        const size_t c1 = (size_t)y0 * pitch + x0, c3 = c1 + pitch;
+
+        float t1 = 0, t2 = 0, t4 = 0, t5 = 0, t6 = 0, e1 = 0;
+        float g1 = 0, g2s = 0, g4 = 0, g5 = 0, g6 = 0, e2 = 0;
+        for (int c = 0; c < L.nc; c++) {
+            const size_t cb = L.cstride * c;
+#define OCT_BIL(F) (p3 * ((p1) * (F)[cb + c1] + (p2) * (F)[cb + c1 + 1]) + p4 * ((p1) * (F)[cb + c3] + (p2) * (F)[cb + c3 + 1]))
+            float w2 = OCT_BIL(L.img2);
+            float Ix = OCT_BIL(L.gx2);
+            float Iy = OCT_BIL(L.gy2);
+            float Ixx = OCT_BIL(L.gxx);
+            float Ixy = OCT_BIL(L.gxy);
+            float Iyy = OCT_BIL(L.gyy);
+#undef OCT_BIL
+            if (hitx) { Ix = 0.f; Ixx = 0.f; Ixy = 0.f; }
+            if (hity) { Iy = 0.f; Ixy = 0.f; Iyy = 0.f; }
+            float It = w2 - L.img1[cb + rc + ii];
+            float Ixt = Ix - L.gx1[cb + rc + ii];
+            float Iyt = Iy - L.gy1[cb + rc + ii];
+            float IxIx = Ix * Ix, IyIy = Iy * Iy, IxxIxx = Ixx * Ixx, IxyIxy = Ixy * Ixy, IyyIyy = Iyy * Iyy;
+            float na, nb, ncc;
+            if (P.dozim) {
+                na = (float)(1. / ((double)(IxIx + IyIy) + 1.));
+                nb = (float)(1. / ((double)(IxxIxx + IxyIxy) + 1.));
+                ncc = (float)(1. / ((double)(IxyIxy + IyyIyy) + 1.));
+            } else {
+                na = 1.f; nb = 1.f; ncc = 1.f;
+            }
+            e1 += na * It * It;
+            e2 += (nb * Ixt * Ixt + ncc * Iyt * Iyt);
+            t1 += (na * IxIx);
+            g1 += (nb * IxxIxx + ncc * IxyIxy);
+            t2 += na * Ix * Iy;
+            g2s += (nb * Ixx * Ixy + ncc * Iyy * Ixy);
+            t4 += (na * IyIy);
+            g4 += ((nb * IxyIxy + ncc * IyyIyy));
+            float naIt = -na * It;
+            float nbIxt = nb * Ixt;
+            float ncIyt = ncc * Iyt;
+            t5 += naIt * Ix;
+            g5 += -(nbIxt * Ixx + ncIyt * Ixy);
+            t6 += naIt * Iy;
+            g6 += -(nbIxt * Ixy + ncIyt * Iyy);
+        }
+        float pd = (float)((double)psi_data(e1) / alpha);
+        float pd2 = (float)(loa * (double)psi_data(e2));
+        float a1 = (float)((al1) * ((double)t1 / alpha + loa * (double)g1 + (double)lambdac + (double)pstotq)
+                           + (1 - al1) * (double)(pd * t1 + pd2 * g1 + lambdac + pstot));
+        float a2 = (float)((al1) * ((double)t2 / alpha + loa * (double)g2s)
+                           + (1 - al1) * (double)(pd * t2 + pd2 * g2s));
+        float a4 = (float)((al1) * ((double)t4 / alpha + loa * (double)g4 + (double)lambdac + (double)pstotq)
+                           + (1 - al1) * (double)(pd * t4 + pd2 * g4 + lambdac + pstot));
+        float a7 = (float)(-1 * (al1 + (1 - al1) * (double)ps3));   // east
+        float a8 = (float)(-1 * (al1 + (1 - al1) * (double)ps4));   // north
+
+        float hint_u = 0.f, hint_v = 0.f;
+        if (lambdac != 0.f) {   // 0*(finite) == 0 exactly, so the reads can be skipped
+            hint_u = lambdac * (uc - L.ut[rc + ii]);
+            hint_v = lambdac * (vc - L.vt[rc + ii]);
+        }
+        float bu = (float)(al1 * ((double)t5 / alpha + loa * (double)g5 - (double)hint_u + (double)snuq - (double)(pstotq * uc))
+                           + (1. - al1) * (double)(pd * t5 + pd2 * g5 - hint_u + snu - pstot * uc));
+        float bv = (float)(al1 * ((double)t6 / alpha + loa * (double)g6 - (double)hint_v + (double)snvq - (double)(pstotq * vc))
+                           + (1 - al1) * (double)(pd * t6 + pd2 * g6 - hint_v + snv - pstot * vc));
+        const size_t o = rc + ii;
+        L.a1[o] = a1; L.a2[o] = a2; L.a4[o] = a4; L.wx[o] = a7; L.wy[o] = a8;
+        L.ru[o] = bu; L.rv[o] = bv;
+        // r.r and r.z of the initial residual (ref .cu:1115-1126, 1157): z = (1/M) r
+        float zu = (float)(1. / (double)a1) * bu;
+        float zv = (float)(1. / (double)a4) * bv;
+        acc_rr += (double)(bu * bu) + (double)(bv * bv);
+        acc_rz += (double)(bu * zu) + (double)(bv * zv);
+    }
+    double tot_rr = block_sum_256(acc_rr, s_red);
+    double tot_rz = block_sum_256(acc_rz, s_red);
+    if (threadIdx.x == 0) {
+        L.part_rr[blockIdx.x] = tot_rr;
+        L.part_rz[blockIdx.x] = tot_rz;
+        if (blockIdx.x == 0) {
+            PcgState s0; s0.rz = 0.f; s0.stopped = 0; s0.iters = 0; s0.pad = 0;
+            L.st[0] = s0;
+        }
+    }
+}
+
+int assemble_grid_size(int w, int h)
+{
+    int tiles = ((w + kAsmTX - 1) / kAsmTX) * ((h + kAsmTY - 1) / kAsmTY);
+    return tiles < kMaxParts ? tiles : kMaxParts;
+}
+
+void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid)
+{
+    hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(256), 0, s, L, P);
+}
+
+}  // namespace octane

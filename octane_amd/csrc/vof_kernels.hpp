@@ -1,0 +1,77 @@
+// vof_kernels.hpp -- launch interface between the host driver (vof_plan.hip) and the
+// gfx950 kernels (vof_kernels.hip, pcg_kernels.hip).  Internal; the public boundary is
+// include/octane_vof.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace octane {
+
+// A 2-D float plane in HBM: w x h pixels, rows `pitch` floats apart (pitch % 64 == 0 for
+// planes the library owns, so every row starts on a 256-byte boundary).
+struct Plane {
+    float *p;
+    int w, h, pitch;
+};
+
+constexpr int kMaxChan = 3;
+constexpr int kMaxParts = 1024;      // upper bound on persistent blocks == reduction partials
+
+// PCG tile geometry: 256 threads, each owning 4 consecutive pixels of one row.
+constexpr int kTileX = 128;
+constexpr int kTileY = 8;
+
+// Scalars of one PCG solve, double-buffered by iteration parity (see pcg_kernels.hip).
+struct PcgState {
+    float rz;        // r.z of the last completed iteration (denominator of the next beta)
+    int stopped;     // sticky: the reference's while-condition failed
+    int iters;       // iterations executed in this solve
+    int pad;
+};
+
+struct LevelPtrs {       // everything one pyramid level's solve touches
+    int w, h, pitch, nc;
+    size_t cstride;                 // floats between channel planes
+    const float *img1, *img2;       // nc planes each
+    const float *gx1, *gy1, *gx2, *gy2, *gxx, *gxy, *gyy;
+    float *u, *v;
+    const float *ut, *vt;           // first-guess hint (only read when lambdac != 0)
+    float *a1, *a2, *a4, *wx, *wy;  // per-pixel operator coefficients
+    float *ru, *rv, *pu, *pv, *qu, *qv, *xu, *xv;   // r (starts as rhs), p, q = A p, x
+    double *part_rz, *part_rr, *part_pq;
+    PcgState *st;
+    long long *iter_total;
+};
+
+struct AssembleParams {
+    double al1, alpha, loa;   // GNC weight, alpha, lambda/alpha
+    float lambdac;
+    int dozim;
+};
+
+void launch_copy2d(hipStream_t s, const float *src, int spitch, float *dst, int dpitch, int w, int h);
+void launch_scale_copy2d(hipStream_t s, const float *src, int spitch, float *dst, int dpitch, int w, int h, float scale);
+void launch_blur_rows_sampled(hipStream_t s, const float *src, int sw, int sh, int spitch,
+                              float *dst, int dw, int dpitch, const float *gk, int fs, float factor);
+void launch_blur_cols_sampled(hipStream_t s, const float *src, int sw, int sh, int spitch,
+                              float *dst, int dh, int dpitch, const float *gk, int fs, float factor, float postscale, int do_scale);
+void launch_gradient(hipStream_t s, const float *f, float *gx, float *gy, int w, int h, int pitch, int nc, size_t cstride);
+void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpitch,
+                     float *fine, int fw, int fh, int fpitch, float sf);
+int  pcg_grid_size(int w, int h);
+int  assemble_grid_size(int w, int h);
+void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid);
+void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
+void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid);
+void launch_flow_update(hipStream_t s, const LevelPtrs &L, int niter_launched);
+
+struct NavArgs {
+    double pph, req, rpol, lam0;
+    float xScale, xOffset, yScale, yOffset;
+    float lat1, lon1, lon0, R;
+    int minX, minY, nx, ny;
+};
+void launch_pix2uv(hipStream_t s, const NavArgs &nav, double t1, double t2, const float *u, const float *v,
+                   int mode, short *ur, short *vr, short *ur2, short *vr2, long n);
+
+}  // namespace octane

@@ -1,0 +1,605 @@
+// vof_plan.hip -- host driver and C-ABI (include/octane_vof.h) of the variational flow core.
+//
+// Control flow restated from ref src/oct_variational_optical_flow.cu:487-1210 (level loop, three
+// GNC steps, liters re-linearisations, cgiters PCG iterations) and :1213-1473 (host wrapper).
+// The reference does all of this inside one cooperative launch with ~40 grid barriers per PCG
+// iteration; here each phase is a stream-ordered launch and the host never synchronises inside
+// a pyramid: the PCG stop test, alpha and beta live on the device (pcg_kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/octane_vof.h"
+#include "vof_kernels.hpp"
+
+namespace octane {
+int pcg_b_grid_size(int w, int h);
+}
+using namespace octane;
+
+static thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return OCTANE_E_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+struct LevelInfo {
+    float factor;
+    int w, h, pitch;
+    int fs;            // blur half width (unused at the finest level)
+    int tap_off;       // offset of this level's taps in the device tap table
+    float lambdac;
+};
+
+struct EvPair { hipEvent_t a, b; int kind; };
+
+struct octane_vof_plan {
+    octane_vof_params prm;
+    int nx, ny, nc, device;
+    int pitch0;
+    size_t plane0;                 // floats per full-resolution plane
+    std::vector<LevelInfo> lev;
+    float *arena = nullptr;
+    size_t arena_bytes = 0;
+    // planes (all plane0 floats unless noted)
+    float *img1p, *img2p, *uh, *vh, *lev1, *lev2;
+    float *gx1, *gy1, *gx2, *gy2, *gxx, *gxy, *gyy;
+    float *U[2], *V[2], *ut, *vt;
+    float *a1, *a2, *a4, *wx, *wy, *ru, *rv, *pu, *pv, *qu, *qv, *xu, *xv, *tmp;
+    float *d_taps = nullptr;
+    double *d_parts = nullptr;     // 3 * kMaxParts
+    PcgState *d_state = nullptr;   // 2
+    long long *d_iters = nullptr;
+    long long *h_iters = nullptr;  // pinned
+    hipStream_t own_stream = nullptr;
+    octane_vof_trace_fn trace = nullptr;
+    void *trace_user = nullptr;
+    int profiling = 0;
+    std::vector<EvPair> evs;
+    size_t evs_used = 0;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+    octane_vof_profile prof;
+    float tol;
+};
+
+extern "C" const char *octane_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int octane_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void octane_vof_default_params(octane_vof_params *p)
+{
+    if (!p) return;
+    p->alpha = 5.; p->lambda = 1.; p->lambdac = 0.; p->scaleF = 0.5; p->scsig = 400.;
+    p->kiters = 4; p->liters = 3; p->cgiters = 30; p->dozim = 1; p->device = 0;
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Gaussian taps exactly as the reference's single thread computes them (ref .cu:207-228);
+// 2*fs+1 values, normalised over all of them although only the first 2*fs are ever applied.
+static void gauss_taps(float factor, int fs, float *gk)
+{
+    float sigma = (float)(0.6 * std::sqrt(1.0 / (double)(factor * factor) - 1.0));
+    float s = (float)(2.0 * (double)sigma * (double)sigma);
+    float sum = 0.0f;
+    for (int x = -fs; x <= fs; x++) {
+        float r = (float)x;
+        gk[x + fs] = (float)((double)expf(-(r * r) / s) / (3.14159265358979323846 * (double)s));
+        sum += gk[x + fs];
+    }
+    for (int i = 0; i < 2 * fs + 1; ++i) gk[i] /= sum;
+}
+
+extern "C" int octane_vof_plan_destroy(octane_vof_plan *pl)
+{
+    if (!pl) return OCTANE_OK;
+    hipSetDevice(pl->device);
+    if (pl->own_stream) hipStreamSynchronize(pl->own_stream);
+    for (auto &e : pl->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    if (pl->ev_t0) hipEventDestroy(pl->ev_t0);
+    if (pl->ev_t1) hipEventDestroy(pl->ev_t1);
+    if (pl->ev_s0) hipEventDestroy(pl->ev_s0);
+    if (pl->ev_s1) hipEventDestroy(pl->ev_s1);
+    if (pl->arena) hipFree(pl->arena);
+    if (pl->d_taps) hipFree(pl->d_taps);
+    if (pl->d_parts) hipFree(pl->d_parts);
+    if (pl->d_state) hipFree(pl->d_state);
+    if (pl->d_iters) hipFree(pl->d_iters);
+    if (pl->h_iters) hipHostFree(pl->h_iters);
+    if (pl->own_stream) hipStreamDestroy(pl->own_stream);
+    delete pl;
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int nchan, const octane_vof_params *p)
+{
+    if (!out || !p || nx < 2 || ny < 2 || nchan < 1 || nchan > kMaxChan || p->kiters < 1 || p->kiters > 24 ||
+        p->liters < 0 || p->cgiters < 0 || !(p->alpha != 0.) || !(p->scaleF > 0. && p->scaleF <= 1.)) {
+        g_last_error = "octane_vof_plan_create: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    *out = nullptr;
+    int ndev = octane_device_count();
+    if (ndev == 0) { g_last_error = "No gpus available for use"; return OCTANE_E_NODEVICE; }
+    int dev = p->device;
+    if (dev > ndev - 1 || dev < 0) dev = 0;      // ref .cu:1260-1264
+    HIP_TRY(hipSetDevice(dev));
+
+    octane_vof_plan *pl = new octane_vof_plan();
+    pl->prm = *p; pl->nx = nx; pl->ny = ny; pl->nc = nchan; pl->device = dev;
+    pl->pitch0 = round_up(nx, 64);
+    pl->plane0 = (size_t)pl->pitch0 * ny;
+    pl->tol = (float)(0.0001 * 0.0001);          // ref .cu:1353
+    memset(&pl->prof, 0, sizeof(pl->prof));
+
+    const float scale = (float)p->scaleF;
+    const float lambdaco = (float)(p->lambdac / p->alpha);   // ref .cu:1236
+    std::vector<float> taps;
+    for (int k = 0; k < p->kiters; k++) {
+        LevelInfo li;
+        li.factor = (float)std::pow((double)scale, (double)(p->kiters - k - 1));   // ref .cu:488
+        li.w = (int)((double)nx * (double)li.factor + 0.5);                        // ref .cu:52-53
+        li.h = (int)((double)ny * (double)li.factor + 0.5);
+        li.pitch = round_up(li.w > 0 ? li.w : 1, 64);
+        li.lambdac = (float)((double)lambdaco * std::pow(0.5, (double)k));         // ref .cu:494
+        li.fs = 0; li.tap_off = 0;
+        if (li.w < 2 || li.h < 2) {
+            g_last_error = "a pyramid level would be smaller than 2 pixels; lower kiters";
+            delete pl;
+            return OCTANE_E_TOOSMALL;
+        }
+        if (k < p->kiters - 1) {
+            float sigma = (float)(1.0 / std::sqrt(2. * (double)li.factor));        // ref .cu:521-526
+            int fs = (int)(2 * sigma);
+            if (fs < 5) fs = 5;
+            li.fs = fs;
+            li.tap_off = (int)taps.size();
+            taps.resize(taps.size() + 2 * fs + 1);
+            gauss_taps(li.factor, fs, taps.data() + li.tap_off);
+        }
+        pl->lev.push_back(li);
+    }
+
+    const int nc = nchan;
+    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 13 + 1;
+    pl->arena_bytes = nplanes * pl->plane0 * sizeof(float);
+    hipError_t e = hipMalloc((void **)&pl->arena, pl->arena_bytes);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipMalloc of the plan arena failed: ") + hipGetErrorString(e);
+        delete pl;
+        return OCTANE_E_NOMEM;
+    }
+    float *cur = pl->arena;
+    auto take = [&](size_t n) { float *r = cur; cur += n * pl->plane0; return r; };
+    pl->img1p = take(nc); pl->img2p = take(nc); pl->uh = take(1); pl->vh = take(1);
+    pl->lev1 = take(nc); pl->lev2 = take(nc);
+    pl->gx1 = take(nc); pl->gy1 = take(nc); pl->gx2 = take(nc); pl->gy2 = take(nc);
+    pl->gxx = take(nc); pl->gxy = take(nc); pl->gyy = take(nc);
+    pl->U[0] = take(1); pl->U[1] = take(1); pl->V[0] = take(1); pl->V[1] = take(1);
+    pl->ut = take(1); pl->vt = take(1);
+    pl->a1 = take(1); pl->a2 = take(1); pl->a4 = take(1); pl->wx = take(1); pl->wy = take(1);
+    pl->ru = take(1); pl->rv = take(1); pl->pu = take(1); pl->pv = take(1);
+    pl->qu = take(1); pl->qv = take(1); pl->xu = take(1); pl->xv = take(1);
+    pl->tmp = take(1);
+
+    int rc = OCTANE_OK;
+    do {
+        size_t ntaps = taps.empty() ? 1 : taps.size();
+        if (hipMalloc((void **)&pl->d_taps, ntaps * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (!taps.empty() &&
+            hipMemcpy(pl->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMalloc((void **)&pl->d_parts, 3 * kMaxParts * sizeof(double)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&pl->d_state, 2 * sizeof(PcgState)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&pl->d_iters, sizeof(long long)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipHostMalloc((void **)&pl->h_iters, sizeof(long long)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        *pl->h_iters = 0;
+        if (hipMemset(pl->d_parts, 0, 3 * kMaxParts * sizeof(double)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemset(pl->d_state, 0, 2 * sizeof(PcgState)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipStreamCreateWithFlags(&pl->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+    } while (0);
+    if (rc != OCTANE_OK) {
+        g_last_error = "octane_vof_plan_create: device allocation failed";
+        octane_vof_plan_destroy(pl);
+        return rc;
+    }
+    *out = pl;
+    return OCTANE_OK;
+}
+
+extern "C" size_t octane_vof_plan_device_bytes(const octane_vof_plan *pl) { return pl ? pl->arena_bytes : 0; }
+
+extern "C" int octane_vof_plan_set_trace(octane_vof_plan *pl, octane_vof_trace_fn fn, void *user)
+{
+    if (!pl) return OCTANE_E_INVALID;
+    pl->trace = fn; pl->trace_user = user;
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_plan_set_profiling(octane_vof_plan *pl, int enable)
+{
+    if (!pl) return OCTANE_E_INVALID;
+    pl->profiling = enable ? 1 : 0;
+    return OCTANE_OK;
+}
+
+// ---- debug tap: copy planes to a dense host buffer and hand them to the callback -------------
+static int emit(octane_vof_plan *pl, hipStream_t s, const char *tag, int k, int gnc, int l,
+                std::initializer_list<const float *> planes, int w, int h, int pitch)
+{
+    if (!pl->trace) return OCTANE_OK;
+    std::vector<float> host((size_t)w * h * planes.size());
+    HIP_TRY(hipStreamSynchronize(s));
+    size_t i = 0;
+    for (const float *p : planes) {
+        HIP_TRY(hipMemcpy2D(host.data() + i * (size_t)w * h, (size_t)w * sizeof(float), p, (size_t)pitch * sizeof(float),
+                            (size_t)w * sizeof(float), h, hipMemcpyDeviceToHost));
+        i++;
+    }
+    pl->trace(pl->trace_user, tag, k, gnc, l, host.data(), w, h, (int)planes.size());
+    return OCTANE_OK;
+}
+
+static int emit_chan(octane_vof_plan *pl, hipStream_t s, const char *tag, int k, const float *base, int w, int h, int pitch)
+{
+    if (!pl->trace) return OCTANE_OK;
+    if (pl->nc == 1) return emit(pl, s, tag, k, -1, -1, {base}, w, h, pitch);
+    if (pl->nc == 2) return emit(pl, s, tag, k, -1, -1, {base, base + pl->plane0}, w, h, pitch);
+    return emit(pl, s, tag, k, -1, -1, {base, base + pl->plane0, base + 2 * pl->plane0}, w, h, pitch);
+}
+
+// ---- profiling helpers ---------------------------------------------------------------------
+enum { EV_PASS_A = 0, EV_PASS_B = 1, EV_ASM = 2, EV_UPD = 3 };
+
+static EvPair *ev_begin(octane_vof_plan *pl, hipStream_t s, int kind, bool on)
+{
+    if (!on) return nullptr;
+    if (pl->evs_used == pl->evs.size()) {
+        EvPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+        p.kind = kind;
+        pl->evs.push_back(p);
+    }
+    EvPair *p = &pl->evs[pl->evs_used++];
+    p->kind = kind;
+    hipEventRecord(p->a, s);
+    return p;
+}
+static void ev_end(EvPair *p, hipStream_t s) { if (p) hipEventRecord(p->b, s); }
+
+static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
+{
+    const octane_vof_params &prm = pl->prm;
+    const int nc = pl->nc;
+    const int nlev = (int)pl->lev.size();
+    const bool hint = (prm.lambdac != 0.);
+    int cur = 0;       // U[cur], V[cur] hold the flow of the level being solved
+    pl->evs_used = 0;
+    const bool prof = pl->profiling != 0;
+    if (prof) {
+        if (!pl->ev_t0) { hipEventCreate(&pl->ev_t0); hipEventCreate(&pl->ev_t1); hipEventCreate(&pl->ev_s0); hipEventCreate(&pl->ev_s1); }
+        hipEventRecord(pl->ev_t0, s);
+    }
+    HIP_TRY(hipMemsetAsync(pl->d_iters, 0, sizeof(long long), s));
+    double setup_ms = 0.;
+
+    for (int k = 0; k < nlev; k++) {
+        const LevelInfo &li = pl->lev[k];
+        const bool finest = (k == nlev - 1);
+        const float *lev1, *lev2, *ut, *vt;
+        if (prof) hipEventRecord(pl->ev_s0, s);
+        if (k > 0) {   // ref .cu:498-503: bicubic up-sample of the previous level's flow, divided by scaleF
+            const LevelInfo &lo = pl->lev[k - 1];
+            launch_upsample(s, pl->U[cur], lo.w, lo.h, lo.pitch, pl->U[cur ^ 1], li.w, li.h, li.pitch, (float)prm.scaleF);
+            launch_upsample(s, pl->V[cur], lo.w, lo.h, lo.pitch, pl->V[cur ^ 1], li.w, li.h, li.pitch, (float)prm.scaleF);
+            cur ^= 1;
+        }
+        if (finest) {  // ref .cu:504-517: the finest level uses the inputs themselves
+            lev1 = pl->img1p; lev2 = pl->img2p; ut = pl->uh; vt = pl->vh;
+        } else {       // ref .cu:519-563
+            const float *gk = pl->d_taps + li.tap_off;
+            // channel 0 only: the reference's zoom_out samples channel 0 for every channel (.cu:406)
+            launch_blur_rows_sampled(s, pl->img1p, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
+            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->lev1, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
+            launch_blur_rows_sampled(s, pl->img2p, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
+            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->lev2, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
+            for (int c = 1; c < nc; c++) {
+                launch_copy2d(s, pl->lev1, li.pitch, pl->lev1 + c * pl->plane0, li.pitch, li.w, li.h);
+                launch_copy2d(s, pl->lev2, li.pitch, pl->lev2 + c * pl->plane0, li.pitch, li.w, li.h);
+            }
+            if (hint || k == 0) {   // decimated first guess, scaled to this level's pixel size
+                launch_blur_rows_sampled(s, pl->uh, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
+                launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->ut, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
+                launch_blur_rows_sampled(s, pl->vh, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
+                launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->vt, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
+            }
+            lev1 = pl->lev1; lev2 = pl->lev2; ut = pl->ut; vt = pl->vt;
+        }
+        if (k == 0) {  // ref .cu:576-585
+            launch_copy2d(s, ut, li.pitch, pl->U[cur], li.pitch, li.w, li.h);
+            launch_copy2d(s, vt, li.pitch, pl->V[cur], li.pitch, li.w, li.h);
+        }
+        // ref .cu:587-595; d/dy of gx2 is dead (overwritten by the fourth call), so it is not stored
+        launch_gradient(s, lev1, pl->gx1, pl->gy1, li.w, li.h, li.pitch, nc, pl->plane0);
+        launch_gradient(s, lev2, pl->gx2, pl->gy2, li.w, li.h, li.pitch, nc, pl->plane0);
+        launch_gradient(s, pl->gx2, pl->gxx, nullptr, li.w, li.h, li.pitch, nc, pl->plane0);
+        launch_gradient(s, pl->gy2, pl->gxy, pl->gyy, li.w, li.h, li.pitch, nc, pl->plane0);
+        if (prof) {
+            hipEventRecord(pl->ev_s1, s);
+            hipEventSynchronize(pl->ev_s1);
+            float ms = 0.f; hipEventElapsedTime(&ms, pl->ev_s0, pl->ev_s1);
+            setup_ms += ms;
+        }
+
+        if (pl->trace) {
+            int rc;
+            if ((rc = emit_chan(pl, s, "img1", k, lev1, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "img2", k, lev2, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gx1", k, pl->gx1, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gy1", k, pl->gy1, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gx2", k, pl->gx2, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gy2", k, pl->gy2, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gxx", k, pl->gxx, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gxy", k, pl->gxy, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gyy", k, pl->gyy, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit(pl, s, "u0", k, -1, -1, {pl->U[cur]}, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit(pl, s, "v0", k, -1, -1, {pl->V[cur]}, li.w, li.h, li.pitch))) return rc;
+        }
+
+        LevelPtrs L;
+        L.w = li.w; L.h = li.h; L.pitch = li.pitch; L.nc = nc; L.cstride = pl->plane0;
+        L.img1 = lev1; L.img2 = lev2;
+        L.gx1 = pl->gx1; L.gy1 = pl->gy1; L.gx2 = pl->gx2; L.gy2 = pl->gy2;
+        L.gxx = pl->gxx; L.gxy = pl->gxy; L.gyy = pl->gyy;
+        L.u = pl->U[cur]; L.v = pl->V[cur]; L.ut = ut; L.vt = vt;
+        L.a1 = pl->a1; L.a2 = pl->a2; L.a4 = pl->a4; L.wx = pl->wx; L.wy = pl->wy;
+        L.ru = pl->ru; L.rv = pl->rv; L.pu = pl->pu; L.pv = pl->pv;
+        L.qu = pl->qu; L.qv = pl->qv; L.xu = pl->xu; L.xv = pl->xv;
+        L.part_rz = pl->d_parts; L.part_rr = pl->d_parts + kMaxParts; L.part_pq = pl->d_parts + 2 * kMaxParts;
+        L.st = pl->d_state; L.iter_total = pl->d_iters;
+
+        const int g_asm = assemble_grid_size(li.w, li.h);
+        const int g_a = pcg_grid_size(li.w, li.h);
+        const int g_b = pcg_b_grid_size(li.w, li.h);
+        const bool pf = prof && finest;
+
+        for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
+            AssembleParams ap;
+            ap.al1 = 1. - 0.5 * gnc;
+            ap.alpha = prm.alpha;
+            ap.loa = prm.lambda / prm.alpha;                // ref .cu:1230
+            ap.lambdac = li.lambdac;
+            ap.dozim = prm.dozim != 0;
+            for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
+                EvPair *e = ev_begin(pl, s, EV_ASM, pf);
+                launch_assemble(s, L, ap, g_asm);
+                ev_end(e, s);
+                if (pl->trace) {
+                    int rc = emit(pl, s, "coef7", k, gnc, l, {pl->a1, pl->a2, pl->a4, pl->wx, pl->wy, pl->ru, pl->rv}, li.w, li.h, li.pitch);
+                    if (rc) return rc;
+                }
+                for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182
+                    e = ev_begin(pl, s, EV_PASS_A, pf);
+                    launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
+                    ev_end(e, s);
+                    e = ev_begin(pl, s, EV_PASS_B, pf);
+                    launch_pcg_pass_b(s, L, it, g_a, g_b);
+                    ev_end(e, s);
+                }
+                e = ev_begin(pl, s, EV_UPD, pf);
+                launch_flow_update(s, L, prm.cgiters);      // ref .cu:1185-1195
+                ev_end(e, s);
+                if (pl->trace) {
+                    int rc;
+                    if ((rc = emit(pl, s, "dx2", k, gnc, l, {pl->xu, pl->xv}, li.w, li.h, li.pitch))) return rc;
+                    if ((rc = emit(pl, s, "u", k, gnc, l, {pl->U[cur]}, li.w, li.h, li.pitch))) return rc;
+                    if ((rc = emit(pl, s, "v", k, gnc, l, {pl->V[cur]}, li.w, li.h, li.pitch))) return rc;
+                }
+            }
+        }
+        if (pl->trace) {
+            int rc;
+            if ((rc = emit(pl, s, "ulev", k, -1, -1, {pl->U[cur]}, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit(pl, s, "vlev", k, -1, -1, {pl->V[cur]}, li.w, li.h, li.pitch))) return rc;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(pl->h_iters, pl->d_iters, sizeof(long long), hipMemcpyDeviceToHost, s));
+    if (prof) {
+        hipEventRecord(pl->ev_t1, s);
+        HIP_TRY(hipEventSynchronize(pl->ev_t1));
+        octane_vof_profile pr;
+        memset(&pr, 0, sizeof(pr));
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, pl->ev_t0, pl->ev_t1);
+        pr.total_ms = ms; pr.setup_ms = setup_ms;
+        pr.finest_pixels = (long long)pl->nx * pl->ny;
+        for (size_t i = 0; i < pl->evs_used; i++) {
+            hipEventElapsedTime(&ms, pl->evs[i].a, pl->evs[i].b);
+            switch (pl->evs[i].kind) {
+            case EV_PASS_A: pr.pass_a_ms += ms; pr.pass_a_launches++; break;
+            case EV_PASS_B: pr.pass_b_ms += ms; pr.pass_b_launches++; break;
+            case EV_ASM: pr.assemble_ms += ms; pr.assemble_launches++; break;
+            default: pr.update_ms += ms; pr.update_launches++; break;
+            }
+        }
+        pl->prof = pr;
+    }
+    // the result lives in U[cur], V[cur]; remember which for the copy-out
+    pl->prof.finest_pixels = (long long)pl->nx * pl->ny;
+    return cur;   // >= 0
+}
+
+extern "C" int octane_vof_plan_get_profile(octane_vof_plan *pl, octane_vof_profile *out)
+{
+    if (!pl || !out) return OCTANE_E_INVALID;
+    *out = pl->prof;
+    return OCTANE_OK;
+}
+
+extern "C" long long octane_vof_plan_last_iterations(octane_vof_plan *pl)
+{
+    if (!pl) return -1;
+    return *pl->h_iters;
+}
+
+extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const float *img2,
+                                   float *u, float *v, int mem, void *hip_stream)
+{
+    if (!pl || !img1 || !img2 || !u || !v || (mem != OCTANE_MEM_HOST && mem != OCTANE_MEM_DEVICE)) {
+        g_last_error = "octane_vof_plan_run: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(pl->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : pl->own_stream;
+    const int nx = pl->nx, ny = pl->ny, nc = pl->nc, p0 = pl->pitch0;
+    const size_t dense_row = (size_t)nx * sizeof(float), pitched_row = (size_t)p0 * sizeof(float);
+    if (mem == OCTANE_MEM_HOST) {   // ref .cu:1330-1352 (element-wise fills of managed memory there)
+        for (int c = 0; c < nc; c++) {
+            HIP_TRY(hipMemcpy2DAsync(pl->img1p + c * pl->plane0, pitched_row, img1 + (size_t)c * nx * ny, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpy2DAsync(pl->img2p + c * pl->plane0, pitched_row, img2 + (size_t)c * nx * ny, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
+        }
+        HIP_TRY(hipMemcpy2DAsync(pl->uh, pitched_row, u, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpy2DAsync(pl->vh, pitched_row, v, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
+    } else {
+        for (int c = 0; c < nc; c++) {
+            launch_copy2d(s, img1 + (size_t)c * nx * ny, nx, pl->img1p + c * pl->plane0, p0, nx, ny);
+            launch_copy2d(s, img2 + (size_t)c * nx * ny, nx, pl->img2p + c * pl->plane0, p0, nx, ny);
+        }
+        launch_copy2d(s, u, nx, pl->uh, p0, nx, ny);
+        launch_copy2d(s, v, nx, pl->vh, p0, nx, ny);
+    }
+    int cur = run_on_stream(pl, s);
+    if (cur < 0) return cur;
+    if (mem == OCTANE_MEM_HOST) {   // ref .cu:1432-1438
+        HIP_TRY(hipMemcpy2DAsync(u, dense_row, pl->U[cur], pitched_row, dense_row, ny, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpy2DAsync(v, dense_row, pl->V[cur], pitched_row, dense_row, ny, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        launch_copy2d(s, pl->U[cur], p0, u, nx, nx, ny);
+        launch_copy2d(s, pl->V[cur], p0, v, nx, nx, ny);
+    }
+    HIP_TRY(hipGetLastError());
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_run(const float *img1, const float *img2, int nx, int ny, int nchan,
+                              float *u, float *v, const octane_vof_params *p)
+{
+    octane_vof_plan *pl = nullptr;
+    int rc = octane_vof_plan_create(&pl, nx, ny, nchan, p);
+    if (rc != OCTANE_OK) return rc;
+    rc = octane_vof_plan_run(pl, img1, img2, u, v, OCTANE_MEM_HOST, nullptr);
+    octane_vof_plan_destroy(pl);
+    return rc;
+}
+
+extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const float *const *img2,
+                                    int nx, int ny, int nchan, float *const *u, float *const *v,
+                                    const octane_vof_params *p, int ndevices, const int *devices)
+{
+    if (npairs < 0 || !img1 || !img2 || !u || !v || !p || ndevices < 1) {
+        g_last_error = "octane_vof_batch_run: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    std::vector<int> rcs(ndevices, OCTANE_OK);
+    std::vector<std::string> errs(ndevices);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < ndevices; d++) {
+        workers.emplace_back([&, d]() {
+            octane_vof_params prm = *p;
+            prm.device = devices ? devices[d] : d;
+            octane_vof_plan *pl = nullptr;
+            bool any = false;
+            for (int b = d; b < npairs; b += ndevices) { any = true; break; }
+            if (!any) return;
+            int rc = octane_vof_plan_create(&pl, nx, ny, nchan, &prm);
+            for (int b = d; rc == OCTANE_OK && b < npairs; b += ndevices)
+                rc = octane_vof_plan_run(pl, img1[b], img2[b], u[b], v[b], OCTANE_MEM_HOST, nullptr);
+            if (rc != OCTANE_OK) errs[d] = g_last_error;
+            rcs[d] = rc;
+            octane_vof_plan_destroy(pl);
+        });
+    }
+    for (auto &t : workers) t.join();
+    for (int d = 0; d < ndevices; d++)
+        if (rcs[d] != OCTANE_OK) { g_last_error = errs[d]; return rcs[d]; }
+    return OCTANE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pix2uv (ref src/oct_pix2uv_cuda.cu:265-370)
+// ---------------------------------------------------------------------------------------------
+extern "C" int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, const float *u, const float *v,
+                                 int pixuv, int mode, short *ur, short *vr, short *ur2, short *vr2,
+                                 float *dT, int *sector_moved, int device)
+{
+    if (!nav || !u || !v || !ur || !vr || nav->nx < 1 || nav->ny < 1 || mode < 0 || mode > 2 ||
+        (pixuv == 0 && (!ur2 || !vr2))) {
+        g_last_error = "octane_pix2uv_run: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    const long n = (long)nav->nx * nav->ny;
+    if (dT) *dT = (float)(t2 - t1);
+    if (sector_moved) *sector_moved = 0;
+    const float dx = nav->xOffset - nav->g2xOffset, dy = nav->yOffset - nav->g2yOffset;
+    const bool same = (((double)(dx * dx) < (0.00001 * 0.00001)) && ((double)(dy * dy) < (0.00001 * 0.00001)));   // ref p2u:295
+    if (!same) {                      // ref p2u:358-368
+        for (long k = 0; k < n; k++) { ur[k] = 0; vr[k] = 0; }
+        if (ur2 && vr2) for (long k = 0; k < n; k++) { ur2[k] = 0; vr2[k] = 0; }
+        if (sector_moved) *sector_moved = 1;
+        return OCTANE_OK;
+    }
+    if (pixuv != 0) {                 // ref p2u:348-356: no navigation, host-only in the reference too
+        for (long k = 0; k < n; k++) { ur[k] = (short)(100 * u[k]); vr[k] = (short)(100 * v[k]); }
+        return OCTANE_OK;
+    }
+    int ndev = octane_device_count();
+    if (ndev == 0) { g_last_error = "No gpus available for use"; return OCTANE_E_NODEVICE; }
+    if (device > ndev - 1 || device < 0) device = 0;
+    HIP_TRY(hipSetDevice(device));
+    float *du = nullptr, *dv = nullptr;
+    short *dout = nullptr;
+    hipStream_t s = nullptr;
+    int rc = OCTANE_OK;
+    do {
+        if (hipMalloc((void **)&du, n * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&dv, n * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&dout, 4 * n * sizeof(short)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipStreamCreate(&s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(du, u, n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(dv, v, n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        NavArgs a;
+        a.pph = nav->pph; a.req = nav->req; a.rpol = nav->rpol; a.lam0 = nav->lam0;
+        a.xScale = nav->xScale; a.xOffset = nav->xOffset; a.yScale = nav->yScale; a.yOffset = nav->yOffset;
+        a.lat1 = nav->lat1; a.lon1 = nav->lon1; a.lon0 = nav->lon0; a.R = nav->R;
+        a.minX = nav->minX; a.minY = nav->minY; a.nx = nav->nx; a.ny = nav->ny;
+        launch_pix2uv(s, a, t1, t2, du, dv, mode, dout, dout + n, dout + 2 * n, dout + 3 * n, n);
+        if (hipGetLastError() != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(ur, dout, n * sizeof(short), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(vr, dout + n, n * sizeof(short), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(ur2, dout + 2 * n, n * sizeof(short), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(vr2, dout + 3 * n, n * sizeof(short), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+    } while (0);
+    if (rc != OCTANE_OK) g_last_error = "octane_pix2uv_run: HIP failure";
+    if (s) hipStreamDestroy(s);
+    if (du) hipFree(du);
+    if (dv) hipFree(dv);
+    if (dout) hipFree(dout);
+    return rc;
+}
