@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpix/s of the full coarse-to-fine solve (BASELINE.json's metric).
+
+A "step" is one whole oct_variational_optical_flow call on one image pair: pyramid build, and per
+level 3 GNC x liters assemblies, each followed by cgiters PCG iterations -- with the pair already
+resident in HBM when the timed region starts.  Workload at every N: BASELINE.json configs[2]
+("R1"): 5000x5000, kiters=8, liters=3, cgiters=30, one channel, synthetic lattice
+scene.  With N ranks each rank solves its own independent pair on its own GPU (the path shards
+over pairs: no collective in the data path; weak scaling); value = N * pixels / max-over-ranks
+time.
+
+The JSON line also carries
+  roofline      -- dominant kernel (PCG pass A at the finest level): algorithmic bytes per launch
+                   (52 B/pixel) / its mean duration from HIP events on the launch stream;
+  cpu_baseline  -- the CPU oracle ("port", 1 core) timed on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PASS_A_BYTES_PER_PIXEL = 36 + 16   # reads r(2) p(2) a1 a2 a4 wx wy, writes p(2) q(2)  -- DESIGN.md
+PASS_B_BYTES_PER_PIXEL = 40 + 16   # reads x(2) r(2) p(2) q(2) a1 a4, writes x(2) r(2)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=5000)
+    ap.add_argument("--kiters", type=int, default=8)
+    ap.add_argument("--liters", type=int, default=3)
+    ap.add_argument("--cgiters", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=768, help="edge of the CPU-baseline sample pair")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from octane_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if capi.lib().octane_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n = args.size
+    prm = capi.FlowParams(kiters=args.kiters, liters=args.liters, cgiters=args.cgiters, device=local)
+    a, b = synth.lattice_scene(n, n, seed=20240613 + 2 + rank, device=dev)
+    u = torch.zeros(n, n, device=dev)
+    v = torch.zeros(n, n, device=dev)
+    plan = capi.Plan(n, n, 1, prm)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        u.zero_(); v.zero_()           # zero first guess, as oct_optical_flow.cc:38-48
+        plan.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    iters = plan.last_iterations()
+    expect = args.kiters * 3 * args.liters * args.cgiters
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * n * n / (elapsed / args.steps) / 1e6
+
+    # per-kernel durations of the finest level: one extra, untimed, profiled step (HIP events are
+    # recorded on the launch stream around every finest-level launch)
+    roof = None
+    if rank == 0:
+        plan.set_profiling(True)
+        step()
+        torch.cuda.synchronize()
+        pr = plan.profile()
+        plan.set_profiling(False)
+        a_ms = pr.pass_a_ms / max(1, pr.pass_a_launches)
+        b_ms = pr.pass_b_ms / max(1, pr.pass_b_launches)
+        if pr.pass_a_ms >= pr.pass_b_ms:
+            dom, dms, bpp = "k_pcg_pass_a", a_ms, PASS_A_BYTES_PER_PIXEL
+        else:
+            dom, dms, bpp = "k_pcg_pass_b", b_ms, PASS_B_BYTES_PER_PIXEL
+        achieved = bpp * n * n / (dms * 1e-3) / 1e9
+        iter_gbs = (PASS_A_BYTES_PER_PIXEL + PASS_B_BYTES_PER_PIXEL + 8) * n * n / ((a_ms + b_ms) * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(dms, 4), "bytes_per_launch": bpp * n * n,
+                "pass_a_ms": round(a_ms, 4), "pass_b_ms": round(b_ms, 4),
+                "pcg_iteration_gbs_at_116B_per_pixel": round(iter_gbs, 1),
+                "assemble_ms": round(pr.assemble_ms / max(1, pr.assemble_launches), 4),
+                "setup_ms_all_levels": round(pr.setup_ms, 3), "profiled_step_ms": round(pr.total_ms, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oct_oracle as oo     # the checker, timed as the CPU baseline ("port")
+        m = args.cpu_sample
+        ca, cb = synth.lattice_scene(m, m, seed=20240613 + 2)
+        ck = 4
+        t1 = time.perf_counter()
+        _, _, cits = oo.flow(ca, cb, oo.FlowParams(kiters=ck, liters=args.liters, cgiters=args.cgiters))
+        ct = time.perf_counter() - t1
+        # same work per pixel-iteration as the GPU workload; scale Mpix/s by iterations per pyramid
+        cpu_mpix = m * m / ct / 1e6 * (ck / args.kiters)
+        cpu = {"value": round(cpu_mpix, 5), "unit": "Mpix/s", "cores": 1, "kind": "port",
+               "sample": f"{m}x{m} lattice pair, kiters={ck} liters={args.liters} cgiters={args.cgiters} "
+                         f"({cits} PCG iterations) in {ct:.1f} s on 1 host core; Mpix/s scaled by {ck}/{args.kiters} "
+                         f"to the workload's levels"}
+
+    if rank == 0:
+        out = {"metric": "Mpix/s (full pyramid) at %dx%d" % (n, n), "value": round(value, 3), "unit": "Mpix/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan=1 "
+                                      f"alpha=5 lambda=1 (BASELINE.json configs[2], SURVEY 8d run R1), "
+                                      f"{iters} PCG iterations per pyramid (expected {expect}), one pair per GPU",
+                          "sharding": "independent pairs, no data-path collective"},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,9 +67,10 @@ size_t octane_vof_plan_device_bytes(const octane_vof_plan *plan);
 
 #define OCTANE_MEM_HOST   0
 #define OCTANE_MEM_DEVICE 1
-/* Solve one pair.  mem says where img1/img2/u/v live.  hip_stream is a hipStream_t (NULL = the
- * plan's own stream).  With OCTANE_MEM_DEVICE the call only enqueues work on the stream and
- * returns; with OCTANE_MEM_HOST it synchronises before returning. */
+/* Solve one pair.  mem says where img1/img2/u/v live.  hip_stream is a hipStream_t.
+ * OCTANE_MEM_DEVICE: the call only enqueues work on hip_stream (NULL = HIP's null stream) and
+ * returns.  OCTANE_MEM_HOST: the call uploads, solves, downloads and synchronises before
+ * returning (NULL = a stream private to the plan). */
 int octane_vof_plan_run(octane_vof_plan *plan, const float *img1, const float *img2,
                         float *u_inout, float *v_inout, int mem, void *hip_stream);
 

@@ -55,6 +55,23 @@ TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so
+    (SONAME libamdhip64.so.7) but asks for it as "libamdhip64.so"; if this library pulled in
+    /opt/rocm's copy first, a later `import torch` would map a second runtime and see no GPU.
+    Loading torch's copy by path first makes both resolve to the same object, whatever the
+    import order (torch tensors and streams are handed to this library in bench.py/tests)."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):  # pragma: no cover
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 class OctaneError(RuntimeError):
     def __init__(self, code: int, where: str):
         self.code = code
@@ -74,6 +91,7 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C octane_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.octane_vof_default_params.argtypes = [C.POINTER(VofParams)]

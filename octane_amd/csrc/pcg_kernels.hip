@@ -66,6 +66,12 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
     const int ntiles = tiles_x * tiles_y;
     const int lx = tid & 31, ly = tid >> 5;
     double acc = 0.;
+    // p is updated out of place: neighbouring tiles re-read the OLD p for their halo while this
+    // block writes the new one, so in-place would race across workgroups.
+    const float *__restrict__ pin_u = L.pu[k & 1];
+    const float *__restrict__ pin_v = L.pv[k & 1];
+    float *__restrict__ pout_u = L.pu[(k + 1) & 1];
+    float *__restrict__ pout_v = L.pv[(k + 1) & 1];
 
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tx0 = (t % tiles_x) * kTileX, ty0 = (t / tiles_x) * kTileY;
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
             if (y > 0) *(float4 *)wys = ld4(L.wy + o - pitch);
             if (x > 0) wxw = L.wx[o - 1];
             float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
-            if (!first) { *(float4 *)pu = ld4(L.pu + o); *(float4 *)pv = ld4(L.pv + o); }
+            if (!first) { *(float4 *)pu = ld4(pin_u + o); *(float4 *)pv = ld4(pin_v + o); }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const bool ok = (x + e) < w;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
                 float r0[4], r1[4], d0[4], d1[4], q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
                 *(float4 *)r0 = ld4(L.ru + ho); *(float4 *)r1 = ld4(L.rv + ho);
                 *(float4 *)d0 = ld4(L.a1 + ho); *(float4 *)d1 = ld4(L.a4 + ho);
-                if (!first) { *(float4 *)q0 = ld4(L.pu + ho); *(float4 *)q1 = ld4(L.pv + ho); }
+                if (!first) { *(float4 *)q0 = ld4(pin_u + ho); *(float4 *)q1 = ld4(pin_v + ho); }
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const bool ok = (hx + e) < w;
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
             float hu = 0.f, hv = 0.f;
             if (hy < h && hx >= 0 && hx < w) {
                 const size_t ho = (size_t)hy * pitch + hx;
-                const float q0 = first ? 0.f : L.pu[ho], q1 = first ? 0.f : L.pv[ho];
+                const float q0 = first ? 0.f : pin_u[ho], q1 = first ? 0.f : pin_v[ho];
                 hu = direction(L.ru[ho], q0, L.a1[ho], beta, first);
                 hv = direction(L.rv[ho], q1, L.a4[ho], beta, first);
             }
@@ -173,8 +179,8 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
                 qu[e] = sumu; qv[e] = sumv;
                 if (i < w) acc += (double)(npu[e] * sumu) + (double)(npv[e] * sumv);
             }
-            st4(L.pu + o, *(float4 *)npu);
-            st4(L.pv + o, *(float4 *)npv);
+            st4(pout_u + o, *(float4 *)npu);
+            st4(pout_v + o, *(float4 *)npv);
             st4(L.qu + o, *(float4 *)qu);
             st4(L.qv + o, *(float4 *)qv);
         }
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
         const size_t o = (size_t)y * pitch + x;
         float xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0}, ru[4], rv[4], pu[4], pv[4], qu[4], qv[4], a1[4], a4[4];
         *(float4 *)ru = ld4(L.ru + o); *(float4 *)rv = ld4(L.rv + o);
-        *(float4 *)pu = ld4(L.pu + o); *(float4 *)pv = ld4(L.pv + o);
+        *(float4 *)pu = ld4(L.pu[(k + 1) & 1] + o); *(float4 *)pv = ld4(L.pv[(k + 1) & 1] + o);
         *(float4 *)qu = ld4(L.qu + o); *(float4 *)qv = ld4(L.qv + o);
         *(float4 *)a1 = ld4(L.a1 + o); *(float4 *)a4 = ld4(L.a4 + o);
         if (!first) { *(float4 *)xu = ld4(L.xu + o); *(float4 *)xv = ld4(L.xv + o); }

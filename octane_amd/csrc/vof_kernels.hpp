@@ -37,7 +37,9 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     float *u, *v;
     const float *ut, *vt;           // first-guess hint (only read when lambdac != 0)
     float *a1, *a2, *a4, *wx, *wy;  // per-pixel operator coefficients
-    float *ru, *rv, *pu, *pv, *qu, *qv, *xu, *xv;   // r (starts as rhs), p, q = A p, x
+    float *ru, *rv, *qu, *qv, *xu, *xv;             // r (starts as rhs), q = A p, x
+    float *pu[2], *pv[2];                           // search direction, ping-pong by iteration parity:
+                                                    // pass A(k) reads p[k&1] (halo too) and writes p[(k+1)&1]
     double *part_rz, *part_rr, *part_pq;
     PcgState *st;
     long long *iter_total;

@@ -55,7 +55,7 @@ struct octane_vof_plan {
     float *img1p, *img2p, *uh, *vh, *lev1, *lev2;
     float *gx1, *gy1, *gx2, *gy2, *gxx, *gxy, *gyy;
     float *U[2], *V[2], *ut, *vt;
-    float *a1, *a2, *a4, *wx, *wy, *ru, *rv, *pu, *pv, *qu, *qv, *xu, *xv, *tmp;
+    float *a1, *a2, *a4, *wx, *wy, *ru, *rv, *pu[2], *pv[2], *qu, *qv, *xu, *xv, *tmp;
     float *d_taps = nullptr;
     double *d_parts = nullptr;     // 3 * kMaxParts
     PcgState *d_state = nullptr;   // 2
@@ -176,13 +176,20 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     }
 
     const int nc = nchan;
-    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 13 + 1;
+    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 15 + 1;
     pl->arena_bytes = nplanes * pl->plane0 * sizeof(float);
     hipError_t e = hipMalloc((void **)&pl->arena, pl->arena_bytes);
     if (e != hipSuccess) {
         g_last_error = std::string("hipMalloc of the plan arena failed: ") + hipGetErrorString(e);
         delete pl;
         return OCTANE_E_NOMEM;
+    }
+    // Poison the arena with NaNs: a kernel that consumed a value nobody wrote would show up as a
+    // NaN flow field instead of a silently run-dependent one (tests rely on this).
+    if (hipMemset(pl->arena, 0xFF, pl->arena_bytes) != hipSuccess) {
+        g_last_error = "hipMemset of the plan arena failed";
+        octane_vof_plan_destroy(pl);
+        return OCTANE_E_HIP;
     }
     float *cur = pl->arena;
     auto take = [&](size_t n) { float *r = cur; cur += n * pl->plane0; return r; };
@@ -193,7 +200,8 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     pl->U[0] = take(1); pl->U[1] = take(1); pl->V[0] = take(1); pl->V[1] = take(1);
     pl->ut = take(1); pl->vt = take(1);
     pl->a1 = take(1); pl->a2 = take(1); pl->a4 = take(1); pl->wx = take(1); pl->wy = take(1);
-    pl->ru = take(1); pl->rv = take(1); pl->pu = take(1); pl->pv = take(1);
+    pl->ru = take(1); pl->rv = take(1);
+    pl->pu[0] = take(1); pl->pu[1] = take(1); pl->pv[0] = take(1); pl->pv[1] = take(1);
     pl->qu = take(1); pl->qv = take(1); pl->xu = take(1); pl->xv = take(1);
     pl->tmp = take(1);
 
@@ -367,7 +375,8 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         L.gxx = pl->gxx; L.gxy = pl->gxy; L.gyy = pl->gyy;
         L.u = pl->U[cur]; L.v = pl->V[cur]; L.ut = ut; L.vt = vt;
         L.a1 = pl->a1; L.a2 = pl->a2; L.a4 = pl->a4; L.wx = pl->wx; L.wy = pl->wy;
-        L.ru = pl->ru; L.rv = pl->rv; L.pu = pl->pu; L.pv = pl->pv;
+        L.ru = pl->ru; L.rv = pl->rv;
+        L.pu[0] = pl->pu[0]; L.pu[1] = pl->pu[1]; L.pv[0] = pl->pv[0]; L.pv[1] = pl->pv[1];
         L.qu = pl->qu; L.qv = pl->qv; L.xu = pl->xu; L.xv = pl->xv;
         L.part_rz = pl->d_parts; L.part_rr = pl->d_parts + kMaxParts; L.part_pq = pl->d_parts + 2 * kMaxParts;
         L.st = pl->d_state; L.iter_total = pl->d_iters;
@@ -465,7 +474,10 @@ extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const
         return OCTANE_E_INVALID;
     }
     HIP_TRY(hipSetDevice(pl->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : pl->own_stream;
+    // Device buffers: the work is ordered on exactly the stream the caller names (NULL is HIP's
+    // null stream, which is what PyTorch's default stream is).  Host buffers: the call blocks
+    // anyway, so NULL selects the plan's private stream.
+    hipStream_t s = (mem == OCTANE_MEM_DEVICE || hip_stream) ? (hipStream_t)hip_stream : pl->own_stream;
     const int nx = pl->nx, ny = pl->ny, nc = pl->nc, p0 = pl->pitch0;
     const size_t dense_row = (size_t)nx * sizeof(float), pitched_row = (size_t)p0 * sizeof(float);
     if (mem == OCTANE_MEM_HOST) {   // ref .cu:1330-1352 (element-wise fills of managed memory there)

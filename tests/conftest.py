@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
+
+
+def rel_l2(u, v, uo, vo):
+    """Relative L2 distance of the flow field (u,v) from (uo,vo): the parity metric of
+    BASELINE.json's north_star (bar: 1e-4)."""
+    num = ((np.asarray(u, np.float64) - uo) ** 2 + (np.asarray(v, np.float64) - vo) ** 2).sum()
+    den = (np.asarray(uo, np.float64) ** 2 + np.asarray(vo, np.float64) ** 2).sum()
+    return float(np.sqrt(num / den)) if den > 0 else float(np.sqrt(num))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oct_oracle
+    oct_oracle.build()
+    return oct_oracle
+
+
+@pytest.fixture(scope="session")
+def golden_ref():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_helpers.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_flow():
+    return np.load(os.path.join(ROOT, "tests", "golden", "oracle_flow.npz"))
+
+
+@pytest.fixture(scope="session")
+def capi():
+    """The product binding.  Builds the HIP library if it is not there yet (hipcc cross-compiles
+    without a GPU)."""
+    from octane_amd import capi as _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "octane_amd", "csrc"), "-s"])
+    return _capi

@@ -1,0 +1,91 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol
+include/octane_vof.h declares, and fails loudly (never falls back) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "octane_vof.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(octane_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    L = capi.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/octane_vof.h but not exported"
+    assert sorted(capi.EXPORTS) == declared
+
+
+def test_default_params_are_the_reference_cli_defaults(capi):
+    p = capi.default_params()      # ref src/main.cc:78-96
+    assert (p.alpha, p.lambda_, p.lambdac, p.scaleF) == (5.0, 1.0, 0.0, 0.5)
+    assert (p.kiters, p.liters, p.cgiters, p.dozim, p.device) == (4, 3, 30, 1, 0)
+
+
+def test_struct_layouts_match_the_header(capi):
+    assert C.sizeof(capi.VofParams) == 5 * 8 + 5 * 4 + 4     # 5 doubles, 5 ints, tail padding
+    assert C.sizeof(capi.Nav) == 4 * 8 + 10 * 4 + 4 * 4
+
+
+def test_invalid_arguments_are_rejected(capi):
+    L = capi.lib()
+    h = C.c_void_p()
+    p = capi.FlowParams().c()
+    assert L.octane_vof_plan_create(C.byref(h), 1, 64, 1, C.byref(p)) == capi.E_INVALID
+    assert L.octane_vof_plan_create(C.byref(h), 64, 64, 4, C.byref(p)) == capi.E_INVALID
+    p.kiters = 0
+    assert L.octane_vof_plan_create(C.byref(h), 64, 64, 1, C.byref(p)) == capi.E_INVALID
+    assert L.octane_vof_plan_create(None, 64, 64, 1, C.byref(p)) == capi.E_INVALID
+    assert b"invalid" in L.octane_last_error()
+
+
+def test_no_gpu_means_an_error_not_a_fallback(capi):
+    if capi.lib().octane_device_count() > 0:
+        pytest.skip("a GPU is visible here; the no-device path is exercised on the CPU box")
+    a = np.zeros((32, 32), np.float32)
+    with pytest.raises(capi.OctaneError) as e:
+        capi.flow(a, a)
+    assert e.value.code == capi.E_NODEVICE
+    nav = capi.Nav(nx=4, ny=4)
+    with pytest.raises(capi.OctaneError):
+        capi.pix2uv(nav, 0.0, 300.0, np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
+
+
+def test_pix2uv_host_only_branches_need_no_gpu(capi):
+    """-pd and the sector-moved guard are host loops in the reference too (ref p2u:348-368)."""
+    nav = capi.Nav(xOffset=-0.1, g2xOffset=-0.1, yOffset=0.1, g2yOffset=0.1, nx=3, ny=2)
+    u = np.array([[1.239, -2.5, 0.0], [3.999, -0.004, 100.0]], np.float32)
+    v = -u
+    ur, vr, _, _, dT, moved = capi.pix2uv(nav, 10.0, 310.0, u, v, pixuv=1)
+    assert moved == 0 and dT == 300.0
+    assert np.array_equal(ur, (100 * u).astype(np.int16)) and np.array_equal(vr, (100 * v).astype(np.int16))
+    nav.g2xOffset = -0.1003
+    ur, vr, ur2, vr2, dT, moved = capi.pix2uv(nav, 10.0, 310.0, u, v)
+    assert moved == 1 and not ur.any() and not vr.any() and not ur2.any() and not vr2.any()
+
+
+def test_product_package_does_not_touch_the_oracle():
+    """The oracle is test infrastructure: nothing under octane_amd/ may import or link it."""
+    pkg = os.path.join(ROOT, "octane_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oct_oracle" not in text and "liboct_oracle" not in text and "from oracle" not in text, f
+
+
+def test_single_hip_runtime_whatever_the_import_order(capi):
+    """Loading the library before torch must not leave two HIP runtimes mapped."""
+    capi.lib()
+    import torch  # noqa: F401
+    mapped = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    assert len(mapped) == 1, mapped

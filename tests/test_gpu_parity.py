@@ -1,0 +1,214 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's sizes --
+through size-independent properties.  Bar (north_star): u/v within 1e-4 relative L2; measured
+values are ~1e-6 (reduction order is the only difference), so anything above 2e-5 fails here as
+'investigate'."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from octane_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BAR = 1e-4          # north_star tolerance
+INVESTIGATE = 2e-5  # expect ~3e-6
+
+
+def _check(capi, oracle, a, b, prm_kwargs, u0=None, v0=None, bar=INVESTIGATE):
+    """GPU vs strict oracle.  The bar is 2e-5 unless the problem itself is more sensitive than
+    that to rounding: the distance between the oracle's two builds (FMA-contracted vs not, same
+    source) measures that sensitivity, and the GPU may not be further from the strict oracle
+    than twice that.  (With the default alpha/lambda the floor is ~1e-6; alpha=12, lambda=0.25
+    on a 90x70 frame has a floor of 1.8e-4 -- the truncated solve amplifies single roundings.)"""
+    uo, vo, its_o = oracle.flow(a, b, oracle.FlowParams(**prm_kwargs), u0=u0, v0=v0)
+    uf, vf, _ = oracle.flow(a, b, oracle.FlowParams(**prm_kwargs), u0=u0, v0=v0, flavour="fma")
+    bar = max(bar, 2.0 * rel_l2(uf, vf, uo, vo))
+    nc, ny, nx = (1,) + a.shape if a.ndim == 2 else a.shape
+    pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm_kwargs))
+    ug, vg = pl.run_host(a, b, u0, v0)
+    its_g = pl.last_iterations()
+    pl.close()
+    d = rel_l2(ug, vg, uo, vo)
+    assert np.isfinite(ug).all() and np.isfinite(vg).all()
+    assert d < bar, f"relative L2 {d:.3e} vs oracle"
+    return d, its_o, its_g
+
+
+@pytest.mark.parametrize("n,shift", [(64, (1.5, -0.75)), (128, (2.0, 1.0))])
+def test_s1_scene_matches_oracle(capi, oracle, n, shift):
+    a, b = synth.gaussian_scene(n, shift)
+    d, io, ig = _check(capi, oracle, a, b, {})
+    assert io == ig
+
+
+@pytest.mark.parametrize("nx,ny,nc,prm", [
+    (96, 80, 1, dict(kiters=3)),
+    (200, 150, 1, dict(kiters=4)),                       # ragged: not a multiple of any tile
+    (131, 67, 1, dict(kiters=3, liters=2)),              # odd sizes, odd level sizes
+    (75, 53, 2, dict(kiters=2, liters=2, cgiters=12)),   # two channels (channel-0 decimation quirk)
+    (64, 48, 3, dict(kiters=3, liters=1, cgiters=8)),    # three channels
+    (90, 70, 1, dict(kiters=2, dozim=0)),                # -brox
+    (90, 70, 1, dict(kiters=3, alpha=12.0, lambda_=0.25)),
+    (257, 129, 1, dict(kiters=1, liters=2)),             # single level: no pyramid at all
+    (300, 260, 1, dict(kiters=5, liters=1, cgiters=40)),
+])
+def test_lattice_scene_matches_oracle(capi, oracle, nx, ny, nc, prm):
+    a, b = synth.lattice_scene(nx, ny, seed=nx * 7 + ny, nchan=nc)
+    _check(capi, oracle, a, b, prm)
+
+
+def test_multi_tile_persistent_loops_match_oracle(capi, oracle):
+    """Large enough that every persistent kernel walks several tiles per workgroup (more than
+    1024 tiles): the regime BASELINE's sizes run in.  Caught an in-place halo race once."""
+    nx, ny = 1300, 1040
+    a, b = synth.lattice_scene(nx, ny, seed=77)
+    _check(capi, oracle, a, b, dict(kiters=2, liters=1, cgiters=15))
+
+
+def test_first_guess_and_hint_term(capi, oracle):
+    """lambdac != 0 (only reachable with -firstguess): the hint term and its pyramid."""
+    nx, ny = 120, 88
+    a, b = synth.lattice_scene(nx, ny, seed=21)
+    tu, tv = synth.true_lattice_flow(nx, ny)
+    u0 = (tu + 0.3).astype(np.float32)
+    v0 = (tv - 0.2).astype(np.float32)
+    _check(capi, oracle, a, b, dict(kiters=3, lambdac=0.5), u0, v0)
+
+
+def test_early_exit_of_the_pcg_loop(capi, oracle, golden_flow):
+    """A case where the reference's tolerance test ends solves early (its < cap): the device-side
+    stop logic must stop at the same iteration."""
+    name = "lat_60x44_brox_hint"
+    a, b = golden_flow[name + "_img1"], golden_flow[name + "_img2"]
+    u0 = np.full(a.shape[1:], 2.0, np.float32)
+    v0 = np.full(a.shape[1:], -1.0, np.float32)
+    prm = dict(kiters=2, dozim=0, lambdac=0.5, alpha=8.0, lambda_=0.5)
+    d, io, ig = _check(capi, oracle, a, b, prm, u0, v0)
+    assert io == int(golden_flow[name + "_its"]) and io < 2 * 3 * 3 * 30
+    assert ig == io
+
+
+def test_identical_images_give_zero_flow_without_nans(capi, oracle):
+    """b == 0 -> residual 0 -> the loop never runs (ref .cu:1131); 0/0 must not appear."""
+    a, _ = synth.lattice_scene(80, 64, seed=3)
+    uo, vo, its = oracle.flow(a, a, oracle.FlowParams(kiters=2))
+    pl = capi.Plan(80, 64, 1, capi.FlowParams(kiters=2))
+    ug, vg = pl.run_host(a, a)
+    assert pl.last_iterations() == its
+    assert np.isfinite(ug).all() and np.abs(ug).max() < 1e-5 and np.abs(vg).max() < 1e-5
+    assert np.abs(ug - uo).max() < 1e-6 and np.abs(vg - vo).max() < 1e-6
+
+
+def test_constant_images(capi):
+    a = np.full((1, 40, 56), 17.0, np.float32)
+    u, v = capi.flow(a, a, capi.FlowParams(kiters=2))
+    assert not u.any() and not v.any()
+
+
+@pytest.mark.parametrize("name,prm,guess", [
+    ("s1_64", dict(), None),
+    ("lat_96x80_k3", dict(kiters=3), None),
+    ("lat_75x53_k2_nc2", dict(kiters=2, liters=2, cgiters=12), None),
+    ("lat_60x44_brox_hint", dict(kiters=2, dozim=0, lambdac=0.5, alpha=8.0, lambda_=0.5), (2.0, -1.0)),
+])
+def test_committed_golden_fixtures(capi, golden_flow, name, prm, guess):
+    a, b = golden_flow[name + "_img1"], golden_flow[name + "_img2"]
+    u0 = v0 = None
+    if guess:
+        u0 = np.full(a.shape[1:], guess[0], np.float32)
+        v0 = np.full(a.shape[1:], guess[1], np.float32)
+    u, v = capi.flow(a, b, capi.FlowParams(**prm), u0, v0)
+    assert rel_l2(u, v, golden_flow[name + "_u"], golden_flow[name + "_v"]) < INVESTIGATE
+
+
+def test_first_assembly_is_bit_exact(capi, oracle):
+    """Everything before the first reduction reproduces the strict oracle bit for bit: pyramid,
+    gradients, warp, coefficients, rhs (the library is built with -ffp-contract=off)."""
+    nx, ny = 112, 72
+    a, b = synth.lattice_scene(nx, ny, seed=9)
+    tr_o, tr_g = {}, {}
+    oracle.flow(a, b, oracle.FlowParams(kiters=3, liters=1, cgiters=2), trace=tr_o)
+    pl = capi.Plan(nx, ny, 1, capi.FlowParams(kiters=3, liters=1, cgiters=2))
+    pl.set_trace(tr_g)
+    pl.run_host(a, b)
+    for tag in ("img1", "img2", "gx1", "gy1", "gx2", "gy2", "gxx", "gxy", "gyy", "u0", "v0"):
+        assert np.array_equal(tr_g[(tag, 0, -1, -1)], tr_o[(tag, 0, -1, -1)]), tag
+    for k in range(3):      # images and gradients of every level (flow-independent)
+        for tag in ("img1", "img2", "gx1", "gy1", "gx2", "gy2", "gxx", "gxy", "gyy"):
+            assert np.array_equal(tr_g[(tag, k, -1, -1)], tr_o[(tag, k, -1, -1)]), (tag, k)
+    g = tr_g[("coef7", 0, 0, 0)]
+    o = tr_o[("coef", 0, 0, 0)]
+    for gi, oi, nm in zip(range(7), (0, 1, 2, 5, 6, 7, 8), ("a1", "a2", "a4", "a7", "a8", "bu", "bv")):
+        assert np.array_equal(g[gi], o[oi]), nm
+
+
+def test_runs_are_bitwise_reproducible(capi):
+    """Two-stage fixed-order reductions: no float atomics, so repeated runs agree exactly
+    (the CUDA reference does not: SURVEY.md 2.2, jVecXVec)."""
+    a, b = synth.lattice_scene(333, 217, seed=4)
+    pl = capi.Plan(333, 217, 1, capi.FlowParams(kiters=4))
+    u1, v1 = pl.run_host(a, b)
+    u2, v2 = pl.run_host(a, b)
+    assert np.array_equal(u1, u2) and np.array_equal(v1, v2)
+    u3, v3 = capi.flow(a, b, capi.FlowParams(kiters=4))
+    assert np.array_equal(u1, u3) and np.array_equal(v1, v3)
+
+
+def test_level_too_small_is_an_error(capi):
+    a = np.zeros((1, 20, 20), np.float32)
+    with pytest.raises(capi.OctaneError) as e:
+        capi.flow(a, a, capi.FlowParams(kiters=6))
+    assert e.value.code == capi.E_TOOSMALL
+
+
+def test_batch_entry_equals_single_runs(capi):
+    pairs = [synth.lattice_scene(100, 76, seed=s) for s in (1, 2, 3)]
+    prm = capi.FlowParams(kiters=3, liters=2)
+    outs = capi.batch_flow(pairs, prm, devices=[0])
+    for (a, b), (u, v) in zip(pairs, outs):
+        us, vs = capi.flow(a, b, prm)
+        assert np.array_equal(u, us) and np.array_equal(v, vs)
+
+
+def test_device_pointer_entry_equals_host_entry(capi):
+    import torch
+    nx, ny = 192, 140
+    a, b = synth.lattice_scene(nx, ny, seed=8)
+    prm = capi.FlowParams(kiters=3)
+    pl = capi.Plan(nx, ny, 1, prm)
+    uh, vh = pl.run_host(a, b)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    du = torch.zeros(ny, nx, device="cuda")
+    dv = torch.zeros(ny, nx, device="cuda")
+    torch.cuda.synchronize()
+    pl.run_device(da.data_ptr(), db.data_ptr(), du.data_ptr(), dv.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(du.cpu().numpy(), uh) and np.array_equal(dv.cpu().numpy(), vh)
+
+
+def test_full_size_properties_2000(capi):
+    """BASELINE.json configs[1] shape (2000x2000, 6 levels): no oracle at this size in test time,
+    so check what the domain offers: the recovered flow follows the analytic displacement field,
+    the run is reproducible, and the iteration count is the fixed kiters*3*liters*cgiters."""
+    import torch
+    n = 2000
+    a, b = synth.lattice_scene(n, n, seed=20240614, device="cuda")
+    prm = capi.FlowParams(kiters=6)
+    pl = capi.Plan(n, n, 1, prm)
+    u = torch.zeros(n, n, device="cuda"); v = torch.zeros(n, n, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    pl.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr(), s)
+    torch.cuda.synchronize()
+    u1, v1 = u.clone(), v.clone()
+    assert pl.last_iterations() == 6 * 3 * 3 * 30
+    tu, tv = synth.true_lattice_flow(n, n, xp=torch)
+    m = n // 8
+    eu = (u1.cpu().double() - tu)[m:-m, m:-m].abs()
+    ev = (v1.cpu().double() - tv)[m:-m, m:-m].abs()
+    assert eu.mean() < 0.05 and ev.mean() < 0.05, (eu.mean(), ev.mean())
+    u.zero_(); v.zero_()
+    pl.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(u, u1) and torch.equal(v, v1)

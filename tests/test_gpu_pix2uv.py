@@ -1,0 +1,93 @@
+"""pix2uv: the navigated `short` outputs must be bit-exact (north_star).  Compared against the
+CPU oracle (oracle/pix2uv_oracle.c) on CONUS-, full-disk-, polar- and mercator-like setups."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def conus_nav(Nav, nx, ny, minX=0, minY=0):
+    # GOES-16 ABI CONUS 2 km fixed grid (x/y scale 56e-6 rad per pixel)
+    return Nav(pph=35786023.0, req=6378137.0, rpol=6356752.31414, lam0=-75.0 * 3.14159265 / 180.0,
+               xScale=5.6e-05, xOffset=-0.101332, yScale=-5.6e-05, yOffset=0.128212,
+               g2xOffset=-0.101332, g2yOffset=0.128212, lat1=0, lon1=0, lon0=0, R=0,
+               minX=minX, minY=minY, nx=nx, ny=ny)
+
+
+def _same(Nav_c, nav_o):
+    for f, _ in Nav_c._fields_:
+        setattr(nav_o, f, getattr(Nav_c, f))
+    return nav_o
+
+
+def _compare(capi, oracle, nav, u, v, mode, t1=0.0, t2=300.0):
+    nav_o = _same(nav, oracle.Nav())
+    got = capi.pix2uv(nav, t1, t2, u, v, 0, mode)
+    want = oracle.pix2uv(nav_o, t1, t2, u, v, 0, mode)
+    names = ("ur", "vr", "ur2", "vr2")
+    for g, w, n in zip(got[:4], want[:4], names):
+        bad = int((g != w).sum())
+        assert bad == 0, f"{n}: {bad} of {g.size} shorts differ (max |d| {np.abs(g.astype(int) - w).max()})"
+    assert got[4] == want[4] and got[5] == want[5]
+    return got
+
+
+def test_conus_geostationary_bit_exact(capi, oracle):
+    nx, ny = 500, 300
+    rng = np.random.RandomState(0)
+    u = (rng.randn(ny, nx) * 3).astype(np.float32)
+    v = (rng.randn(ny, nx) * 3).astype(np.float32)
+    u[5, 7] = -9999.0                              # fill value -> -32768 (ref p2u:212-218)
+    got = _compare(capi, oracle, conus_nav(capi.Nav, nx, ny, 100, 50), u, v, capi.NAV_GEOS)
+    assert got[0][5, 7] == -32768 and got[1][5, 7] == -32768
+    assert np.abs(got[0]).max() > 100              # something was navigated
+
+
+def test_recorded_reference_answer(capi, oracle):
+    """CONUS-like navigation, u = 1.5 px, dt = 300 s -> U = 983 cm/s
+    (1.5 px x 2 km / 300 s); the sub-satellite region of a 2 km grid reproduces it."""
+    nx = ny = 64
+    nav = capi.Nav(pph=35786023.0, req=6378137.0, rpol=6356752.31414, lam0=-75.0 * 3.14159265 / 180.0,
+                   xScale=5.6e-05, xOffset=-0.0018, yScale=-5.6e-05, yOffset=0.0018,
+                   g2xOffset=-0.0018, g2yOffset=0.0018, nx=nx, ny=ny)
+    u = np.full((ny, nx), 1.5, np.float32)
+    v = np.zeros((ny, nx), np.float32)
+    ur = _compare(capi, oracle, nav, u, v, capi.NAV_GEOS)[0]
+    assert abs(int(np.median(ur)) - 983) <= 25
+
+
+def test_full_disk_limb_and_space_pixels(capi, oracle):
+    """Off-earth pixels (negative discriminant) and the sds > 0.021 limb mask give zeros."""
+    nx, ny = 340, 340
+    nav = capi.Nav(pph=35786023.0, req=6378137.0, rpol=6356752.31414, lam0=-1.308996939,
+                   xScale=8.96e-04, xOffset=-0.151872, yScale=-8.96e-04, yOffset=0.151872,
+                   g2xOffset=-0.151872, g2yOffset=0.151872, nx=nx, ny=ny)
+    rng = np.random.RandomState(1)
+    u = (rng.rand(ny, nx) * 4 - 2).astype(np.float32)
+    v = (rng.rand(ny, nx) * 4 - 2).astype(np.float32)
+    got = _compare(capi, oracle, nav, u, v, capi.NAV_GEOS, 1000.0, 1600.0)
+    assert got[0][0, 0] == 0 and got[0][ny // 2, nx // 2] != 0
+
+
+def test_polar_and_mercator_modes(capi, oracle):
+    nx, ny = 200, 120
+    rng = np.random.RandomState(2)
+    u = (rng.randn(ny, nx)).astype(np.float32)
+    v = (rng.randn(ny, nx)).astype(np.float32)
+    polar = capi.Nav(xScale=1000.0, xOffset=-100000.0, yScale=1000.0, yOffset=-60000.0,
+                     g2xOffset=-100000.0, g2yOffset=-60000.0, lat1=90.0, lon0=-45.0, R=6371228.0, nx=nx, ny=ny)
+    _compare(capi, oracle, polar, u, v, capi.NAV_POLAR, 0.0, 86400.0)
+    polar.lat1 = 70.0
+    _compare(capi, oracle, polar, u, v, capi.NAV_POLAR, 0.0, 86400.0)
+    merc = capi.Nav(xScale=2000.0, xOffset=-200000.0, yScale=2000.0, yOffset=1000000.0,
+                    g2xOffset=-200000.0, g2yOffset=1000000.0, lon1=-1.2, R=6371228.0, nx=nx, ny=ny)
+    _compare(capi, oracle, merc, u, v, capi.NAV_MERC, 0.0, 600.0)
+
+
+def test_flow_then_navigation_end_to_end(capi, oracle):
+    """The oct_optical_flow() sequence (ref src/oct_optical_flow.cc:67,91): solver then pix2uv."""
+    from octane_amd import synth
+    nx, ny = 160, 120
+    a, b = synth.lattice_scene(nx, ny, seed=12)
+    u, v = capi.flow(a, b, capi.FlowParams(kiters=3))
+    _compare(capi, oracle, conus_nav(capi.Nav, nx, ny), u, v, capi.NAV_GEOS)
