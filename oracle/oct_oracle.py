@@ -82,6 +82,7 @@ def lib(flavour: str = "strict") -> C.CDLL:
     L.oct_oracle_upsample_flow.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
     L.oct_oracle_nnz_before.restype = C.c_long
     L.oct_oracle_nnz_before.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.oct_oracle_set_dot_schedule.argtypes = [C.c_int]
     L.oct_oracle_pix2uv.restype = C.c_int
     L.oct_oracle_pix2uv.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, _F, _F, C.c_int, C.c_int,
                                     _S, _S, _S, _S, C.POINTER(C.c_float)]
@@ -107,9 +108,12 @@ class FlowParams:
                       self.kiters, self.liters, self.cgiters, self.dozim)
 
 
+REF_GRID_THREADS = 20 * 16 * 128   # the reference's launch: 20 SMs (hard-coded, ref .cu:1422) x 16 blocks x 128 threads
+
+
 def flow(img1: np.ndarray, img2: np.ndarray, prm: FlowParams | None = None,
          u0: np.ndarray | None = None, v0: np.ndarray | None = None,
-         trace: dict | None = None, flavour: str = "strict"):
+         trace: dict | None = None, flavour: str = "strict", dot_threads: int = 0):
     """Run the oracle solver.  Images are [nc, ny, nx] or [ny, nx] float32
     (x fastest, channel-planar: Image.data[i + nx*j + nx*ny*c]).
     Returns (u, v, total_pcg_iterations).  If `trace` is a dict it is filled with
@@ -134,7 +138,13 @@ def flow(img1: np.ndarray, img2: np.ndarray, prm: FlowParams | None = None,
         t = _Trace(keep, None)
         tr_ptr = C.cast(C.pointer(t), C.c_void_p)
     p = prm.c()
-    its = L.oct_oracle_vof(a, b, nx, ny, nc, u, v, C.byref(p), tr_ptr)
+    # dot-product schedule: 0 = one thread (what the survey recorded), >0 = the CUDA launch
+    # geometry (see dotf in vof_oracle.c); large frames need the latter to be meaningful.
+    L.oct_oracle_set_dot_schedule(dot_threads)
+    try:
+        its = L.oct_oracle_vof(a, b, nx, ny, nc, u, v, C.byref(p), tr_ptr)
+    finally:
+        L.oct_oracle_set_dot_schedule(0)
     if its < 0:
         raise RuntimeError(f"oracle failed with code {its}")
     return u, v, its

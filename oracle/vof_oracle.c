@@ -434,12 +434,46 @@ void oct_oracle_spmv(const float *val, const int *rowptr, const int *col, const 
     }
 }
 
-/* ref .cu:151-186 jVecXVec under a one-thread schedule: plain running sum */
+/* ref .cu:151-186 jVecXVec.  The order in which the reference adds the products depends on
+ * its launch geometry (and, through atomicAdd, on timing), so the restatement offers two
+ * schedules of the same code:
+ *   threads == 0  one thread: a plain running float sum.  This is the schedule under which the
+ *                 survey recorded the reference's answers; its rounding error
+ *                 grows with N (0.3 % of alpha at 1.3 Mpixel) -- an artefact of the schedule.
+ *   threads  > 0  the CUDA launch: `threads` grid threads (a multiple of 128; the reference's
+ *                 default geometry on its sm_60 target is 20 SMs x 16 blocks x 128 = 40960),
+ *                 each accumulating elements t, t+threads, ... in float (.cu:155-159), the
+ *                 32-wide tile tree and the per-block tile loop (.cu:164-183), and the per-block
+ *                 atomicAdd (.cu:184) taken in block order.
+ * Large-frame parity tests use the second: it is what a GPU run of the reference computes, up to
+ * the order of its atomics. */
+static int g_dot_threads = 0;
+void oct_oracle_set_dot_schedule(int threads) { g_dot_threads = (threads > 0) ? (threads + 127) / 128 * 128 : 0; }
+
 static float dotf(const float *a, const float *b, int n)
 {
-    float s = 0.0f;
-    for (int i = 0; i < n; i++) s += (float)(a[i] * b[i]);
-    return s;
+    if (g_dot_threads <= 0) {
+        float s = 0.0f;
+        for (int i = 0; i < n; i++) s += (float)(a[i] * b[i]);
+        return s;
+    }
+    const int G = g_dot_threads;
+    float result = 0.0f;
+    float tmp[128];
+    for (int blk = 0; blk < G / 128; blk++) {
+        for (int t = 0; t < 128; t++) {                 /* per-thread grid-stride partial */
+            float s = 0.0f;
+            for (long i = (long)blk * 128 + t; i < n; i += G) s += (float)(a[i] * b[i]);
+            tmp[t] = s;
+        }
+        for (int tile = 0; tile < 128; tile += 32)      /* tile32 tree: lane r adds lane r+i */
+            for (int i = 16; i > 0; i >>= 1)
+                for (int r = 0; r < i; r++) tmp[tile + r] = tmp[tile + r] + tmp[tile + r + i];
+        float beta = 0.0f;
+        for (int i = 0; i < 128; i += 32) beta += tmp[i];
+        result += beta;                                  /* atomicAdd, block order */
+    }
+    return result;
 }
 
 /* ref .cu:198-205 jVecPVec: c = d*a + b */

@@ -47,6 +47,8 @@ void  oct_oracle_assemble(const oct_oracle_level *L, const float *u, const float
                           oct_oracle_system *S, oct_oracle_planes *P);
 void  oct_oracle_spmv(const float *val, const int *rowptr, const int *col, const float *x,
                       long nnz, int nrows, float *y);
+/* 0 = one-thread running sum (default), >0 = the reference's grid schedule with that many threads */
+void  oct_oracle_set_dot_schedule(int threads);
 int   oct_oracle_pcg(oct_oracle_system *S, float *x, float tol, int maxit, oct_oracle_cgwork *W);
 
 /* Whole solve.  u/v are in-out (first guess in, flow out).  Returns the number
