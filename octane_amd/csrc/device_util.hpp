@@ -27,9 +27,9 @@ __device__ __forceinline__ double block_sum_256(double v, double *scratch)
     return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
 }
 
-// Every block folds the same `n` per-block partials (n <= 1024) in the same order, so all
+// Every block folds the same `n` per-block partials (n <= kMaxParts) in the same order, so all
 // blocks obtain bit-identical totals without atomics, fences or an extra launch: thread t
-// adds partials t, t+256, t+512, t+768, then the workgroup tree above.
+// adds partials t, t+256, t+512, ..., then the workgroup tree above.
 __device__ __forceinline__ double fold_partials_256(const double *__restrict__ part, int n, double *scratch)
 {
     double v = 0.;

@@ -32,9 +32,13 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
 // p_new = z + beta * p_old with z = M^-1 r  (ref .cu:1117/1138 then jVecPVec(p0,z0,p0,Bk) at :1146)
+// The preconditioner entry is re-derived from the diagonal here (pass A reads a1/a4 anyway for
+// A p) with one correctly rounded float division.  The reference rounds 1./M through double
+// first; the two agree except when the double quotient sits exactly on a float rounding
+// boundary (probability ~2^-29 per value, 1 ulp then).
 __device__ __forceinline__ float direction(float r, float pold, float diag, float beta, bool first)
 {
-    float z = jacobi_inv(diag) * r;
+    float z = (1.0f / diag) * r;
     return first ? z : beta * pold + z;
 }
 
@@ -203,14 +207,18 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
     const int gw = (w + 3) / 4;
     const long ngroups = (long)gw * h;
     double acc_rz = 0., acc_rr = 0.;
-    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
+    // Pass B walks the frame from the end to the start and pass A from the start to the end, so
+    // each pass begins on the planes the previous one touched last (p, q, r and the diagonal are
+    // still in the 256 MiB Infinity Cache there).
+    for (long gr = (long)blockIdx.x * 256 + threadIdx.x; gr < ngroups; gr += (long)gridDim.x * 256) {
+        const long g = L.reverse_b ? ngroups - 1 - gr : gr;
         const int y = (int)(g / gw), x = (int)(g - (long)y * gw) * 4;
         const size_t o = (size_t)y * pitch + x;
-        float xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0}, ru[4], rv[4], pu[4], pv[4], qu[4], qv[4], a1[4], a4[4];
+        float xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0}, ru[4], rv[4], pu[4], pv[4], qu[4], qv[4], mu[4], mv[4];
         *(float4 *)ru = ld4(L.ru + o); *(float4 *)rv = ld4(L.rv + o);
         *(float4 *)pu = ld4(L.pu[(k + 1) & 1] + o); *(float4 *)pv = ld4(L.pv[(k + 1) & 1] + o);
         *(float4 *)qu = ld4(L.qu + o); *(float4 *)qv = ld4(L.qv + o);
-        *(float4 *)a1 = ld4(L.a1 + o); *(float4 *)a4 = ld4(L.a4 + o);
+        *(float4 *)mu = ld4(L.mu + o); *(float4 *)mv = ld4(L.mv + o);
         if (!first) { *(float4 *)xu = ld4(L.xu + o); *(float4 *)xv = ld4(L.xv + o); }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
             ru[e] = nalpha * qu[e] + ru[e];                // jVecPVec(dummyvec,bcu,rk,-alphak), ref .cu:1174
             rv[e] = nalpha * qv[e] + rv[e];
             if (x + e < w) {
-                const float zu = jacobi_inv(a1[e]) * ru[e], zv = jacobi_inv(a4[e]) * rv[e];
+                const float zu = mu[e] * ru[e], zv = mv[e] * rv[e];
                 acc_rz += (double)(ru[e] * zu) + (double)(rv[e] * zv);
                 acc_rr += (double)(ru[e] * ru[e]) + (double)(rv[e] * rv[e]);
             }
@@ -254,15 +262,13 @@ __global__ __launch_bounds__(256) void k_flow_update(LevelPtrs L, int nlaunched)
 
 int pcg_grid_size(int w, int h)
 {
-    int tiles = ((w + kTileX - 1) / kTileX) * ((h + kTileY - 1) / kTileY);
-    return tiles < kMaxParts ? tiles : kMaxParts;
+    return balanced_grid((long)((w + kTileX - 1) / kTileX) * ((h + kTileY - 1) / kTileY));
 }
 
 static int stream_grid_size(int w, int h)
 {
     long groups = (long)((w + 3) / 4) * h;
-    long blocks = (groups + 255) / 256;
-    return (int)(blocks < kMaxParts ? blocks : kMaxParts);
+    return balanced_grid((groups + 255) / 256);
 }
 
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)

@@ -333,9 +333,13 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
         const size_t o = rc + ii;
         L.a1[o] = a1; L.a2[o] = a2; L.a4[o] = a4; L.wx[o] = a7; L.wy[o] = a8;
         L.ru[o] = bu; L.rv[o] = bv;
-        // r.r and r.z of the initial residual (ref .cu:1115-1126, 1157): z = (1/M) r
-        float zu = (float)(1. / (double)a1) * bu;
-        float zv = (float)(1. / (double)a4) * bv;
+        // Jacobi preconditioner, M <- 1./M in double (ref .cu:141-149); stored so that the
+        // streaming PCG pass never divides
+        const float mu = jacobi_inv(a1), mv = jacobi_inv(a4);
+        L.mu[o] = mu; L.mv[o] = mv;
+        // r.r and r.z of the initial residual (ref .cu:1115-1126, 1157): z = M r
+        float zu = mu * bu;
+        float zv = mv * bv;
         acc_rr += (double)(bu * bu) + (double)(bv * bv);
         acc_rz += (double)(bu * zu) + (double)(bv * zv);
     }
@@ -351,10 +355,22 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
     }
 }
 
+// Persistent grid for `items` equal work items: the fewest rounds that fit kMaxParts blocks, then
+// as many blocks as give every block that many items (+-1) -- no half-empty last round.
+static int g_max_blocks = kMaxParts;
+void set_max_blocks(int n) { g_max_blocks = (n >= 64 && n <= kMaxParts) ? n : kMaxParts; }
+
+int balanced_grid(long items)
+{
+    const int cap = g_max_blocks;
+    if (items <= cap) return items < 1 ? 1 : (int)items;
+    long rounds = (items + cap - 1) / cap;
+    return (int)((items + rounds - 1) / rounds);
+}
+
 int assemble_grid_size(int w, int h)
 {
-    int tiles = ((w + kAsmTX - 1) / kAsmTX) * ((h + kAsmTY - 1) / kAsmTY);
-    return tiles < kMaxParts ? tiles : kMaxParts;
+    return balanced_grid((long)((w + kAsmTX - 1) / kAsmTX) * ((h + kAsmTY - 1) / kAsmTY));
 }
 
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid)

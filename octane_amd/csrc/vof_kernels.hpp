@@ -15,7 +15,8 @@ struct Plane {
 };
 
 constexpr int kMaxChan = 3;
-constexpr int kMaxParts = 1024;      // upper bound on persistent blocks == reduction partials
+constexpr int kMaxParts = 2048;      // upper bound on persistent blocks == reduction partials
+                                     // (256 CUs x 8 resident 256-thread workgroups)
 
 // PCG tile geometry: 256 threads, each owning 4 consecutive pixels of one row.
 constexpr int kTileX = 128;
@@ -37,12 +38,14 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     float *u, *v;
     const float *ut, *vt;           // first-guess hint (only read when lambdac != 0)
     float *a1, *a2, *a4, *wx, *wy;  // per-pixel operator coefficients
+    float *mu, *mv;                 // Jacobi preconditioner 1/a1, 1/a4 as the reference rounds it (ref .cu:141-149)
     float *ru, *rv, *qu, *qv, *xu, *xv;             // r (starts as rhs), q = A p, x
     float *pu[2], *pv[2];                           // search direction, ping-pong by iteration parity:
                                                     // pass A(k) reads p[k&1] (halo too) and writes p[(k+1)&1]
     double *part_rz, *part_rr, *part_pq;
     PcgState *st;
     long long *iter_total;
+    int reverse_b;                  // pass B walks the frame backwards (Infinity-Cache reuse)
 };
 
 struct AssembleParams {
@@ -60,6 +63,8 @@ void launch_blur_cols_sampled(hipStream_t s, const float *src, int sw, int sh, i
 void launch_gradient(hipStream_t s, const float *f, float *gx, float *gy, int w, int h, int pitch, int nc, size_t cstride);
 void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpitch,
                      float *fine, int fw, int fh, int fpitch, float sf);
+void set_max_blocks(int n);           // tuning knob (<= kMaxParts)
+int  balanced_grid(long work_items);   // persistent grid: every block gets the same number of items (+-1)
 int  pcg_grid_size(int w, int h);
 int  assemble_grid_size(int w, int h);
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid);

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -55,7 +56,7 @@ struct octane_vof_plan {
     float *img1p, *img2p, *uh, *vh, *lev1, *lev2;
     float *gx1, *gy1, *gx2, *gy2, *gxx, *gxy, *gyy;
     float *U[2], *V[2], *ut, *vt;
-    float *a1, *a2, *a4, *wx, *wy, *ru, *rv, *pu[2], *pv[2], *qu, *qv, *xu, *xv, *tmp;
+    float *a1, *a2, *a4, *wx, *wy, *mu, *mv, *ru, *rv, *pu[2], *pv[2], *qu, *qv, *xu, *xv, *tmp;
     float *d_taps = nullptr;
     double *d_parts = nullptr;     // 3 * kMaxParts
     PcgState *d_state = nullptr;   // 2
@@ -70,6 +71,7 @@ struct octane_vof_plan {
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     octane_vof_profile prof;
     float tol;
+    int reverse_b = 1;
 };
 
 extern "C" const char *octane_last_error(void) { return g_last_error.c_str(); }
@@ -145,6 +147,8 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     pl->pitch0 = round_up(nx, 64);
     pl->plane0 = (size_t)pl->pitch0 * ny;
     pl->tol = (float)(0.0001 * 0.0001);          // ref .cu:1353
+    if (const char *e = getenv("OCTANE_TUNE_MAXBLOCKS")) set_max_blocks(atoi(e));   // developer tuning knobs
+    if (const char *e = getenv("OCTANE_TUNE_REVERSE_B")) pl->reverse_b = atoi(e) != 0;
     memset(&pl->prof, 0, sizeof(pl->prof));
 
     const float scale = (float)p->scaleF;
@@ -176,7 +180,7 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     }
 
     const int nc = nchan;
-    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 15 + 1;
+    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 17 + 1;
     pl->arena_bytes = nplanes * pl->plane0 * sizeof(float);
     hipError_t e = hipMalloc((void **)&pl->arena, pl->arena_bytes);
     if (e != hipSuccess) {
@@ -199,7 +203,7 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     pl->gxx = take(nc); pl->gxy = take(nc); pl->gyy = take(nc);
     pl->U[0] = take(1); pl->U[1] = take(1); pl->V[0] = take(1); pl->V[1] = take(1);
     pl->ut = take(1); pl->vt = take(1);
-    pl->a1 = take(1); pl->a2 = take(1); pl->a4 = take(1); pl->wx = take(1); pl->wy = take(1);
+    pl->a1 = take(1); pl->a2 = take(1); pl->a4 = take(1); pl->wx = take(1); pl->wy = take(1); pl->mu = take(1); pl->mv = take(1);
     pl->ru = take(1); pl->rv = take(1);
     pl->pu[0] = take(1); pl->pu[1] = take(1); pl->pv[0] = take(1); pl->pv[1] = take(1);
     pl->qu = take(1); pl->qv = take(1); pl->xu = take(1); pl->xv = take(1);
@@ -374,12 +378,13 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         L.gx1 = pl->gx1; L.gy1 = pl->gy1; L.gx2 = pl->gx2; L.gy2 = pl->gy2;
         L.gxx = pl->gxx; L.gxy = pl->gxy; L.gyy = pl->gyy;
         L.u = pl->U[cur]; L.v = pl->V[cur]; L.ut = ut; L.vt = vt;
-        L.a1 = pl->a1; L.a2 = pl->a2; L.a4 = pl->a4; L.wx = pl->wx; L.wy = pl->wy;
+        L.a1 = pl->a1; L.a2 = pl->a2; L.a4 = pl->a4; L.wx = pl->wx; L.wy = pl->wy; L.mu = pl->mu; L.mv = pl->mv;
         L.ru = pl->ru; L.rv = pl->rv;
         L.pu[0] = pl->pu[0]; L.pu[1] = pl->pu[1]; L.pv[0] = pl->pv[0]; L.pv[1] = pl->pv[1];
         L.qu = pl->qu; L.qv = pl->qv; L.xu = pl->xu; L.xv = pl->xv;
         L.part_rz = pl->d_parts; L.part_rr = pl->d_parts + kMaxParts; L.part_pq = pl->d_parts + 2 * kMaxParts;
         L.st = pl->d_state; L.iter_total = pl->d_iters;
+        L.reverse_b = pl->reverse_b;
 
         const int g_asm = assemble_grid_size(li.w, li.h);
         const int g_a = pcg_grid_size(li.w, li.h);

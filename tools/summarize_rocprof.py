@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Condense a `rocprofv3 --kernel-trace --stats --output-format csv` run of bench.py into the
+per-kernel / per-pyramid-level table kept under profiles/.
+
+usage: summarize_rocprof.py <dir with *_kernel_trace.csv> <out.md> [size kiters liters cgiters]
+Launch order inside one pyramid is fixed (coarse -> fine; per level 3*liters solves of
+1 assemble + cgiters x (pass A, pass B) + 1 update), so the level of a dispatch follows from its
+index among the dispatches of the same kernel."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    size, kiters, liters, cgiters = (int(x) for x in (sys.argv[3:7] if len(sys.argv) >= 7 else (5000, 8, 3, 30)))
+    trace = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
+    rows = defaultdict(list)
+    meta = {}
+    with open(trace) as f:
+        for r in csv.DictReader(f):
+            name = r["Kernel_Name"]
+            if "octane::" not in name:
+                continue
+            short = name.split("octane::")[1].split("(")[0]
+            rows[short].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])))
+            meta[short] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Workgroup_Size_X"])
+    per_level = {"k_pcg_pass_a": 3 * liters * cgiters, "k_pcg_pass_b": 3 * liters * cgiters,
+                 "k_assemble": 3 * liters, "k_flow_update": 3 * liters}
+    lines = [f"# rocprofv3 kernel-trace summary: bench.py, {size}x{size}, kiters={kiters} liters={liters} cgiters={cgiters}", "",
+             "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...` on one MI355X;",
+             "durations are End-Start of each dispatch in ns, averaged over every pyramid in the run (warm-up included).", "",
+             "| kernel | VGPR | AGPR | SGPR | LDS B | scratch | level (size) | launches | mean us | min us | max us | grid (threads) |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for k, n_per_level in per_level.items():
+        if k not in rows:
+            continue
+        v = sorted(rows[k])
+        per_pyr = n_per_level * kiters
+        npyr = len(v) // per_pyr
+        for lev in range(kiters):
+            sel = []
+            for p in range(npyr):
+                sel += v[p * per_pyr + lev * n_per_level: p * per_pyr + (lev + 1) * n_per_level]
+            durs = [s[1] for s in sel]
+            f = 0.5 ** (kiters - 1 - lev)
+            lw = int(size * f + 0.5)
+            m = meta[k]
+            lines.append(f"| {k} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} | {lev} ({lw}x{lw}) | {len(durs)} | "
+                         f"{sum(durs) / len(durs) / 1e3:.2f} | {min(durs) / 1e3:.2f} | {max(durs) / 1e3:.2f} | {sel[0][2]} |")
+    lines += ["", "| other kernels | launches | mean us | total ms |", "|---|---|---|---|"]
+    for k, v in sorted(rows.items()):
+        if k in per_level:
+            continue
+        durs = [s[1] for s in v]
+        lines.append(f"| {k} | {len(durs)} | {sum(durs) / len(durs) / 1e3:.2f} | {sum(durs) / 1e6:.3f} |")
+    fin = {k: None for k in ("k_pcg_pass_a", "k_pcg_pass_b")}
+    for k in fin:
+        if k in rows:
+            v = sorted(rows[k]); n = per_level[k]; per_pyr = n * kiters; npyr = len(v) // per_pyr
+            d_ = []
+            for p in range(npyr):
+                d_ += [s[1] for s in v[p * per_pyr + (kiters - 1) * n: (p + 1) * per_pyr]]
+            fin[k] = sum(d_) / len(d_)
+    if all(fin.values()):
+        px = size * size
+        lines += ["", "## Finest level against the HBM roofline (algorithmic bytes, DESIGN.md)", "",
+                  f"* pass A: 52 B/px x {px} px = {52 * px / 1e9:.3f} GB per launch / {fin['k_pcg_pass_a'] / 1e3:.1f} us = "
+                  f"**{52 * px / fin['k_pcg_pass_a']:.0f} GB/s** ({52 * px / fin['k_pcg_pass_a'] / 80:.1f} % of 8 TB/s)",
+                  f"* pass B: 56 B/px x {px} px = {56 * px / 1e9:.3f} GB per launch / {fin['k_pcg_pass_b'] / 1e3:.1f} us = "
+                  f"**{56 * px / fin['k_pcg_pass_b']:.0f} GB/s** ({56 * px / fin['k_pcg_pass_b'] / 80:.1f} % of 8 TB/s)",
+                  f"* one PCG iteration at SURVEY 8(d)'s 116 B/px: {116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']):.0f} GB/s "
+                  f"({116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']) / 80:.1f} % of 8 TB/s)"]
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
