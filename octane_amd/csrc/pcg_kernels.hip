@@ -194,6 +194,156 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
     if (tid == 0) L.part_pq[blockIdx.x] = tot;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass A, row-rolling form (experimental: OCTANE_TUNE_PASS_A=1; measured slower than the tiled form).
+//
+// One wavefront owns a strip of 62 lanes x 4 pixels = 248 columns (lanes 0 and 63 are halo lanes
+// that recompute p_new for the neighbouring strips' edge columns) and marches down kSegRows rows.
+// The three rows of p_new that the 5-point operator needs (j-1, j, j+1) stay in registers, the
+// vertical neighbours therefore cost nothing, and the horizontal ones come from the adjacent
+// lanes with wavefront shuffles.  No LDS tile, no workgroup barrier inside the loop, every
+// global access is a 16-byte-per-lane row segment (1 KiB per wave instruction), the row above's
+// wy and the west wx ride along in registers.  Halo recomputation costs 2/64 of the columns and
+// 2 reduced rows (r, p, diagonal only) per kSegRows -- all L2 / Infinity-Cache hits.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStripLanes = 62;
+constexpr int kStripW = kStripLanes * 4;
+constexpr int kSegRows = 16;
+
+struct RowDir { float u[4], v[4]; };
+
+__device__ __forceinline__ RowDir row_direction(const LevelPtrs &L, const float *__restrict__ pin_u,
+                                                const float *__restrict__ pin_v, size_t o, int x, int w,
+                                                float beta, bool first, bool colok, float *a1out, float *a4out)
+{
+    RowDir d;
+    float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0}, a1[4] = {1, 1, 1, 1}, a4[4] = {1, 1, 1, 1};
+    float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
+    if (colok) {
+        *(float4 *)ru = ld4(L.ru + o); *(float4 *)rv = ld4(L.rv + o);
+        *(float4 *)a1 = ld4(L.a1 + o); *(float4 *)a4 = ld4(L.a4 + o);
+        if (!first) { *(float4 *)pu = ld4(pin_u + o); *(float4 *)pv = ld4(pin_v + o); }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const bool ok = colok && (x + e) < w;
+        d.u[e] = ok ? direction(ru[e], pu[e], a1[e], beta, first) : 0.f;
+        d.v[e] = ok ? direction(rv[e], pv[e], a4[e], beta, first) : 0.f;
+        if (a1out) { a1out[e] = a1[e]; a4out[e] = a4[e]; }
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(256, 4) void k_pcg_pass_a_rows(LevelPtrs L, int k, int nparts_prev, float tol)
+{
+    __shared__ double s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
+    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
+    const PcgState prev = L.st[k & 1];
+    const bool active = (prev.stopped == 0) && (rr > tol);          // ref .cu:1131
+    if (!active) {
+        if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
+        return;
+    }
+    const bool first = (k == 0);
+    const float beta = first ? 0.f : rz_new / prev.rz;
+    if (blockIdx.x == 0 && tid == 0) {
+        PcgState n; n.rz = rz_new; n.stopped = 0; n.iters = prev.iters + 1; n.pad = 0;
+        L.st[(k + 1) & 1] = n;
+    }
+
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int strips = (w + kStripW - 1) / kStripW, segs = (h + kSegRows - 1) / kSegRows;
+    const int nitems = strips * segs;
+    const float *__restrict__ pin_u = L.pu[k & 1];
+    const float *__restrict__ pin_v = L.pv[k & 1];
+    float *__restrict__ pout_u = L.pu[(k + 1) & 1];
+    float *__restrict__ pout_v = L.pv[(k + 1) & 1];
+    double acc = 0.;
+
+    for (int item = blockIdx.x * 4 + wave; item < nitems; item += gridDim.x * 4) {
+        const int sidx = item % strips, gidx = item / strips;
+        const int x = sidx * kStripW - 4 + lane * 4;
+        const int j0 = gidx * kSegRows, j1 = min(j0 + kSegRows, h);
+        const bool colok = (x >= 0) && (x < w);
+        const bool owner = colok && (lane >= 1) && (lane <= kStripLanes);
+
+        RowDir pm, pc, pn;
+        float a1c[4], a4c[4], a2c[4] = {0, 0, 0, 0}, wxc[4] = {0, 0, 0, 0}, wyc[4] = {0, 0, 0, 0}, wym[4] = {0, 0, 0, 0};
+        float a1n[4], a4n[4], a2n[4] = {0, 0, 0, 0}, wxn[4] = {0, 0, 0, 0}, wyn[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { pm.u[e] = 0.f; pm.v[e] = 0.f; }
+        if (j0 > 0) {
+            const size_t om = (size_t)(j0 - 1) * pitch + x;
+            pm = row_direction(L, pin_u, pin_v, om, x, w, beta, first, colok, nullptr, nullptr);
+            if (colok) *(float4 *)wym = ld4(L.wy + om);
+        }
+        {
+            const size_t oc = (size_t)j0 * pitch + x;
+            pc = row_direction(L, pin_u, pin_v, oc, x, w, beta, first, colok, a1c, a4c);
+            if (colok) { *(float4 *)a2c = ld4(L.a2 + oc); *(float4 *)wxc = ld4(L.wx + oc); *(float4 *)wyc = ld4(L.wy + oc); }
+        }
+        for (int y = j0; y < j1; ++y) {
+            // next row: full operands if this wave also owns it, otherwise just enough for p_new
+            const size_t on = (size_t)(y + 1) * pitch + x;
+            if (y + 1 < h) {
+                pn = row_direction(L, pin_u, pin_v, on, x, w, beta, first, colok, a1n, a4n);
+                if (y + 1 < j1 && colok) {
+                    *(float4 *)a2n = ld4(L.a2 + on); *(float4 *)wxn = ld4(L.wx + on); *(float4 *)wyn = ld4(L.wy + on);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { pn.u[e] = 0.f; pn.v[e] = 0.f; }
+            }
+            // horizontal neighbours from the adjacent lanes
+            const float uwest = __shfl_up(pc.u[3], 1, 64), vwest = __shfl_up(pc.v[3], 1, 64);
+            const float ueast = __shfl_down(pc.u[0], 1, 64), veast = __shfl_down(pc.v[0], 1, 64);
+            const float wxw = __shfl_up(wxc[3], 1, 64);
+            if (owner) {
+                float qu[4], qv[4];
+                float rowdot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = x + e;
+                    const float pwu = (e == 0) ? uwest : pc.u[(e + 3) & 3], pwv = (e == 0) ? vwest : pc.v[(e + 3) & 3];
+                    const float peu = (e == 3) ? ueast : pc.u[(e + 1) & 3], pev = (e == 3) ? veast : pc.v[(e + 1) & 3];
+                    const float a5 = (e == 0) ? wxw : wxc[(e + 3) & 3];
+                    const float wS = (y == h - 1) ? wym[e] + wyc[e] : wym[e];
+                    const float wW = (i == w - 1) ? a5 + wxc[e] : a5;
+                    const float wE = (i == 0) ? wxc[e] + wxc[e] : wxc[e];
+                    const float wN = (y == 0) ? wyc[e] + wyc[e] : wyc[e];
+                    float sumu = 0.f, sumv = 0.f;
+                    if (y > 0) { sumu += wS * pm.u[e]; sumv += wS * pm.v[e]; }
+                    if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
+                    sumu += a1c[e] * pc.u[e]; sumv += a2c[e] * pc.u[e];
+                    sumu += a2c[e] * pc.v[e]; sumv += a4c[e] * pc.v[e];
+                    if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
+                    if (y < h - 1) { sumu += wN * pn.u[e]; sumv += wN * pn.v[e]; }
+                    qu[e] = sumu; qv[e] = sumv;
+                    if (i < w) { rowdot += pc.u[e] * sumu; rowdot += pc.v[e] * sumv; }
+                }
+                const size_t o = (size_t)y * pitch + x;
+                st4(pout_u + o, *(float4 *)pc.u);
+                st4(pout_v + o, *(float4 *)pc.v);
+                st4(L.qu + o, *(float4 *)qu);
+                st4(L.qv + o, *(float4 *)qv);
+                acc += (double)rowdot;
+            }
+            // roll the window down one row
+            pm = pc; pc = pn;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                wym[e] = wyc[e];
+                a1c[e] = a1n[e]; a4c[e] = a4n[e]; a2c[e] = a2n[e]; wxc[e] = wxn[e]; wyc[e] = wyn[e];
+            }
+        }
+    }
+    const double tot = block_sum_256(acc, s_red);
+    if (tid == 0) L.part_pq[blockIdx.x] = tot;
+}
+
 __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int nparts_a)
 {
     __shared__ double s_red[8];
@@ -260,7 +410,7 @@ __global__ __launch_bounds__(256) void k_flow_update(LevelPtrs L, int nlaunched)
     }
 }
 
-int pcg_grid_size(int w, int h)
+static int pcg_tiled_grid_size(int w, int h)
 {
     return balanced_grid((long)((w + kTileX - 1) / kTileX) * ((h + kTileY - 1) / kTileY));
 }
@@ -271,9 +421,22 @@ static int stream_grid_size(int w, int h)
     return balanced_grid((groups + 255) / 256);
 }
 
+static int g_pass_a_variant = 0;   // 0 = LDS-tiled (default), 1 = row-rolling (experimental, slower so far)
+void set_pass_a_variant(int v) { g_pass_a_variant = v; }
+
+int pcg_grid_size(int w, int h)
+{
+    if (g_pass_a_variant == 0) return pcg_tiled_grid_size(w, h);
+    long items = (long)((w + kStripW - 1) / kStripW) * ((h + kSegRows - 1) / kSegRows);
+    return balanced_grid((items + 3) / 4);
+}
+
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
-    hipLaunchKernelGGL(k_pcg_pass_a, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    if (g_pass_a_variant == 0)
+        hipLaunchKernelGGL(k_pcg_pass_a, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    else
+        hipLaunchKernelGGL(k_pcg_pass_a_rows, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
 }
 
 void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid)

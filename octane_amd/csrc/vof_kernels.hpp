@@ -66,6 +66,7 @@ void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpi
 void set_max_blocks(int n);           // tuning knob (<= kMaxParts)
 int  balanced_grid(long work_items);   // persistent grid: every block gets the same number of items (+-1)
 int  pcg_grid_size(int w, int h);
+void set_pass_a_variant(int v);       // tuning knob: 0 LDS-tiled (default), 1 row-rolling
 int  assemble_grid_size(int w, int h);
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid);
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);

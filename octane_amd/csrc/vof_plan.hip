@@ -110,20 +110,20 @@ static void gauss_taps(float factor, int fs, float *gk)
 extern "C" int octane_vof_plan_destroy(octane_vof_plan *pl)
 {
     if (!pl) return OCTANE_OK;
-    hipSetDevice(pl->device);
-    if (pl->own_stream) hipStreamSynchronize(pl->own_stream);
-    for (auto &e : pl->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-    if (pl->ev_t0) hipEventDestroy(pl->ev_t0);
-    if (pl->ev_t1) hipEventDestroy(pl->ev_t1);
-    if (pl->ev_s0) hipEventDestroy(pl->ev_s0);
-    if (pl->ev_s1) hipEventDestroy(pl->ev_s1);
-    if (pl->arena) hipFree(pl->arena);
-    if (pl->d_taps) hipFree(pl->d_taps);
-    if (pl->d_parts) hipFree(pl->d_parts);
-    if (pl->d_state) hipFree(pl->d_state);
-    if (pl->d_iters) hipFree(pl->d_iters);
-    if (pl->h_iters) hipHostFree(pl->h_iters);
-    if (pl->own_stream) hipStreamDestroy(pl->own_stream);
+    (void)hipSetDevice(pl->device);
+    if (pl->own_stream) (void)hipStreamSynchronize(pl->own_stream);
+    for (auto &e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (pl->ev_t0) (void)hipEventDestroy(pl->ev_t0);
+    if (pl->ev_t1) (void)hipEventDestroy(pl->ev_t1);
+    if (pl->ev_s0) (void)hipEventDestroy(pl->ev_s0);
+    if (pl->ev_s1) (void)hipEventDestroy(pl->ev_s1);
+    if (pl->arena) (void)hipFree(pl->arena);
+    if (pl->d_taps) (void)hipFree(pl->d_taps);
+    if (pl->d_parts) (void)hipFree(pl->d_parts);
+    if (pl->d_state) (void)hipFree(pl->d_state);
+    if (pl->d_iters) (void)hipFree(pl->d_iters);
+    if (pl->h_iters) (void)hipHostFree(pl->h_iters);
+    if (pl->own_stream) (void)hipStreamDestroy(pl->own_stream);
     delete pl;
     return OCTANE_OK;
 }
@@ -149,6 +149,7 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     pl->tol = (float)(0.0001 * 0.0001);          // ref .cu:1353
     if (const char *e = getenv("OCTANE_TUNE_MAXBLOCKS")) set_max_blocks(atoi(e));   // developer tuning knobs
     if (const char *e = getenv("OCTANE_TUNE_REVERSE_B")) pl->reverse_b = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_PASS_A")) set_pass_a_variant(atoi(e));
     memset(&pl->prof, 0, sizeof(pl->prof));
 
     const float scale = (float)p->scaleF;
@@ -288,10 +289,10 @@ static EvPair *ev_begin(octane_vof_plan *pl, hipStream_t s, int kind, bool on)
     }
     EvPair *p = &pl->evs[pl->evs_used++];
     p->kind = kind;
-    hipEventRecord(p->a, s);
+    (void)hipEventRecord(p->a, s);
     return p;
 }
-static void ev_end(EvPair *p, hipStream_t s) { if (p) hipEventRecord(p->b, s); }
+static void ev_end(EvPair *p, hipStream_t s) { if (p) (void)hipEventRecord(p->b, s); }
 
 static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
 {
@@ -303,8 +304,8 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
     pl->evs_used = 0;
     const bool prof = pl->profiling != 0;
     if (prof) {
-        if (!pl->ev_t0) { hipEventCreate(&pl->ev_t0); hipEventCreate(&pl->ev_t1); hipEventCreate(&pl->ev_s0); hipEventCreate(&pl->ev_s1); }
-        hipEventRecord(pl->ev_t0, s);
+        if (!pl->ev_t0) { (void)hipEventCreate(&pl->ev_t0); (void)hipEventCreate(&pl->ev_t1); (void)hipEventCreate(&pl->ev_s0); (void)hipEventCreate(&pl->ev_s1); }
+        (void)hipEventRecord(pl->ev_t0, s);
     }
     HIP_TRY(hipMemsetAsync(pl->d_iters, 0, sizeof(long long), s));
     double setup_ms = 0.;
@@ -313,7 +314,7 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         const LevelInfo &li = pl->lev[k];
         const bool finest = (k == nlev - 1);
         const float *lev1, *lev2, *ut, *vt;
-        if (prof) hipEventRecord(pl->ev_s0, s);
+        if (prof) (void)hipEventRecord(pl->ev_s0, s);
         if (k > 0) {   // ref .cu:498-503: bicubic up-sample of the previous level's flow, divided by scaleF
             const LevelInfo &lo = pl->lev[k - 1];
             launch_upsample(s, pl->U[cur], lo.w, lo.h, lo.pitch, pl->U[cur ^ 1], li.w, li.h, li.pitch, (float)prm.scaleF);
@@ -351,9 +352,9 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         launch_gradient(s, pl->gx2, pl->gxx, nullptr, li.w, li.h, li.pitch, nc, pl->plane0);
         launch_gradient(s, pl->gy2, pl->gxy, pl->gyy, li.w, li.h, li.pitch, nc, pl->plane0);
         if (prof) {
-            hipEventRecord(pl->ev_s1, s);
-            hipEventSynchronize(pl->ev_s1);
-            float ms = 0.f; hipEventElapsedTime(&ms, pl->ev_s0, pl->ev_s1);
+            (void)hipEventRecord(pl->ev_s1, s);
+            (void)hipEventSynchronize(pl->ev_s1);
+            float ms = 0.f; (void)hipEventElapsedTime(&ms, pl->ev_s0, pl->ev_s1);
             setup_ms += ms;
         }
 
@@ -434,16 +435,16 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(pl->h_iters, pl->d_iters, sizeof(long long), hipMemcpyDeviceToHost, s));
     if (prof) {
-        hipEventRecord(pl->ev_t1, s);
+        (void)hipEventRecord(pl->ev_t1, s);
         HIP_TRY(hipEventSynchronize(pl->ev_t1));
         octane_vof_profile pr;
         memset(&pr, 0, sizeof(pr));
         float ms = 0.f;
-        hipEventElapsedTime(&ms, pl->ev_t0, pl->ev_t1);
+        (void)hipEventElapsedTime(&ms, pl->ev_t0, pl->ev_t1);
         pr.total_ms = ms; pr.setup_ms = setup_ms;
         pr.finest_pixels = (long long)pl->nx * pl->ny;
         for (size_t i = 0; i < pl->evs_used; i++) {
-            hipEventElapsedTime(&ms, pl->evs[i].a, pl->evs[i].b);
+            (void)hipEventElapsedTime(&ms, pl->evs[i].a, pl->evs[i].b);
             switch (pl->evs[i].kind) {
             case EV_PASS_A: pr.pass_a_ms += ms; pr.pass_a_launches++; break;
             case EV_PASS_B: pr.pass_b_ms += ms; pr.pass_b_launches++; break;
@@ -614,9 +615,9 @@ extern "C" int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, co
         if (hipStreamSynchronize(s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
     } while (0);
     if (rc != OCTANE_OK) g_last_error = "octane_pix2uv_run: HIP failure";
-    if (s) hipStreamDestroy(s);
-    if (du) hipFree(du);
-    if (dv) hipFree(dv);
-    if (dout) hipFree(dout);
+    if (s) (void)hipStreamDestroy(s);
+    if (du) (void)hipFree(du);
+    if (dv) (void)hipFree(dv);
+    if (dout) (void)hipFree(dout);
     return rc;
 }

@@ -13,10 +13,57 @@ import sys
 from collections import defaultdict
 
 
+def pmc_section(d, size, kiters, per_level):
+    """HBM traffic of the finest level from the FETCH_SIZE / WRITE_SIZE passes (sub-directories fetch/ and
+    write/ of the profile directory).  Units and the gfx950 correction follow MI355X_MICROARCH.md 'HBM':
+    both counters are in KiB; FETCH_SIZE reads exactly half the bytes of a wide (16 B/lane) coalesced
+    stream, so it is doubled; WRITE_SIZE is exact for 16 B/lane stores."""
+    out = []
+    vals = {}
+    for sub, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        fs = glob.glob(os.path.join(d, sub, "**", "*_counter_collection.csv"), recursive=True)
+        if not fs:
+            return out
+        agg = defaultdict(list)
+        with open(fs[0]) as f:
+            for r in csv.DictReader(f):
+                if "octane::" not in r["Kernel_Name"] or r["Counter_Name"] != cname:
+                    continue
+                short = r["Kernel_Name"].split("octane::")[1].split("(")[0]
+                agg[short].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        for k, n in per_level.items():
+            if k not in agg:
+                continue
+            v = [x for _, x in sorted(agg[k])]
+            per_pyr = n * kiters
+            sel = []
+            for p in range(len(v) // per_pyr):
+                sel += v[p * per_pyr + (kiters - 1) * n:(p + 1) * per_pyr]
+            vals[(k, cname)] = sum(sel) / len(sel)
+    px = size * size
+    alg = {"k_pcg_pass_a": (36, 16), "k_pcg_pass_b": (40, 16), "k_assemble": (52, 36), "k_flow_update": (16, 8)}
+    out += ["", "## HBM traffic per launch at the finest level (rocprofv3 --pmc, separate passes)", "",
+            "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE x1, both KiB -> bytes. Infinity-Cache hits are",
+            "counted by these counters (they sit on the L2's fabric side), so this is L2<->fabric traffic, an upper",
+            "bound on HBM bytes.", "",
+            "| kernel | read MB (FETCH_SIZE x 2) | algorithmic read MB | write MB (WRITE_SIZE) | algorithmic write MB | total / algorithmic |",
+            "|---|---|---|---|---|---|"]
+    for k in ("k_pcg_pass_a", "k_pcg_pass_b", "k_assemble", "k_flow_update"):
+        if (k, "FETCH_SIZE") not in vals:
+            continue
+        rd = vals[(k, "FETCH_SIZE")] * 1024 * 2
+        wr = vals[(k, "WRITE_SIZE")] * 1024
+        ar, aw = alg[k][0] * px, alg[k][1] * px
+        out.append(f"| {k} | {rd / 1e6:.0f} | {ar / 1e6:.0f} | {wr / 1e6:.0f} | {aw / 1e6:.0f} | {(rd + wr) / (ar + aw):.3f} |")
+    return out
+
+
 def main():
     d, out = sys.argv[1], sys.argv[2]
     size, kiters, liters, cgiters = (int(x) for x in (sys.argv[3:7] if len(sys.argv) >= 7 else (5000, 8, 3, 30)))
-    trace = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
+    cands = glob.glob(os.path.join(d, "trace", "**", "*_kernel_trace.csv"), recursive=True) or \
+        glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)
+    trace = cands[0]
     rows = defaultdict(list)
     meta = {}
     with open(trace) as f:
@@ -73,6 +120,7 @@ def main():
                   f"**{56 * px / fin['k_pcg_pass_b']:.0f} GB/s** ({56 * px / fin['k_pcg_pass_b'] / 80:.1f} % of 8 TB/s)",
                   f"* one PCG iteration at SURVEY 8(d)'s 116 B/px: {116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']):.0f} GB/s "
                   f"({116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']) / 80:.1f} % of 8 TB/s)"]
+    lines += pmc_section(d, size, kiters, per_level)
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
