@@ -43,14 +43,13 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from octane_amd import capi, synth
+    from octane_amd import capi, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world > 1:   # one process per GPU over RCCL; only the barrier and the max-over-ranks time use it
+        shard.init_from_env("nccl", device_id=torch.device("cuda", local))
     if capi.lib().octane_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -81,15 +80,11 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
     iters = plan.last_iterations()
     expect = args.kiters * 3 * args.liters * args.cgiters
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * n * n / (elapsed / args.steps) / 1e6
+    value = shard.whole_job_mpix(world * n * n, args.steps, elapsed)
 
     # per-kernel durations of the finest level: one extra, untimed, profiled step (HIP events are
     # recorded on the launch stream around every finest-level launch)

@@ -1,0 +1,3 @@
+// goesread.h -- forwarding header: the reference's host code includes "goesread.h"; the definitions live in octane_types.hpp.
+#pragma once
+#include "octane_types.hpp"

@@ -1,0 +1,34 @@
+// octane_host.hpp -- C++ entry points with the reference's own signatures, implemented in
+// octane_amd/csrc/host_shim.cpp on top of the C-ABI (octane_vof.h).  Linking liboctane_host.so in place of
+// the reference's oct_variational_optical_flow.o / oct_pix2uv_cuda.o / oct_optical_flow.o is the drop-in.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "octane_types.hpp"
+
+// ref src/oct_variational_optical_flow.cu:1213 (declared by the caller at src/oct_optical_flow.cc:12).
+// `nc` is ignored exactly as in the reference (it uses geo1i.nchannels, .cu:1223); CTH is never dereferenced
+// (dodiscrete is hard-wired false, .cu:1302).  uarr/varr: first guess in, flow out.  Prints the reference's
+// messages and exit(0)s when no GPU is present (.cu:1255-1259).
+void oct_variational_optical_flow(Image geo1i, Image geo2i, float *CTH, float *uarr, float *varr,
+                                  int nx, int ny, int nc, OFFlags args);
+
+// ref src/oct_pix2uv_cuda.cu:265 (declared at src/oct_optical_flow.cc:15).  Writes goesData.dT.
+void oct_pix2uv_cuda(GOESVar &goesData, double t2, float *uarr, float *varr, short *ur, short *vr,
+                     short *ur2, short *vr2, OFFlags args);
+
+// ref src/oct_optical_flow.cc:21-111: zero / first-guess initialisation, solver dispatch, CTP scaling,
+// pix2uv.  -sosm, -firstguess and -srsal belong to components outside this library's scope and are reported.
+int oct_optical_flow(GOESVar &goesData, GOESVar &goesData2, OFFlags &args);
+
+// The `octane` command line (ref src/main.cc:42-50 spellings, :53-108 defaults, :166-350 scan), including
+// its quirks: -scsig squares its argument, -set_device is 1-based, -corn clears docorn, -cgiters is not parsed.
+struct OctaneCommandLine {
+    OFFlags args;
+    std::string f1, f2, f1c, f2c, fc21, fc22, fc31, fc32, f1fg;
+    std::string interploc = "./interpolation", outdir = "./";
+    bool show_help = false;     // argc < 4 (ref src/main.cc:112)
+};
+void octane_default_flags(OFFlags &args);
+OctaneCommandLine octane_parse_command_line(int argc, const char *const *argv);
