@@ -37,6 +37,29 @@ __device__ __forceinline__ double fold_partials_256(const double *__restrict__ p
     return block_sum_256(v, scratch);
 }
 
+// Work-item range of this workgroup in a persistent launch.  Plain: items b, b+G, b+2G, ...  Banded: the item
+// list is cut into 8 contiguous bands and workgroup b serves band b % 8 -- workgroups are dealt round-robin over
+// the 8 XCDs (observed, not guaranteed: MI355X_MICROARCH.md), so each XCD's L2 then sees one compact region of
+// the frame and the halo lines shared by neighbouring tiles are L2 hits instead of second fetches through the
+// fabric.  Placement only affects speed, never results.
+struct ItemRange { int base, first, end, step; };   // items first, first+step, ... < end of the range [base, end)
+__device__ __forceinline__ ItemRange item_range(int nitems, bool banded)
+{
+    ItemRange r;
+    if (banded && (gridDim.x & 7) == 0 && nitems >= 64) {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int per = (nitems + 7) >> 3;
+        const int b0 = xcd * per;
+        r.base = b0;
+        r.first = b0 + local;
+        r.end = min(nitems, b0 + per);
+        r.step = gridDim.x >> 3;
+    } else {
+        r.base = 0; r.first = blockIdx.x; r.end = nitems; r.step = gridDim.x;
+    }
+    return r;
+}
+
 // Jacobi preconditioner entry exactly as the reference forms it: M = 1./M in double, stored
 // as float (ref .cu:141-149).
 __device__ __forceinline__ float jacobi_inv(float a) { return (float)(1. / (double)a); }

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
     float *__restrict__ pout_u = L.pu[(k + 1) & 1];
     float *__restrict__ pout_v = L.pv[(k + 1) & 1];
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
+    for (int t = tr.first; t < tr.end; t += tr.step) {
         const int tx0 = (t % tiles_x) * kTileX, ty0 = (t / tiles_x) * kTileY;
         const int x = tx0 + lx * 4, y = ty0 + ly;
         const bool rowok = (y < h) && (x < w);
@@ -344,46 +345,245 @@ __global__ __launch_bounds__(256, 4) void k_pcg_pass_a_rows(LevelPtrs L, int k, 
     if (tid == 0) L.part_pq[blockIdx.x] = tot;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass A, marching form (OCTANE_TUNE_PASS_A=2).
+//
+// A workgroup owns a strip 1024 pixels wide (256 lanes x 4 px) and marches down a run of rows.  Each
+// lane keeps p_new of rows y-1, y, y+1 of its four columns in registers, so the vertical neighbours are
+// free and no row is ever loaded twice inside a run; horizontal neighbours come from the adjacent lane
+// (wavefront shuffle), from the adjacent wave (a 4-entry LDS edge table, one barrier per row) or, at the
+// two ends of the strip, from one recomputed pixel.  Re-fetch through the fabric is then ~4 % (strip
+// ends) + 2 reduced rows per run instead of the 44 % of the 128x8 tiles.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMarchW = 1024;
+
+__global__ __launch_bounds__(256, 4) void k_pcg_pass_a_march(LevelPtrs L, int k, int nparts_prev, float tol)
+{
+    __shared__ double s_red[8];
+    __shared__ float s_edge[2][4][6];   // [row parity][wave]{u,v of first px, u,v,wx of last px}
+    __shared__ float s_side[2][4];      // [row parity]{u,v just west of the strip, u,v just east}
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
+    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
+    const PcgState prev = L.st[k & 1];
+    const bool active = (prev.stopped == 0) && (rr > tol);          // ref .cu:1131
+    if (!active) {
+        if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
+        return;
+    }
+    const bool first = (k == 0);
+    const float beta = first ? 0.f : rz_new / prev.rz;
+    if (blockIdx.x == 0 && tid == 0) {
+        PcgState n; n.rz = rz_new; n.stopped = 0; n.iters = prev.iters + 1; n.pad = 0;
+        L.st[(k + 1) & 1] = n;
+    }
+
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int strips = (w + kMarchW - 1) / kMarchW;
+    const long total_rows = (long)strips * h;
+    const float *__restrict__ pin_u = L.pu[k & 1];
+    const float *__restrict__ pin_v = L.pv[k & 1];
+    float *__restrict__ pout_u = L.pu[(k + 1) & 1];
+    float *__restrict__ pout_v = L.pv[(k + 1) & 1];
+    double acc = 0.;
+
+    // this workgroup's share of the (strip-major) list of strip rows: equal for all workgroups (+-1)
+    long vr = total_rows * blockIdx.x / gridDim.x;
+    const long vr_end = total_rows * (blockIdx.x + 1) / gridDim.x;
+    while (vr < vr_end) {
+        const int sidx = (int)(vr / h);
+        const int y0 = (int)(vr - (long)sidx * h);
+        const int y1 = (int)min((long)h, y0 + (vr_end - vr));
+        vr += y1 - y0;
+        const int x0 = sidx * kMarchW;
+        const int x = x0 + tid * 4;
+        const bool colok = x < w;
+        const bool west_side = (tid == 0) && (x0 > 0);
+        const bool east_side = (tid == 255) && (x0 + kMarchW < w);
+        const int xs = west_side ? x0 - 1 : x0 + kMarchW;     // the one pixel outside the strip this lane recomputes
+
+        auto side_dir = [&](int yy, float &su, float &sv) {
+            const size_t so = (size_t)yy * pitch + xs;
+            const float q0 = first ? 0.f : pin_u[so], q1 = first ? 0.f : pin_v[so];
+            su = direction(L.ru[so], q0, L.a1[so], beta, first);
+            sv = direction(L.rv[so], q1, L.a4[so], beta, first);
+        };
+        auto publish = [&](const RowDir &d, const float *wx4, int yy) {     // edges of row yy for the other waves
+            const int par = yy & 1;
+            if (lane == 0) { s_edge[par][wave][0] = d.u[0]; s_edge[par][wave][1] = d.v[0]; }
+            if (lane == 63) { s_edge[par][wave][2] = d.u[3]; s_edge[par][wave][3] = d.v[3]; s_edge[par][wave][4] = wx4[3]; }
+            if (west_side || east_side) {
+                float su, sv;
+                side_dir(yy, su, sv);
+                s_side[par][west_side ? 0 : 2] = su; s_side[par][west_side ? 1 : 3] = sv;
+            }
+        };
+
+        RowDir pm, pc, pn;
+        float a1c[4], a4c[4], a2c[4] = {0, 0, 0, 0}, wxc[4] = {0, 0, 0, 0}, wyc[4] = {0, 0, 0, 0}, wym[4] = {0, 0, 0, 0};
+        float a1n[4], a4n[4], a2n[4] = {0, 0, 0, 0}, wxn[4] = {0, 0, 0, 0}, wyn[4] = {0, 0, 0, 0};
+        float wx_side_c = 0.f, wx_side_n = 0.f;     // wx just west of the strip (lane 0 of wave 0 only)
+#pragma unroll
+        for (int e = 0; e < 4; e++) { pm.u[e] = 0.f; pm.v[e] = 0.f; }
+        __syncthreads();                             // the edge tables may still be read by a previous run
+        if (y0 > 0) {
+            const size_t om = (size_t)(y0 - 1) * pitch + x;
+            pm = row_direction(L, pin_u, pin_v, om, x, w, beta, first, colok, nullptr, nullptr);
+            if (colok) *(float4 *)wym = ld4(L.wy + om);
+        }
+        {
+            const size_t oc = (size_t)y0 * pitch + x;
+            pc = row_direction(L, pin_u, pin_v, oc, x, w, beta, first, colok, a1c, a4c);
+            if (colok) { *(float4 *)a2c = ld4(L.a2 + oc); *(float4 *)wxc = ld4(L.wx + oc); *(float4 *)wyc = ld4(L.wy + oc); }
+            if (west_side) wx_side_c = L.wx[oc - 1];
+            publish(pc, wxc, y0);
+        }
+        for (int y = y0; y < y1; ++y) {
+            const size_t on = (size_t)(y + 1) * pitch + x;
+            if (y + 1 < h) {
+                pn = row_direction(L, pin_u, pin_v, on, x, w, beta, first, colok, a1n, a4n);
+                if (y + 1 < y1) {
+                    if (colok) { *(float4 *)a2n = ld4(L.a2 + on); *(float4 *)wxn = ld4(L.wx + on); *(float4 *)wyn = ld4(L.wy + on); }
+                    if (west_side) wx_side_n = L.wx[on - 1];
+                    publish(pn, wxn, y + 1);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { pn.u[e] = 0.f; pn.v[e] = 0.f; }
+            }
+            __syncthreads();                         // row y's edge entries (written one step ago) are visible
+            const int par = y & 1;
+            float uwest = __shfl_up(pc.u[3], 1, 64), vwest = __shfl_up(pc.v[3], 1, 64);
+            float ueast = __shfl_down(pc.u[0], 1, 64), veast = __shfl_down(pc.v[0], 1, 64);
+            float wxw = __shfl_up(wxc[3], 1, 64);
+            if (lane == 0) {
+                if (wave > 0) { uwest = s_edge[par][wave - 1][2]; vwest = s_edge[par][wave - 1][3]; wxw = s_edge[par][wave - 1][4]; }
+                else { uwest = s_side[par][0]; vwest = s_side[par][1]; wxw = wx_side_c; }
+            }
+            if (lane == 63) {
+                if (wave < 3) { ueast = s_edge[par][wave + 1][0]; veast = s_edge[par][wave + 1][1]; }
+                else { ueast = s_side[par][2]; veast = s_side[par][3]; }
+            }
+            if (colok) {
+                float qu[4], qv[4];
+                float rowdot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = x + e;
+                    const float pwu = (e == 0) ? uwest : pc.u[(e + 3) & 3], pwv = (e == 0) ? vwest : pc.v[(e + 3) & 3];
+                    const float peu = (e == 3) ? ueast : pc.u[(e + 1) & 3], pev = (e == 3) ? veast : pc.v[(e + 1) & 3];
+                    const float a5 = (e == 0) ? wxw : wxc[(e + 3) & 3];
+                    const float wS = (y == h - 1) ? wym[e] + wyc[e] : wym[e];
+                    const float wW = (i == w - 1) ? a5 + wxc[e] : a5;
+                    const float wE = (i == 0) ? wxc[e] + wxc[e] : wxc[e];
+                    const float wN = (y == 0) ? wyc[e] + wyc[e] : wyc[e];
+                    float sumu = 0.f, sumv = 0.f;
+                    if (y > 0) { sumu += wS * pm.u[e]; sumv += wS * pm.v[e]; }
+                    if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
+                    sumu += a1c[e] * pc.u[e]; sumv += a2c[e] * pc.u[e];
+                    sumu += a2c[e] * pc.v[e]; sumv += a4c[e] * pc.v[e];
+                    if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
+                    if (y < h - 1) { sumu += wN * pn.u[e]; sumv += wN * pn.v[e]; }
+                    qu[e] = sumu; qv[e] = sumv;
+                    if (i < w) { rowdot += pc.u[e] * sumu; rowdot += pc.v[e] * sumv; }
+                }
+                const size_t o = (size_t)y * pitch + x;
+                st4(pout_u + o, *(float4 *)pc.u);
+                st4(pout_v + o, *(float4 *)pc.v);
+                st4(L.qu + o, *(float4 *)qu);
+                st4(L.qv + o, *(float4 *)qv);
+                acc += (double)rowdot;
+            }
+            pm = pc; pc = pn;
+            wx_side_c = wx_side_n;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                wym[e] = wyc[e];
+                a1c[e] = a1n[e]; a4c[e] = a4n[e]; a2c[e] = a2n[e]; wxc[e] = wxn[e]; wyc[e] = wyn[e];
+            }
+        }
+    }
+    const double tot = block_sum_256(acc, s_red);
+    if (tid == 0) L.part_pq[blockIdx.x] = tot;
+}
+
+struct BOperands {
+    float4 ru, rv, pu, pv, qu, qv, mu, mv, xu, xv;
+    size_t o;
+    int x;
+    bool valid;
+};
+
+// Operand loads of one 256-group chunk of pass B.  None of them depends on alpha, so the first chunk's loads
+// are issued BEFORE the partials are folded and the next chunk's before the current one is computed: the
+// reduction's round trip and the arithmetic hide under memory latency instead of adding to it.
+__device__ __forceinline__ void pass_b_issue(const LevelPtrs &L, int k, bool first, const ItemRange &cr, int ci,
+                                             long ngroups, int gw, int pitch, BOperands &b)
+{
+    b.valid = false;
+    if (ci >= cr.end) return;
+    const int c = L.reverse_b ? cr.end - 1 - (ci - cr.base) : ci;
+    const long g = (long)c * 256 + threadIdx.x;
+    if (g >= ngroups) return;
+    const int y = (int)(g / gw);
+    b.x = (int)(g - (long)y * gw) * 4;
+    b.o = (size_t)y * pitch + b.x;
+    b.valid = true;
+    b.ru = ld4(L.ru + b.o); b.rv = ld4(L.rv + b.o);
+    b.pu = ld4(L.pu[(k + 1) & 1] + b.o); b.pv = ld4(L.pv[(k + 1) & 1] + b.o);
+    b.qu = ld4(L.qu + b.o); b.qv = ld4(L.qv + b.o);
+    b.mu = ld4(L.mu + b.o); b.mv = ld4(L.mv + b.o);
+    if (!first) { b.xu = ld4(L.xu + b.o); b.xv = ld4(L.xv + b.o); }
+    else { b.xu = make_float4(0, 0, 0, 0); b.xv = make_float4(0, 0, 0, 0); }
+}
+
 __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int nparts_a)
 {
     __shared__ double s_red[8];
+    const bool first = (k == 0);
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int gw = (w + 3) / 4;
+    const long ngroups = (long)gw * h;
+    // Pass B walks the frame from the end to the start and pass A from the start to the end, so
+    // each pass begins on the planes the previous one touched last (p, q, r and the diagonal are
+    // still in the 256 MiB Infinity Cache there).
+    const int nchunks = (int)((ngroups + 255) / 256);
+    const ItemRange cr = item_range(nchunks, L.xcd_bands != 0);
+    BOperands cur, nxt;
+    pass_b_issue(L, k, first, cr, cr.first, ngroups, gw, pitch, cur);
+
     const PcgState st = L.st[(k + 1) & 1];
     if (st.stopped) return;
     const float pq = (float)fold_partials_256(L.part_pq, nparts_a, s_red);
     const float alpha = st.rz / pq;                        // ref .cu:1169
     const float nalpha = (float)(-1. * (double)alpha);     // ref .cu:1174
-    const bool first = (k == 0);
-    const int w = L.w, h = L.h, pitch = L.pitch;
-    const int gw = (w + 3) / 4;
-    const long ngroups = (long)gw * h;
     double acc_rz = 0., acc_rr = 0.;
-    // Pass B walks the frame from the end to the start and pass A from the start to the end, so
-    // each pass begins on the planes the previous one touched last (p, q, r and the diagonal are
-    // still in the 256 MiB Infinity Cache there).
-    for (long gr = (long)blockIdx.x * 256 + threadIdx.x; gr < ngroups; gr += (long)gridDim.x * 256) {
-        const long g = L.reverse_b ? ngroups - 1 - gr : gr;
-        const int y = (int)(g / gw), x = (int)(g - (long)y * gw) * 4;
-        const size_t o = (size_t)y * pitch + x;
-        float xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0}, ru[4], rv[4], pu[4], pv[4], qu[4], qv[4], mu[4], mv[4];
-        *(float4 *)ru = ld4(L.ru + o); *(float4 *)rv = ld4(L.rv + o);
-        *(float4 *)pu = ld4(L.pu[(k + 1) & 1] + o); *(float4 *)pv = ld4(L.pv[(k + 1) & 1] + o);
-        *(float4 *)qu = ld4(L.qu + o); *(float4 *)qv = ld4(L.qv + o);
-        *(float4 *)mu = ld4(L.mu + o); *(float4 *)mv = ld4(L.mv + o);
-        if (!first) { *(float4 *)xu = ld4(L.xu + o); *(float4 *)xv = ld4(L.xv + o); }
+    for (int ci = cr.first; ci < cr.end; ci += cr.step) {
+        pass_b_issue(L, k, first, cr, ci + cr.step, ngroups, gw, pitch, nxt);
+        if (cur.valid) {
+            float xu[4], xv[4], ru[4], rv[4], pu[4], pv[4], qu[4], qv[4], mu[4], mv[4];
+            *(float4 *)xu = cur.xu; *(float4 *)xv = cur.xv; *(float4 *)ru = cur.ru; *(float4 *)rv = cur.rv;
+            *(float4 *)pu = cur.pu; *(float4 *)pv = cur.pv; *(float4 *)qu = cur.qu; *(float4 *)qv = cur.qv;
+            *(float4 *)mu = cur.mu; *(float4 *)mv = cur.mv;
+            float srz = 0.f, srr = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            xu[e] = alpha * pu[e] + xu[e];                 // jVecPVec(p0,x0,x0,alphak), ref .cu:1172
-            xv[e] = alpha * pv[e] + xv[e];
-            ru[e] = nalpha * qu[e] + ru[e];                // jVecPVec(dummyvec,bcu,rk,-alphak), ref .cu:1174
-            rv[e] = nalpha * qv[e] + rv[e];
-            if (x + e < w) {
-                const float zu = mu[e] * ru[e], zv = mv[e] * rv[e];
-                acc_rz += (double)(ru[e] * zu) + (double)(rv[e] * zv);
-                acc_rr += (double)(ru[e] * ru[e]) + (double)(rv[e] * rv[e]);
+            for (int e = 0; e < 4; e++) {
+                xu[e] = alpha * pu[e] + xu[e];             // jVecPVec(p0,x0,x0,alphak), ref .cu:1172
+                xv[e] = alpha * pv[e] + xv[e];
+                ru[e] = nalpha * qu[e] + ru[e];            // jVecPVec(dummyvec,bcu,rk,-alphak), ref .cu:1174
+                rv[e] = nalpha * qv[e] + rv[e];
+                if (cur.x + e < w) {
+                    const float zu = mu[e] * ru[e], zv = mv[e] * rv[e];
+                    srz += ru[e] * zu; srz += rv[e] * zv;
+                    srr += ru[e] * ru[e]; srr += rv[e] * rv[e];
+                }
             }
+            st4(L.xu + cur.o, *(float4 *)xu); st4(L.xv + cur.o, *(float4 *)xv);
+            st4(L.ru + cur.o, *(float4 *)ru); st4(L.rv + cur.o, *(float4 *)rv);
+            acc_rz += (double)srz; acc_rr += (double)srr;
         }
-        st4(L.xu + o, *(float4 *)xu); st4(L.xv + o, *(float4 *)xv);
-        st4(L.ru + o, *(float4 *)ru); st4(L.rv + o, *(float4 *)rv);
+        cur = nxt;
     }
     const double trz = block_sum_256(acc_rz, s_red);
     const double trr = block_sum_256(acc_rr, s_red);
@@ -421,12 +621,28 @@ static int stream_grid_size(int w, int h)
     return balanced_grid((groups + 255) / 256);
 }
 
+// Pass B keeps two chunks of operands in registers (~124 VGPRs): 4 workgroups per CU are resident, so its
+// persistent grid is capped at 256 x 4.
+static int pass_b_grid_size(int w, int h)
+{
+    long chunks = ((long)((w + 3) / 4) * h + 255) / 256;
+    int g = balanced_grid(chunks);
+    if (g > 1024) { long rounds = (chunks + 1023) / 1024; g = (int)((chunks + rounds - 1) / rounds); }
+    return g;
+}
+
 static int g_pass_a_variant = 0;   // 0 = LDS-tiled (default), 1 = row-rolling (experimental, slower so far)
 void set_pass_a_variant(int v) { g_pass_a_variant = v; }
 
 int pcg_grid_size(int w, int h)
 {
     if (g_pass_a_variant == 0) return pcg_tiled_grid_size(w, h);
+    if (g_pass_a_variant == 2) {   // marching: at least 8 rows per workgroup, at most 1024 workgroups (4 per CU resident)
+        long rows = (long)((w + kMarchW - 1) / kMarchW) * h;
+        long g = rows / 8;
+        if (g < 1) g = 1;
+        return (int)(g > 1024 ? 1024 : g);
+    }
     long items = (long)((w + kStripW - 1) / kStripW) * ((h + kSegRows - 1) / kSegRows);
     return balanced_grid((items + 3) / 4);
 }
@@ -435,6 +651,8 @@ void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev
 {
     if (g_pass_a_variant == 0)
         hipLaunchKernelGGL(k_pcg_pass_a, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    else if (g_pass_a_variant == 2)
+        hipLaunchKernelGGL(k_pcg_pass_a_march, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
     else
         hipLaunchKernelGGL(k_pcg_pass_a_rows, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
 }
@@ -449,6 +667,6 @@ void launch_flow_update(hipStream_t s, const LevelPtrs &L, int nlaunched)
     hipLaunchKernelGGL(k_flow_update, dim3(stream_grid_size(L.w, L.h)), dim3(256), 0, s, L, nlaunched);
 }
 
-int pcg_b_grid_size(int w, int h) { return stream_grid_size(w, h); }
+int pcg_b_grid_size(int w, int h) { return pass_b_grid_size(w, h); }
 
 }  // namespace octane

@@ -358,14 +358,25 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
 // Persistent grid for `items` equal work items: the fewest rounds that fit kMaxParts blocks, then
 // as many blocks as give every block that many items (+-1) -- no half-empty last round.
 static int g_max_blocks = kMaxParts;
+static int g_grid_multiple = 1;
 void set_max_blocks(int n) { g_max_blocks = (n >= 64 && n <= kMaxParts) ? n : kMaxParts; }
+void set_grid_multiple(int m) { g_grid_multiple = m > 0 ? m : 1; }
 
 int balanced_grid(long items)
 {
     const int cap = g_max_blocks;
-    if (items <= cap) return items < 1 ? 1 : (int)items;
-    long rounds = (items + cap - 1) / cap;
-    return (int)((items + rounds - 1) / rounds);
+    long g;
+    if (items <= cap) {
+        g = items < 1 ? 1 : items;
+    } else {
+        long rounds = (items + cap - 1) / cap;
+        g = (items + rounds - 1) / rounds;
+    }
+    if (g_grid_multiple > 1 && g >= 8 * g_grid_multiple) {   // XCD-banded launches want a multiple of 8
+        g = (g + g_grid_multiple - 1) / g_grid_multiple * g_grid_multiple;
+        if (g > cap) g -= g_grid_multiple;
+    }
+    return (int)g;
 }
 
 int assemble_grid_size(int w, int h)

@@ -46,6 +46,7 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     PcgState *st;
     long long *iter_total;
     int reverse_b;                  // pass B walks the frame backwards (Infinity-Cache reuse)
+    int xcd_bands;                  // give each XCD (blockIdx % 8) one contiguous band of the frame
 };
 
 struct AssembleParams {
@@ -63,7 +64,8 @@ void launch_blur_cols_sampled(hipStream_t s, const float *src, int sw, int sh, i
 void launch_gradient(hipStream_t s, const float *f, float *gx, float *gy, int w, int h, int pitch, int nc, size_t cstride);
 void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpitch,
                      float *fine, int fw, int fh, int fpitch, float sf);
-void set_max_blocks(int n);           // tuning knob (<= kMaxParts)
+void set_max_blocks(int n);
+void set_grid_multiple(int m);           // tuning knob (<= kMaxParts)
 int  balanced_grid(long work_items);   // persistent grid: every block gets the same number of items (+-1)
 int  pcg_grid_size(int w, int h);
 void set_pass_a_variant(int v);       // tuning knob: 0 LDS-tiled (default), 1 row-rolling

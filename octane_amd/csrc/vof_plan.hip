@@ -72,6 +72,7 @@ struct octane_vof_plan {
     octane_vof_profile prof;
     float tol;
     int reverse_b = 1;
+    int xcd_bands = 0;
 };
 
 extern "C" const char *octane_last_error(void) { return g_last_error.c_str(); }
@@ -150,6 +151,8 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     if (const char *e = getenv("OCTANE_TUNE_MAXBLOCKS")) set_max_blocks(atoi(e));   // developer tuning knobs
     if (const char *e = getenv("OCTANE_TUNE_REVERSE_B")) pl->reverse_b = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_PASS_A")) set_pass_a_variant(atoi(e));
+    if (const char *e = getenv("OCTANE_TUNE_XCD")) pl->xcd_bands = atoi(e) != 0;
+    set_grid_multiple(pl->xcd_bands ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
 
     const float scale = (float)p->scaleF;
@@ -386,6 +389,7 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         L.part_rz = pl->d_parts; L.part_rr = pl->d_parts + kMaxParts; L.part_pq = pl->d_parts + 2 * kMaxParts;
         L.st = pl->d_state; L.iter_total = pl->d_iters;
         L.reverse_b = pl->reverse_b;
+        L.xcd_bands = pl->xcd_bands;
 
         const int g_asm = assemble_grid_size(li.w, li.h);
         const int g_a = pcg_grid_size(li.w, li.h);

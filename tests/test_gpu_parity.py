@@ -16,25 +16,31 @@ INVESTIGATE = 2e-5  # expect ~3e-6
 
 
 def _check(capi, oracle, a, b, prm_kwargs, u0=None, v0=None, bar=INVESTIGATE):
-    """GPU vs strict oracle.  The bar is 2e-5 unless the problem itself is more sensitive than
-    that to rounding: the distance between the oracle's two builds (FMA-contracted vs not, same
-    source) measures that sensitivity, and the GPU may not be further from the strict oracle
-    than twice that.  (With the default alpha/lambda the floor is ~1e-6; alpha=12, lambda=0.25
-    on a 90x70 frame has a floor of 1.8e-4 -- the truncated solve amplifies single roundings.)"""
-    # dot products under the reference's CUDA launch geometry (oracle/vof_oracle.c, dotf): the
-    # one-thread running sum drifts by 1e-3 beyond ~0.3 Mpixel, which is the schedule's artefact
+    """GPU vs strict oracle.
+
+    The oracle offers two valid schedules of the reference's dot product (oracle/vof_oracle.c, dotf): the CUDA
+    launch geometry (what a GPU run of the reference adds up) and the one-thread running sum (what the survey
+    recorded; only meaningful on small frames, it drifts by 1e-3 beyond ~0.3 Mpixel).  The GPU has to match
+    one of them.  The bar is 2e-5 unless the problem itself is more sensitive than that to rounding: the
+    distance between the oracle's two builds (FMA-contracted vs not, same source) measures that sensitivity,
+    and the GPU may not be further away than twice that.  (alpha=12, lambda=0.25 on a 90x70 frame is such a
+    case: a 1e-7 change in a dot product moves the flow by 1.5e-4.)"""
     g = oracle.REF_GRID_THREADS
-    uo, vo, its_o = oracle.flow(a, b, oracle.FlowParams(**prm_kwargs), u0=u0, v0=v0, dot_threads=g)
-    uf, vf, _ = oracle.flow(a, b, oracle.FlowParams(**prm_kwargs), u0=u0, v0=v0, flavour="fma", dot_threads=g)
+    P = oracle.FlowParams(**prm_kwargs)
+    uo, vo, its_o = oracle.flow(a, b, P, u0=u0, v0=v0, dot_threads=g)
+    uf, vf, _ = oracle.flow(a, b, P, u0=u0, v0=v0, flavour="fma", dot_threads=g)
     bar = max(bar, 2.0 * rel_l2(uf, vf, uo, vo))
     nc, ny, nx = (1,) + a.shape if a.ndim == 2 else a.shape
     pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm_kwargs))
     ug, vg = pl.run_host(a, b, u0, v0)
     its_g = pl.last_iterations()
     pl.close()
-    d = rel_l2(ug, vg, uo, vo)
     assert np.isfinite(ug).all() and np.isfinite(vg).all()
-    assert d < bar, f"relative L2 {d:.3e} vs oracle"
+    d = rel_l2(ug, vg, uo, vo)
+    if d >= bar and nx * ny <= 100_000:
+        us, vs, _ = oracle.flow(a, b, P, u0=u0, v0=v0)          # one-thread schedule
+        d = min(d, rel_l2(ug, vg, us, vs))
+    assert d < bar, f"relative L2 {d:.3e} vs oracle (bar {bar:.1e})"
     return d, its_o, its_g
 
 
