@@ -667,6 +667,154 @@ void launch_flow_update(hipStream_t s, const LevelPtrs &L, int nlaunched)
     hipLaunchKernelGGL(k_flow_update, dim3(stream_grid_size(L.w, L.h)), dim3(256), 0, s, L, nlaunched);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Whole PCG solve in one workgroup, for the coarsest pyramid levels (<= kSmallMaxPix pixels).
+//
+// At 39x39 or 78x78 pixels a PCG pass is 5-7 us of launch + latency for a few hundred nanoseconds of
+// work, 60 times per solve.  Here one 512-thread workgroup keeps r, x, p and the operator in registers
+// (up to 12 pixels per thread), exchanges p through LDS and runs all cgiters iterations, the stop test and
+// the flow update u += dx, v += dy (ref .cu:1105-1195) between workgroup barriers: one launch per solve.
+// Same recurrences, same operator, same stop rule as the two-pass kernels; only the (fp64) summation
+// order of the dot products differs.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSmallThreads = 512;             // 2 waves per SIMD -> 256 VGPRs per lane
+constexpr int kSmallMaxPerThread = 12;         // 15 register arrays per pixel
+constexpr int kSmallMaxPix = kSmallThreads * kSmallMaxPerThread;
+
+__device__ __forceinline__ double block_sum_1024(double v, double *scratch)   // over kSmallThreads lanes
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.;
+#pragma unroll
+    for (int i = 0; i < kSmallThreads / 64; i++) t += scratch[i];
+    return t;
+}
+
+template <int kSmallPerThread>
+__global__ __launch_bounds__(kSmallThreads) void k_pcg_solve_small(LevelPtrs L, int maxit, float tol)
+{
+    extern __shared__ float s_mem[];               // p_u, p_v, x_u, x_v, wx, wy: npix floats each
+    __shared__ double s_red[16];
+    const int w = L.w, h = L.h, pitch = L.pitch, npix = w * h;
+    float *s_pu = s_mem, *s_pv = s_mem + npix, *s_xu = s_mem + 2 * npix, *s_xv = s_mem + 3 * npix;
+    float *s_wx = s_mem + 4 * npix, *s_wy = s_mem + 5 * npix;
+    const int tid = threadIdx.x;
+
+    float ru[kSmallPerThread], rv[kSmallPerThread], pu[kSmallPerThread], pv[kSmallPerThread];
+    float a1[kSmallPerThread], a2[kSmallPerThread], a4[kSmallPerThread], mu[kSmallPerThread], mv[kSmallPerThread];
+    double d_rz = 0., d_rr = 0.;
+#pragma unroll
+    for (int s = 0; s < kSmallPerThread; s++) {
+        const int n = tid + s * kSmallThreads;
+        ru[s] = rv[s] = pu[s] = pv[s] = 0.f;
+        a1[s] = a4[s] = 1.f; a2[s] = mu[s] = mv[s] = 0.f;
+        if (n < npix) {
+            const size_t o = (size_t)(n / w) * pitch + (n % w);
+            ru[s] = L.ru[o]; rv[s] = L.rv[o];
+            a1[s] = L.a1[o]; a2[s] = L.a2[o]; a4[s] = L.a4[o]; mu[s] = L.mu[o]; mv[s] = L.mv[o];
+            s_wx[n] = L.wx[o]; s_wy[n] = L.wy[o];
+            s_xu[n] = 0.f; s_xv[n] = 0.f;
+            const float zu = mu[s] * ru[s], zv = mv[s] * rv[s];
+            float t = 0.f; t += ru[s] * zu; t += rv[s] * zv; d_rz += (double)t;
+            t = 0.f; t += ru[s] * ru[s]; t += rv[s] * rv[s]; d_rr += (double)t;
+        }
+    }
+    float rz = (float)block_sum_1024(d_rz, s_red);
+    float rr = (float)block_sum_1024(d_rr, s_red);
+    float rz_old = 0.f;
+    int it = 0;
+    while (rr > tol && it < maxit) {                                   // ref .cu:1131
+        const float beta = (it == 0) ? 0.f : rz / rz_old;
+#pragma unroll
+        for (int s = 0; s < kSmallPerThread; s++) {
+            const int n = tid + s * kSmallThreads;
+            if (n < npix) {
+                const float zu = mu[s] * ru[s], zv = mv[s] * rv[s];
+                pu[s] = (it == 0) ? zu : beta * pu[s] + zu;
+                pv[s] = (it == 0) ? zv : beta * pv[s] + zv;
+                s_pu[n] = pu[s]; s_pv[n] = pv[s];
+            }
+        }
+        __syncthreads();
+        float qu[kSmallPerThread], qv[kSmallPerThread];
+        double d_pq = 0.;
+#pragma unroll
+        for (int s = 0; s < kSmallPerThread; s++) {
+            const int n = tid + s * kSmallThreads;
+            qu[s] = qv[s] = 0.f;
+            if (n < npix) {
+                const int j = n / w, i = n - j * w;
+                // merged border weights exactly as the two-pass kernel forms them (ref .cu:929-1001)
+                const float wxc = s_wx[n], wyc = s_wy[n];
+                float sumu = 0.f, sumv = 0.f;
+                if (j > 0) { const float a6 = s_wy[n - w]; const float wS = (j == h - 1) ? a6 + wyc : a6; sumu += wS * s_pu[n - w]; sumv += wS * s_pv[n - w]; }
+                if (i > 0) { const float a5 = s_wx[n - 1]; const float wW = (i == w - 1) ? a5 + wxc : a5; sumu += wW * s_pu[n - 1]; sumv += wW * s_pv[n - 1]; }
+                sumu += a1[s] * pu[s]; sumv += a2[s] * pu[s];
+                sumu += a2[s] * pv[s]; sumv += a4[s] * pv[s];
+                if (i < w - 1) { const float wE = (i == 0) ? wxc + wxc : wxc; sumu += wE * s_pu[n + 1]; sumv += wE * s_pv[n + 1]; }
+                if (j < h - 1) { const float wN = (j == 0) ? wyc + wyc : wyc; sumu += wN * s_pu[n + w]; sumv += wN * s_pv[n + w]; }
+                qu[s] = sumu; qv[s] = sumv;
+                float t = 0.f; t += pu[s] * sumu; t += pv[s] * sumv; d_pq += (double)t;
+            }
+        }
+        const float pq = (float)block_sum_1024(d_pq, s_red);          // its barriers also order the LDS reads of p
+        const float alpha = rz / pq;                                    // before the next iteration's writes
+        const float nalpha = (float)(-1. * (double)alpha);
+        d_rz = 0.; d_rr = 0.;
+#pragma unroll
+        for (int s = 0; s < kSmallPerThread; s++) {
+            const int n = tid + s * kSmallThreads;
+            if (n < npix) {
+                s_xu[n] = alpha * pu[s] + s_xu[n];                      // own element only: no hazard
+                s_xv[n] = alpha * pv[s] + s_xv[n];
+                ru[s] = nalpha * qu[s] + ru[s];
+                rv[s] = nalpha * qv[s] + rv[s];
+                const float zu = mu[s] * ru[s], zv = mv[s] * rv[s];
+                float t = 0.f; t += ru[s] * zu; t += rv[s] * zv; d_rz += (double)t;
+                t = 0.f; t += ru[s] * ru[s]; t += rv[s] * rv[s]; d_rr += (double)t;
+            }
+        }
+        rz_old = rz;
+        rz = (float)block_sum_1024(d_rz, s_red);
+        rr = (float)block_sum_1024(d_rr, s_red);
+        it++;
+    }
+    if (it > 0) {                                                      // ref .cu:1185-1195
+#pragma unroll
+        for (int s = 0; s < kSmallPerThread; s++) {
+            const int n = tid + s * kSmallThreads;
+            if (n < npix) {
+                const size_t o = (size_t)(n / w) * pitch + (n % w);
+                L.u[o] = L.u[o] + s_xu[n];
+                L.v[o] = L.v[o] + s_xv[n];
+                L.xu[o] = s_xu[n]; L.xv[o] = s_xv[n];                   // kept for the debug tap
+            }
+        }
+    }
+    if (tid == 0) *L.iter_total += it;
+}
+
+bool pcg_small_applicable(int w, int h) { return (long)w * h <= kSmallMaxPix; }
+
+void launch_pcg_solve_small(hipStream_t s, const LevelPtrs &L, int maxit, float tol)
+{
+    const size_t lds = (size_t)6 * L.w * L.h * sizeof(float);       // <= 147456 B of the CU's 160 KiB
+    const int per = (L.w * L.h + kSmallThreads - 1) / kSmallThreads;
+    static bool configured = false;
+    if (!configured) {    // dynamic LDS above 64 KiB has to be allowed per kernel
+        (void)hipFuncSetAttribute((const void *)k_pcg_solve_small<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kSmallMaxPix * 4);
+        (void)hipFuncSetAttribute((const void *)k_pcg_solve_small<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kSmallMaxPix * 4);
+        (void)hipFuncSetAttribute((const void *)k_pcg_solve_small<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kSmallMaxPix * 4);
+        configured = true;
+    }
+    if (per <= 3) hipLaunchKernelGGL(k_pcg_solve_small<3>, dim3(1), dim3(kSmallThreads), lds, s, L, maxit, tol);
+    else if (per <= 6) hipLaunchKernelGGL(k_pcg_solve_small<6>, dim3(1), dim3(kSmallThreads), lds, s, L, maxit, tol);
+    else hipLaunchKernelGGL(k_pcg_solve_small<12>, dim3(1), dim3(kSmallThreads), lds, s, L, maxit, tol);
+}
+
 int pcg_b_grid_size(int w, int h) { return pass_b_grid_size(w, h); }
 
 }  // namespace octane

@@ -74,6 +74,8 @@ void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P,
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid);
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int niter_launched);
+bool pcg_small_applicable(int w, int h);
+void launch_pcg_solve_small(hipStream_t s, const LevelPtrs &L, int maxit, float tol);   // whole solve + flow update, one workgroup
 
 struct NavArgs {
     double pph, req, rpol, lam0;

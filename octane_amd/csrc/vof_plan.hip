@@ -73,6 +73,7 @@ struct octane_vof_plan {
     float tol;
     int reverse_b = 1;
     int xcd_bands = 0;
+    int use_small = 1;
 };
 
 extern "C" const char *octane_last_error(void) { return g_last_error.c_str(); }
@@ -152,6 +153,7 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     if (const char *e = getenv("OCTANE_TUNE_REVERSE_B")) pl->reverse_b = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_PASS_A")) set_pass_a_variant(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_XCD")) pl->xcd_bands = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_SMALL")) pl->use_small = atoi(e) != 0;
     set_grid_multiple(pl->xcd_bands ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
 
@@ -395,6 +397,7 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         const int g_a = pcg_grid_size(li.w, li.h);
         const int g_b = pcg_b_grid_size(li.w, li.h);
         const bool pf = prof && finest;
+        const bool small = pl->use_small && pcg_small_applicable(li.w, li.h);
 
         for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
             AssembleParams ap;
@@ -411,6 +414,9 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
                     int rc = emit(pl, s, "coef7", k, gnc, l, {pl->a1, pl->a2, pl->a4, pl->wx, pl->wy, pl->ru, pl->rv}, li.w, li.h, li.pitch);
                     if (rc) return rc;
                 }
+                if (small) {       // coarsest levels: the whole solve and the flow update in one workgroup
+                    launch_pcg_solve_small(s, L, prm.cgiters, pl->tol);
+                } else {
                 for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182
                     e = ev_begin(pl, s, EV_PASS_A, pf);
                     launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
@@ -422,6 +428,7 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
                 e = ev_begin(pl, s, EV_UPD, pf);
                 launch_flow_update(s, L, prm.cgiters);      // ref .cu:1185-1195
                 ev_end(e, s);
+                }
                 if (pl->trace) {
                     int rc;
                     if ((rc = emit(pl, s, "dx2", k, gnc, l, {pl->xu, pl->xv}, li.w, li.h, li.pitch))) return rc;
