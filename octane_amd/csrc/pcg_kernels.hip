@@ -31,6 +31,22 @@ constexpr int kLInt = 4;            // interior starts 16-byte aligned
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
+// Streaming ("nt") variants for data with no reuse before it would be evicted anyway: they keep single-use
+// planes from displacing the planes pass A and pass B share (r, p) in the Infinity Cache.
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float *p)
+{
+    f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_nt(float *p, float4 v)
+{
+    f4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));
+}
+__device__ __forceinline__ float4 ld4_if(const float *p, bool nt) { return nt ? ld4_nt(p) : ld4(p); }
+__device__ __forceinline__ void st4_if(float *p, float4 v, bool nt) { if (nt) st4_nt(p, v); else st4(p, v); }
+
 // p_new = z + beta * p_old with z = M^-1 r  (ref .cu:1117/1138 then jVecPVec(p0,z0,p0,Bk) at :1146)
 // The preconditioner entry is re-derived from the diagonal here (pass A reads a1/a4 anyway for
 // A p) with one correctly rounded float division.  The reference rounds 1./M through double
@@ -91,11 +107,11 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
         if (rowok) {
             *(float4 *)ru = ld4(L.ru + o);
             *(float4 *)rv = ld4(L.rv + o);
-            *(float4 *)a1 = ld4(L.a1 + o);
-            *(float4 *)a4 = ld4(L.a4 + o);
-            *(float4 *)a2 = ld4(L.a2 + o);
-            *(float4 *)wxc = ld4(L.wx + o);
-            *(float4 *)wyc = ld4(L.wy + o);
+            *(float4 *)a1 = ld4_if(L.a1 + o, L.nt_hints & 16);
+            *(float4 *)a4 = ld4_if(L.a4 + o, L.nt_hints & 16);
+            *(float4 *)a2 = ld4_if(L.a2 + o, L.nt_hints & 8);
+            *(float4 *)wxc = ld4_if(L.wx + o, L.nt_hints & 32);
+            *(float4 *)wyc = ld4_if(L.wy + o, L.nt_hints & 32);
             if (y > 0) *(float4 *)wys = ld4(L.wy + o - pitch);
             if (x > 0) wxw = L.wx[o - 1];
             float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(256, 4) void k_pcg_pass_a_march(LevelPtrs L, int k,
 }
 
 struct BOperands {
-    float4 ru, rv, pu, pv, qu, qv, mu, mv, xu, xv;
+    float4 ru, rv, pu, pv, qu, qv, mu, mv, xu, xv, ou, ov;   // ou/ov: the previous iteration's p (deferred x update)
     size_t o;
     int x;
     bool valid;
@@ -518,7 +534,21 @@ struct BOperands {
 // Operand loads of one 256-group chunk of pass B.  None of them depends on alpha, so the first chunk's loads
 // are issued BEFORE the partials are folded and the next chunk's before the current one is computed: the
 // reduction's round trip and the arithmetic hide under memory latency instead of adding to it.
-__device__ __forceinline__ void pass_b_issue(const LevelPtrs &L, int k, bool first, const ItemRange &cr, int ci,
+// x handling of pass B(k).  Immediate mode: x += alpha_k p_k every iteration, as the reference does.  Deferred mode
+// (default): even iterations leave x alone; odd iterations apply the two pending updates in the reference's order,
+//   x <- alpha_k p_k + (alpha_{k-1} p_{k-1} + x),
+// reading p_{k-1} from the other half of the p ping-pong.  Same operations, same roundings, but x is read and
+// written every second iteration only (4 B/pixel/iteration less traffic).  A solve that ends on an even iteration
+// has one update pending; k_flow_update applies it.
+enum { XMODE_NOW_FIRST = 0, XMODE_NOW = 1, XMODE_SKIP = 2, XMODE_PAIR_FIRST = 3, XMODE_PAIR = 4 };
+__device__ __forceinline__ int pass_b_xmode(int defer, int k)
+{
+    if (!defer) return k == 0 ? XMODE_NOW_FIRST : XMODE_NOW;
+    if ((k & 1) == 0) return XMODE_SKIP;
+    return k == 1 ? XMODE_PAIR_FIRST : XMODE_PAIR;
+}
+
+__device__ __forceinline__ void pass_b_issue(const LevelPtrs &L, int k, int xmode, const ItemRange &cr, int ci,
                                              long ngroups, int gw, int pitch, BOperands &b)
 {
     b.valid = false;
@@ -532,16 +562,18 @@ __device__ __forceinline__ void pass_b_issue(const LevelPtrs &L, int k, bool fir
     b.valid = true;
     b.ru = ld4(L.ru + b.o); b.rv = ld4(L.rv + b.o);
     b.pu = ld4(L.pu[(k + 1) & 1] + b.o); b.pv = ld4(L.pv[(k + 1) & 1] + b.o);
-    b.qu = ld4(L.qu + b.o); b.qv = ld4(L.qv + b.o);
-    b.mu = ld4(L.mu + b.o); b.mv = ld4(L.mv + b.o);
-    if (!first) { b.xu = ld4(L.xu + b.o); b.xv = ld4(L.xv + b.o); }
+    b.qu = ld4_if(L.qu + b.o, L.nt_hints & 2); b.qv = ld4_if(L.qv + b.o, L.nt_hints & 2);
+    b.mu = ld4_if(L.mu + b.o, L.nt_hints & 4); b.mv = ld4_if(L.mv + b.o, L.nt_hints & 4);
+    if (xmode == XMODE_NOW || xmode == XMODE_PAIR) { b.xu = ld4_if(L.xu + b.o, L.nt_hints & 1); b.xv = ld4_if(L.xv + b.o, L.nt_hints & 1); }
     else { b.xu = make_float4(0, 0, 0, 0); b.xv = make_float4(0, 0, 0, 0); }
+    if (xmode == XMODE_PAIR_FIRST || xmode == XMODE_PAIR) { b.ou = ld4(L.pu[k & 1] + b.o); b.ov = ld4(L.pv[k & 1] + b.o); }
+    else { b.ou = make_float4(0, 0, 0, 0); b.ov = make_float4(0, 0, 0, 0); }
 }
 
 __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int nparts_a)
 {
     __shared__ double s_red[8];
-    const bool first = (k == 0);
+    const int xmode = pass_b_xmode(L.defer_x, k);
     const int w = L.w, h = L.h, pitch = L.pitch;
     const int gw = (w + 3) / 4;
     const long ngroups = (long)gw * h;
@@ -551,24 +583,31 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
     const int nchunks = (int)((ngroups + 255) / 256);
     const ItemRange cr = item_range(nchunks, L.xcd_bands != 0);
     BOperands cur, nxt;
-    pass_b_issue(L, k, first, cr, cr.first, ngroups, gw, pitch, cur);
+    pass_b_issue(L, k, xmode, cr, cr.first, ngroups, gw, pitch, cur);
 
     const PcgState st = L.st[(k + 1) & 1];
     if (st.stopped) return;
     const float pq = (float)fold_partials_256(L.part_pq, nparts_a, s_red);
     const float alpha = st.rz / pq;                        // ref .cu:1169
     const float nalpha = (float)(-1. * (double)alpha);     // ref .cu:1174
+    const float alpha_prev = (xmode >= XMODE_PAIR_FIRST) ? L.alpha[(k - 1) & 1] : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) L.alpha[k & 1] = alpha;
     double acc_rz = 0., acc_rr = 0.;
     for (int ci = cr.first; ci < cr.end; ci += cr.step) {
-        pass_b_issue(L, k, first, cr, ci + cr.step, ngroups, gw, pitch, nxt);
+        pass_b_issue(L, k, xmode, cr, ci + cr.step, ngroups, gw, pitch, nxt);
         if (cur.valid) {
-            float xu[4], xv[4], ru[4], rv[4], pu[4], pv[4], qu[4], qv[4], mu[4], mv[4];
+            float xu[4], xv[4], ru[4], rv[4], pu[4], pv[4], qu[4], qv[4], mu[4], mv[4], ou[4], ov[4];
+            *(float4 *)ou = cur.ou; *(float4 *)ov = cur.ov;
             *(float4 *)xu = cur.xu; *(float4 *)xv = cur.xv; *(float4 *)ru = cur.ru; *(float4 *)rv = cur.rv;
             *(float4 *)pu = cur.pu; *(float4 *)pv = cur.pv; *(float4 *)qu = cur.qu; *(float4 *)qv = cur.qv;
             *(float4 *)mu = cur.mu; *(float4 *)mv = cur.mv;
             float srz = 0.f, srr = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
+                if (xmode >= XMODE_PAIR_FIRST) {           // the previous iteration's update first
+                    xu[e] = alpha_prev * ou[e] + xu[e];
+                    xv[e] = alpha_prev * ov[e] + xv[e];
+                }
                 xu[e] = alpha * pu[e] + xu[e];             // jVecPVec(p0,x0,x0,alphak), ref .cu:1172
                 xv[e] = alpha * pv[e] + xv[e];
                 ru[e] = nalpha * qu[e] + ru[e];            // jVecPVec(dummyvec,bcu,rk,-alphak), ref .cu:1174
@@ -579,7 +618,9 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
                     srr += ru[e] * ru[e]; srr += rv[e] * rv[e];
                 }
             }
-            st4(L.xu + cur.o, *(float4 *)xu); st4(L.xv + cur.o, *(float4 *)xv);
+            if (xmode != XMODE_SKIP) {
+                st4_if(L.xu + cur.o, *(float4 *)xu, L.nt_hints & 1); st4_if(L.xv + cur.o, *(float4 *)xv, L.nt_hints & 1);
+            }
             st4(L.ru + cur.o, *(float4 *)ru); st4(L.rv + cur.o, *(float4 *)rv);
             acc_rz += (double)srz; acc_rr += (double)srr;
         }
@@ -596,14 +637,28 @@ __global__ __launch_bounds__(256) void k_flow_update(LevelPtrs L, int nlaunched)
 {
     const PcgState st = L.st[nlaunched & 1];
     if (blockIdx.x == 0 && threadIdx.x == 0) *L.iter_total += st.iters;
-    if (st.iters == 0) return;
+    const int n = st.iters;
+    if (n == 0) return;
+    // deferred-x mode: an odd number of executed iterations leaves alpha_{n-1} p_{n-1} pending
+    const bool pending = L.defer_x && (n & 1);
+    const float apend = pending ? L.alpha[(n - 1) & 1] : 0.f;
+    const float *__restrict__ ppu = L.pu[n & 1];
+    const float *__restrict__ ppv = L.pv[n & 1];
     const int w = L.w, h = L.h, pitch = L.pitch;
     const int gw = (w + 3) / 4;
     const long ngroups = (long)gw * h;
     for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
         const int y = (int)(g / gw), x = (int)(g - (long)y * gw) * 4;
         const size_t o = (size_t)y * pitch + x;
-        float4 u = ld4(L.u + o), v = ld4(L.v + o), dx = ld4(L.xu + o), dy = ld4(L.xv + o);
+        float4 u = ld4(L.u + o), v = ld4(L.v + o), dx, dy;
+        if (pending && n == 1) { dx = make_float4(0, 0, 0, 0); dy = dx; }
+        else { dx = ld4(L.xu + o); dy = ld4(L.xv + o); }
+        if (pending) {
+            const float4 pu = ld4(ppu + o), pv = ld4(ppv + o);
+            dx.x = apend * pu.x + dx.x; dx.y = apend * pu.y + dx.y; dx.z = apend * pu.z + dx.z; dx.w = apend * pu.w + dx.w;
+            dy.x = apend * pv.x + dy.x; dy.y = apend * pv.y + dy.y; dy.z = apend * pv.z + dy.z; dy.w = apend * pv.w + dy.w;
+            st4(L.xu + o, dx); st4(L.xv + o, dy);          // keep x complete for the debug tap
+        }
         u.x = u.x + dx.x; u.y = u.y + dx.y; u.z = u.z + dx.z; u.w = u.w + dx.w;
         v.x = v.x + dy.x; v.y = v.y + dy.y; v.z = v.z + dy.z; v.w = v.w + dy.w;
         st4(L.u + o, u); st4(L.v + o, v);

@@ -44,8 +44,11 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
                                                     // pass A(k) reads p[k&1] (halo too) and writes p[(k+1)&1]
     double *part_rz, *part_rr, *part_pq;
     PcgState *st;
+    float *alpha;                   // alpha of the last two iterations (pass B of iteration k writes alpha[k&1])
+    int defer_x;                    // fold x += alpha p of two iterations into every second pass B
     long long *iter_total;
     int reverse_b;                  // pass B walks the frame backwards (Infinity-Cache reuse)
+    int nt_hints;                   // bit mask of streaming-load/store hints (tuning)
     int xcd_bands;                  // give each XCD (blockIdx % 8) one contiguous band of the frame
 };
 

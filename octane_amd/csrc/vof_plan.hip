@@ -60,6 +60,7 @@ struct octane_vof_plan {
     float *d_taps = nullptr;
     double *d_parts = nullptr;     // 3 * kMaxParts
     PcgState *d_state = nullptr;   // 2
+    float *d_alpha = nullptr;      // 2
     long long *d_iters = nullptr;
     long long *h_iters = nullptr;  // pinned
     hipStream_t own_stream = nullptr;
@@ -74,6 +75,8 @@ struct octane_vof_plan {
     int reverse_b = 1;
     int xcd_bands = 0;
     int use_small = 1;
+    int defer_x = 1;
+    int nt_hints = 15;   // x, q, mu/mv in pass B and a2 in pass A are single-use: streaming loads/stores
 };
 
 extern "C" const char *octane_last_error(void) { return g_last_error.c_str(); }
@@ -123,6 +126,7 @@ extern "C" int octane_vof_plan_destroy(octane_vof_plan *pl)
     if (pl->d_taps) (void)hipFree(pl->d_taps);
     if (pl->d_parts) (void)hipFree(pl->d_parts);
     if (pl->d_state) (void)hipFree(pl->d_state);
+    if (pl->d_alpha) (void)hipFree(pl->d_alpha);
     if (pl->d_iters) (void)hipFree(pl->d_iters);
     if (pl->h_iters) (void)hipHostFree(pl->h_iters);
     if (pl->own_stream) (void)hipStreamDestroy(pl->own_stream);
@@ -154,6 +158,8 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     if (const char *e = getenv("OCTANE_TUNE_PASS_A")) set_pass_a_variant(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_XCD")) pl->xcd_bands = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_SMALL")) pl->use_small = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_NT")) pl->nt_hints = atoi(e);
+    if (const char *e = getenv("OCTANE_TUNE_DEFER_X")) pl->defer_x = atoi(e) != 0;
     set_grid_multiple(pl->xcd_bands ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
 
@@ -223,6 +229,8 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
             hipMemcpy(pl->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMalloc((void **)&pl->d_parts, 3 * kMaxParts * sizeof(double)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         if (hipMalloc((void **)&pl->d_state, 2 * sizeof(PcgState)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&pl->d_alpha, 2 * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMemset(pl->d_alpha, 0, 2 * sizeof(float)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMalloc((void **)&pl->d_iters, sizeof(long long)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         if (hipHostMalloc((void **)&pl->h_iters, sizeof(long long)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         *pl->h_iters = 0;
@@ -389,9 +397,10 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         L.pu[0] = pl->pu[0]; L.pu[1] = pl->pu[1]; L.pv[0] = pl->pv[0]; L.pv[1] = pl->pv[1];
         L.qu = pl->qu; L.qv = pl->qv; L.xu = pl->xu; L.xv = pl->xv;
         L.part_rz = pl->d_parts; L.part_rr = pl->d_parts + kMaxParts; L.part_pq = pl->d_parts + 2 * kMaxParts;
-        L.st = pl->d_state; L.iter_total = pl->d_iters;
+        L.st = pl->d_state; L.iter_total = pl->d_iters; L.alpha = pl->d_alpha; L.defer_x = pl->defer_x;
         L.reverse_b = pl->reverse_b;
         L.xcd_bands = pl->xcd_bands;
+        L.nt_hints = pl->nt_hints;
 
         const int g_asm = assemble_grid_size(li.w, li.h);
         const int g_a = pcg_grid_size(li.w, li.h);

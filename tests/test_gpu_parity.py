@@ -173,6 +173,27 @@ def test_runs_are_bitwise_reproducible(capi):
     assert np.array_equal(u1, u3) and np.array_equal(v1, v3)
 
 
+@pytest.mark.parametrize("cgiters", [1, 2, 7, 30])
+def test_deferred_x_update_is_bitwise_identical(capi, cgiters):
+    """Pass B applies x += alpha p for two iterations at once (every second launch) in the reference's order of
+    operations; the result must equal the every-iteration form bit for bit, for even and odd iteration counts
+    (an odd count leaves one update pending for the flow-update kernel)."""
+    import os
+    nx, ny = 310, 240           # finest level above the single-workgroup solver's size
+    a, b = synth.lattice_scene(nx, ny, seed=17)
+    prm = capi.FlowParams(kiters=2, liters=1, cgiters=cgiters)
+    outs = []
+    for mode in ("0", "1"):
+        os.environ["OCTANE_TUNE_DEFER_X"] = mode
+        try:
+            pl = capi.Plan(nx, ny, 1, prm)
+            outs.append(pl.run_host(a, b))
+            pl.close()
+        finally:
+            del os.environ["OCTANE_TUNE_DEFER_X"]
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_level_too_small_is_an_error(capi):
     a = np.zeros((1, 20, 20), np.float32)
     with pytest.raises(capi.OctaneError) as e:
