@@ -854,17 +854,18 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_solve_small(LevelPtrs L, 
 
 bool pcg_small_applicable(int w, int h) { return (long)w * h <= kSmallMaxPix; }
 
+// dynamic LDS above 64 KiB has to be allowed per kernel; done once per plan, outside any stream capture
+void pcg_small_configure()
+{
+    (void)hipFuncSetAttribute((const void *)k_pcg_solve_small<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kSmallMaxPix * 4);
+    (void)hipFuncSetAttribute((const void *)k_pcg_solve_small<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kSmallMaxPix * 4);
+    (void)hipFuncSetAttribute((const void *)k_pcg_solve_small<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kSmallMaxPix * 4);
+}
+
 void launch_pcg_solve_small(hipStream_t s, const LevelPtrs &L, int maxit, float tol)
 {
     const size_t lds = (size_t)6 * L.w * L.h * sizeof(float);       // <= 147456 B of the CU's 160 KiB
     const int per = (L.w * L.h + kSmallThreads - 1) / kSmallThreads;
-    static bool configured = false;
-    if (!configured) {    // dynamic LDS above 64 KiB has to be allowed per kernel
-        (void)hipFuncSetAttribute((const void *)k_pcg_solve_small<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kSmallMaxPix * 4);
-        (void)hipFuncSetAttribute((const void *)k_pcg_solve_small<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kSmallMaxPix * 4);
-        (void)hipFuncSetAttribute((const void *)k_pcg_solve_small<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * kSmallMaxPix * 4);
-        configured = true;
-    }
     if (per <= 3) hipLaunchKernelGGL(k_pcg_solve_small<3>, dim3(1), dim3(kSmallThreads), lds, s, L, maxit, tol);
     else if (per <= 6) hipLaunchKernelGGL(k_pcg_solve_small<6>, dim3(1), dim3(kSmallThreads), lds, s, L, maxit, tol);
     else hipLaunchKernelGGL(k_pcg_solve_small<12>, dim3(1), dim3(kSmallThreads), lds, s, L, maxit, tol);

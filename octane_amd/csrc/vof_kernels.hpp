@@ -78,6 +78,7 @@ void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev
 void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid);
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int niter_launched);
 bool pcg_small_applicable(int w, int h);
+void pcg_small_configure();
 void launch_pcg_solve_small(hipStream_t s, const LevelPtrs &L, int maxit, float tol);   // whole solve + flow update, one workgroup
 
 struct NavArgs {

@@ -76,6 +76,10 @@ struct octane_vof_plan {
     int xcd_bands = 0;
     int use_small = 1;
     int defer_x = 1;
+    int use_graph = 0;   // OCTANE_TUNE_GRAPH=1: replay the pyramid as one hipGraph (measured: no throughput gain,
+                         // the host already runs ahead of the GPU; useful only when calls are latency-bound)
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_cur = 0;
     int nt_hints = 15;   // x, q, mu/mv in pass B and a2 in pass A are single-use: streaming loads/stores
 };
 
@@ -122,6 +126,7 @@ extern "C" int octane_vof_plan_destroy(octane_vof_plan *pl)
     if (pl->ev_t1) (void)hipEventDestroy(pl->ev_t1);
     if (pl->ev_s0) (void)hipEventDestroy(pl->ev_s0);
     if (pl->ev_s1) (void)hipEventDestroy(pl->ev_s1);
+    if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
     if (pl->arena) (void)hipFree(pl->arena);
     if (pl->d_taps) (void)hipFree(pl->d_taps);
     if (pl->d_parts) (void)hipFree(pl->d_parts);
@@ -160,6 +165,8 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     if (const char *e = getenv("OCTANE_TUNE_SMALL")) pl->use_small = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_NT")) pl->nt_hints = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_DEFER_X")) pl->defer_x = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_GRAPH")) pl->use_graph = atoi(e) != 0;
+    pcg_small_configure();
     set_grid_multiple(pl->xcd_bands ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
 
@@ -521,8 +528,40 @@ extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const
         launch_copy2d(s, u, nx, pl->uh, p0, nx, ny);
         launch_copy2d(s, v, nx, pl->vh, p0, nx, ny);
     }
-    int cur = run_on_stream(pl, s);
-    if (cur < 0) return cur;
+    // The launch sequence of a pyramid is fixed for a plan (every pointer and size is the plan's own), so it is
+    // captured once into a hipGraph and replayed: the ~4500 launches of a pyramid then cost a kernel boundary
+    // each (~1.5 us) instead of a host launch (~3.5 us), which is what the coarse levels' 5-8 us kernels were
+    // waiting on.  Debug taps and per-kernel profiling need host work between launches and use the eager path.
+    int cur;
+    if (pl->use_graph && !pl->trace && !pl->profiling) {
+        if (!pl->graph_exec) {
+            hipGraph_t graph = nullptr;
+            // captured on the plan's private stream (the caller's may be the null stream, which cannot
+            // capture); the instantiated graph is then launched into whatever stream the caller names
+            hipStream_t cs = pl->own_stream;
+            HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            const int c = run_on_stream(pl, cs);
+            hipError_t e = hipStreamEndCapture(cs, &graph);
+            if (c < 0 || e != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                if (c >= 0) g_last_error = std::string("hipStreamEndCapture: ") + hipGetErrorString(e);
+                return c < 0 ? c : OCTANE_E_HIP;
+            }
+            e = hipGraphInstantiate(&pl->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) {
+                pl->graph_exec = nullptr;
+                g_last_error = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+                return OCTANE_E_HIP;
+            }
+            pl->graph_cur = c;
+        }
+        HIP_TRY(hipGraphLaunch(pl->graph_exec, s));
+        cur = pl->graph_cur;
+    } else {
+        cur = run_on_stream(pl, s);
+        if (cur < 0) return cur;
+    }
     if (mem == OCTANE_MEM_HOST) {   // ref .cu:1432-1438
         HIP_TRY(hipMemcpy2DAsync(u, dense_row, pl->U[cur], pitched_row, dense_row, ny, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpy2DAsync(v, dense_row, pl->V[cur], pitched_row, dense_row, ny, hipMemcpyDeviceToHost, s));
