@@ -211,6 +211,167 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
     if (tid == 0) L.part_pq[blockIdx.x] = tot;
 }
 
+// Tall-tile form of the LDS-tiled pass A (OCTANE_TUNE_PASS_A=4): the same kernel with R rows per thread, i.e. a
+// 128 x 8R tile per workgroup iteration: the two halo rows are amortised over 8R rows and there are R times fewer
+// barriers per pixel.
+template <int R>
+__global__ __launch_bounds__(256) void k_pcg_pass_a_tall(LevelPtrs L, int k, int nparts_prev, float tol)
+{
+    constexpr int TY = kTileY * R;
+    __shared__ __attribute__((aligned(16))) float s_pu[(TY + 2) * kLRow];
+    __shared__ __attribute__((aligned(16))) float s_pv[(TY + 2) * kLRow];
+    __shared__ double s_red[8];
+    const int tid = threadIdx.x;
+
+    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
+    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
+    const PcgState prev = L.st[k & 1];
+    const bool active = (prev.stopped == 0) && (rr > tol);          // ref .cu:1131
+    if (!active) {
+        if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
+        return;
+    }
+    const bool first = (k == 0);
+    const float beta = first ? 0.f : rz_new / prev.rz;
+    if (blockIdx.x == 0 && tid == 0) {
+        PcgState n; n.rz = rz_new; n.stopped = 0; n.iters = prev.iters + 1; n.pad = 0;
+        L.st[(k + 1) & 1] = n;
+    }
+
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int tiles_x = (w + kTileX - 1) / kTileX, tiles_y = (h + TY - 1) / TY;
+    const int ntiles = tiles_x * tiles_y;
+    const int lx = tid & 31, ly = tid >> 5;
+    double acc = 0.;
+    const float *__restrict__ pin_u = L.pu[k & 1];
+    const float *__restrict__ pin_v = L.pv[k & 1];
+    float *__restrict__ pout_u = L.pu[(k + 1) & 1];
+    float *__restrict__ pout_v = L.pv[(k + 1) & 1];
+
+    const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
+    for (int t = tr.first; t < tr.end; t += tr.step) {
+        const int tx0 = (t % tiles_x) * kTileX, ty0 = (t / tiles_x) * TY;
+        const int x = tx0 + lx * 4;
+        float a1[R][4], a4[R][4], a2[R][4], wxc[R][4], wyc[R][4], wys[R][4], npu[R][4], npv[R][4];
+        float wxw[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int y = ty0 + ly + kTileY * q;
+            const bool rowok = (y < h) && (x < w);
+            const size_t o = (size_t)y * pitch + x;
+            float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0};
+            wxw[q] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { a1[q][e] = 1.f; a4[q][e] = 1.f; a2[q][e] = 0.f; wxc[q][e] = 0.f; wyc[q][e] = 0.f; wys[q][e] = 0.f; npu[q][e] = 0.f; npv[q][e] = 0.f; }
+            if (rowok) {
+                *(float4 *)ru = ld4(L.ru + o);
+                *(float4 *)rv = ld4(L.rv + o);
+                *(float4 *)a1[q] = ld4(L.a1 + o);
+                *(float4 *)a4[q] = ld4(L.a4 + o);
+                *(float4 *)a2[q] = ld4_if(L.a2 + o, L.nt_hints & 8);
+                *(float4 *)wxc[q] = ld4(L.wx + o);
+                *(float4 *)wyc[q] = ld4(L.wy + o);
+                if (y > 0) *(float4 *)wys[q] = ld4(L.wy + o - pitch);
+                if (x > 0) wxw[q] = L.wx[o - 1];
+                float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
+                if (!first) { *(float4 *)pu = ld4(pin_u + o); *(float4 *)pv = ld4(pin_v + o); }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool ok = (x + e) < w;
+                    npu[q][e] = ok ? direction(ru[e], pu[e], a1[q][e], beta, first) : 0.f;
+                    npv[q][e] = ok ? direction(rv[e], pv[e], a4[q][e], beta, first) : 0.f;
+                }
+            }
+            st4(&s_pu[(ly + kTileY * q + 1) * kLRow + kLInt + lx * 4], *(float4 *)npu[q]);
+            st4(&s_pv[(ly + kTileY * q + 1) * kLRow + kLInt + lx * 4], *(float4 *)npv[q]);
+        }
+        // one-pixel halo of p_new, recomputed from r, p_old and the diagonal
+        if (tid < 64) {                                  // rows above and below the tile
+            const int hy = (tid < 32) ? ty0 - 1 : ty0 + TY;
+            const int hx = tx0 + (tid & 31) * 4;
+            const int lrow = (tid < 32) ? 0 : TY + 1;
+            float hu[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0};
+            if (hy >= 0 && hy < h && hx < w) {
+                const size_t ho = (size_t)hy * pitch + hx;
+                float r0[4], r1[4], d0[4], d1[4], q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
+                *(float4 *)r0 = ld4(L.ru + ho); *(float4 *)r1 = ld4(L.rv + ho);
+                *(float4 *)d0 = ld4(L.a1 + ho); *(float4 *)d1 = ld4(L.a4 + ho);
+                if (!first) { *(float4 *)q0 = ld4(pin_u + ho); *(float4 *)q1 = ld4(pin_v + ho); }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool ok = (hx + e) < w;
+                    hu[e] = ok ? direction(r0[e], q0[e], d0[e], beta, first) : 0.f;
+                    hv[e] = ok ? direction(r1[e], q1[e], d1[e], beta, first) : 0.f;
+                }
+            }
+            st4(&s_pu[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hu);
+            st4(&s_pv[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hv);
+        } else if (tid < 64 + 2 * TY) {                  // columns left and right of the tile
+            const int side = (tid - 64) / TY, row = (tid - 64) % TY;
+            const int hy = ty0 + row;
+            const int hx = side ? tx0 + kTileX : tx0 - 1;
+            float hu = 0.f, hv = 0.f;
+            if (hy < h && hx >= 0 && hx < w) {
+                const size_t ho = (size_t)hy * pitch + hx;
+                const float q0 = first ? 0.f : pin_u[ho], q1 = first ? 0.f : pin_v[ho];
+                hu = direction(L.ru[ho], q0, L.a1[ho], beta, first);
+                hv = direction(L.rv[ho], q1, L.a4[ho], beta, first);
+            }
+            const int lcol = side ? kLInt + kTileX : kLInt - 1;
+            s_pu[(row + 1) * kLRow + lcol] = hu;
+            s_pv[(row + 1) * kLRow + lcol] = hv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int y = ty0 + ly + kTileY * q;
+            const int lrow = ly + kTileY * q;
+            if ((y < h) && (x < w)) {
+                float su[4], sv[4], nu[4], nv[4];
+                *(float4 *)su = ld4(&s_pu[lrow * kLRow + kLInt + lx * 4]);
+                *(float4 *)sv = ld4(&s_pv[lrow * kLRow + kLInt + lx * 4]);
+                *(float4 *)nu = ld4(&s_pu[(lrow + 2) * kLRow + kLInt + lx * 4]);
+                *(float4 *)nv = ld4(&s_pv[(lrow + 2) * kLRow + kLInt + lx * 4]);
+                const float uwest = s_pu[(lrow + 1) * kLRow + kLInt + lx * 4 - 1];
+                const float vwest = s_pv[(lrow + 1) * kLRow + kLInt + lx * 4 - 1];
+                const float ueast = s_pu[(lrow + 1) * kLRow + kLInt + lx * 4 + 4];
+                const float veast = s_pv[(lrow + 1) * kLRow + kLInt + lx * 4 + 4];
+                float qu[4], qv[4];
+                float rowdot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = x + e;
+                    const float pwu = (e == 0) ? uwest : npu[q][(e + 3) & 3], pwv = (e == 0) ? vwest : npv[q][(e + 3) & 3];
+                    const float peu = (e == 3) ? ueast : npu[q][(e + 1) & 3], pev = (e == 3) ? veast : npv[q][(e + 1) & 3];
+                    const float a5 = (e == 0) ? wxw[q] : wxc[q][(e + 3) & 3];
+                    const float wS = (y == h - 1) ? wys[q][e] + wyc[q][e] : wys[q][e];
+                    const float wW = (i == w - 1) ? a5 + wxc[q][e] : a5;
+                    const float wE = (i == 0) ? wxc[q][e] + wxc[q][e] : wxc[q][e];
+                    const float wN = (y == 0) ? wyc[q][e] + wyc[q][e] : wyc[q][e];
+                    float sumu = 0.f, sumv = 0.f;
+                    if (y > 0) { sumu += wS * su[e]; sumv += wS * sv[e]; }
+                    if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
+                    sumu += a1[q][e] * npu[q][e]; sumv += a2[q][e] * npu[q][e];
+                    sumu += a2[q][e] * npv[q][e]; sumv += a4[q][e] * npv[q][e];
+                    if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
+                    if (y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
+                    qu[e] = sumu; qv[e] = sumv;
+                    if (i < w) { rowdot += npu[q][e] * sumu; rowdot += npv[q][e] * sumv; }
+                }
+                const size_t o = (size_t)y * pitch + x;
+                st4(pout_u + o, *(float4 *)npu[q]);
+                st4(pout_v + o, *(float4 *)npv[q]);
+                st4(L.qu + o, *(float4 *)qu);
+                st4(L.qv + o, *(float4 *)qv);
+                acc += (double)rowdot;
+            }
+        }
+        __syncthreads();
+    }
+    const double tot = block_sum_256(acc, s_red);
+    if (tid == 0) L.part_pq[blockIdx.x] = tot;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pass A, row-rolling form (experimental: OCTANE_TUNE_PASS_A=1; measured slower than the tiled form).
 //
@@ -524,6 +685,190 @@ __global__ __launch_bounds__(256, 4) void k_pcg_pass_a_march(LevelPtrs L, int k,
     if (tid == 0) L.part_pq[blockIdx.x] = tot;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pass A, marching form with an LDS row ring (OCTANE_TUNE_PASS_A=3).
+//
+// Same decomposition as k_pcg_pass_a_march (1024-pixel strips, contiguous runs of rows, equal shares), but
+// the rolling window of p_new rows lives in a 4-slot LDS ring instead of registers: row y+1 is computed
+// and written to the ring one step before q(y) needs it, all horizontal and vertical neighbours are LDS
+// reads, and the operand loads of row y+2 are in flight while q(y) is evaluated.  One barrier per row.
+// Nothing is fetched twice inside a run; re-fetch is 2 pixels per row (strip ends) + 2 reduced rows per
+// run.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRingRow = kMarchW + 8;     // [3 pad][west px][1024 interior][east px][3 pad]
+
+struct RawRow { float4 ru, rv, pu, pv, a1, a4; float s[6]; };   // s: the strip-end pixel's r,p,a (2 lanes only)
+
+__global__ __launch_bounds__(256, 3) void k_pcg_pass_a_ring(LevelPtrs L, int k, int nparts_prev, float tol)
+{
+    __shared__ double s_red[8];
+    __shared__ __attribute__((aligned(16))) float s_ru[4][kRingRow];
+    __shared__ __attribute__((aligned(16))) float s_rv[4][kRingRow];
+    __shared__ float s_wxe[2][4];        // [row parity][wave]: wx of the wave's last pixel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
+    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
+    const PcgState prev = L.st[k & 1];
+    const bool active = (prev.stopped == 0) && (rr > tol);          // ref .cu:1131
+    if (!active) {
+        if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
+        return;
+    }
+    const bool first = (k == 0);
+    const float beta = first ? 0.f : rz_new / prev.rz;
+    if (blockIdx.x == 0 && tid == 0) {
+        PcgState n; n.rz = rz_new; n.stopped = 0; n.iters = prev.iters + 1; n.pad = 0;
+        L.st[(k + 1) & 1] = n;
+    }
+
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int strips = (w + kMarchW - 1) / kMarchW;
+    const long total_rows = (long)strips * h;
+    const float *__restrict__ pin_u = L.pu[k & 1];
+    const float *__restrict__ pin_v = L.pv[k & 1];
+    float *__restrict__ pout_u = L.pu[(k + 1) & 1];
+    float *__restrict__ pout_v = L.pv[(k + 1) & 1];
+    double acc = 0.;
+
+    long vr = total_rows * blockIdx.x / gridDim.x;
+    const long vr_end = total_rows * (blockIdx.x + 1) / gridDim.x;
+    while (vr < vr_end) {
+        const int sidx = (int)(vr / h);
+        const int y0 = (int)(vr - (long)sidx * h);
+        const int y1 = (int)min((long)h, y0 + (vr_end - vr));
+        vr += y1 - y0;
+        const int x0 = sidx * kMarchW;
+        const int x = x0 + tid * 4;
+        const bool colok = x < w;
+        const bool west_side = (tid == 0) && (x0 > 0);
+        const bool east_side = (tid == 255) && (x0 + kMarchW < w);
+        const bool side = west_side || east_side;
+        const int xs = west_side ? x0 - 1 : x0 + kMarchW;
+
+        // issue the operand loads a row needs for p_new
+        auto issue = [&](int yy, RawRow &r) {
+            const size_t o = (size_t)yy * pitch + x;
+            if (colok) {
+                r.ru = ld4(L.ru + o); r.rv = ld4(L.rv + o); r.a1 = ld4(L.a1 + o); r.a4 = ld4(L.a4 + o);
+                if (!first) { r.pu = ld4(pin_u + o); r.pv = ld4(pin_v + o); }
+            }
+            if (side) {
+                const size_t so = (size_t)yy * pitch + xs;
+                r.s[0] = L.ru[so]; r.s[1] = L.rv[so]; r.s[2] = L.a1[so]; r.s[3] = L.a4[so];
+                if (!first) { r.s[4] = pin_u[so]; r.s[5] = pin_v[so]; }
+            }
+        };
+        // turn them into p_new and put the row into its ring slot
+        auto deposit = [&](int yy, const RawRow &r) {
+            const int slot = yy & 3;
+            float ru[4], rv[4], pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0}, a1[4], a4[4], du[4], dv[4];
+            *(float4 *)ru = r.ru; *(float4 *)rv = r.rv; *(float4 *)a1 = r.a1; *(float4 *)a4 = r.a4;
+            if (!first) { *(float4 *)pu = r.pu; *(float4 *)pv = r.pv; }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool ok = colok && (x + e) < w;
+                du[e] = ok ? direction(ru[e], pu[e], a1[e], beta, first) : 0.f;
+                dv[e] = ok ? direction(rv[e], pv[e], a4[e], beta, first) : 0.f;
+            }
+            st4(&s_ru[slot][4 + tid * 4], *(float4 *)du);
+            st4(&s_rv[slot][4 + tid * 4], *(float4 *)dv);
+            if (side) {
+                const float su = direction(r.s[0], first ? 0.f : r.s[4], r.s[2], beta, first);
+                const float sv = direction(r.s[1], first ? 0.f : r.s[5], r.s[3], beta, first);
+                s_ru[slot][west_side ? 3 : 4 + kMarchW] = su;
+                s_rv[slot][west_side ? 3 : 4 + kMarchW] = sv;
+            }
+        };
+
+        RawRow raw;
+        float a1c[4] = {1, 1, 1, 1}, a4c[4] = {1, 1, 1, 1}, a2c[4] = {0, 0, 0, 0}, wxc[4] = {0, 0, 0, 0}, wyc[4] = {0, 0, 0, 0};
+        float wym[4] = {0, 0, 0, 0};
+        float4 a2n = make_float4(0, 0, 0, 0), wxn = a2n, wyn = a2n;
+        float wx_side_c = 0.f, wx_side_n = 0.f;
+
+        __syncthreads();                             // a previous run may still be reading the ring
+        if (y0 > 0) {
+            issue(y0 - 1, raw);
+            if (colok) *(float4 *)wym = ld4(L.wy + (size_t)(y0 - 1) * pitch + x);
+            deposit(y0 - 1, raw);
+        }
+        {
+            const size_t oc = (size_t)y0 * pitch + x;
+            issue(y0, raw);
+            if (colok) { *(float4 *)a2c = ld4_if(L.a2 + oc, L.nt_hints & 8); *(float4 *)wxc = ld4(L.wx + oc); *(float4 *)wyc = ld4(L.wy + oc); }
+            if (west_side) wx_side_c = L.wx[oc - 1];
+            deposit(y0, raw);
+            *(float4 *)a1c = raw.a1; *(float4 *)a4c = raw.a4;
+            if (lane == 63) s_wxe[y0 & 1][wave] = wxc[3];
+        }
+        if (y0 + 1 < h) issue(y0 + 1, raw);
+        for (int y = y0; y < y1; ++y) {
+            const bool have_next = (y + 1 < y1);
+            float4 a1n = make_float4(1, 1, 1, 1), a4n = a1n;
+            if (y + 1 < h) {
+                deposit(y + 1, raw);                 // waits for the loads issued one step ago
+                a1n = raw.a1; a4n = raw.a4;
+            }
+            if (have_next) {
+                const size_t on = (size_t)(y + 1) * pitch + x;
+                if (colok) { a2n = ld4_if(L.a2 + on, L.nt_hints & 8); wxn = ld4(L.wx + on); wyn = ld4(L.wy + on); }
+                if (west_side) wx_side_n = L.wx[on - 1];
+                if (y + 2 < h) issue(y + 2, raw);    // in flight while q(y) is evaluated
+            }
+            __syncthreads();
+            const int sm = (y - 1) & 3, sc = y & 3, sn = (y + 1) & 3;
+            float wxw = __shfl_up(wxc[3], 1, 64);
+            if (lane == 0) wxw = (wave > 0) ? s_wxe[y & 1][wave - 1] : wx_side_c;
+            if (colok) {
+                float pmu[4], pmv[4], pcu[4], pcv[4], pnu[4], pnv[4];
+                *(float4 *)pmu = ld4(&s_ru[sm][4 + tid * 4]); *(float4 *)pmv = ld4(&s_rv[sm][4 + tid * 4]);
+                *(float4 *)pcu = ld4(&s_ru[sc][4 + tid * 4]); *(float4 *)pcv = ld4(&s_rv[sc][4 + tid * 4]);
+                *(float4 *)pnu = ld4(&s_ru[sn][4 + tid * 4]); *(float4 *)pnv = ld4(&s_rv[sn][4 + tid * 4]);
+                const float uwest = s_ru[sc][3 + tid * 4], vwest = s_rv[sc][3 + tid * 4];
+                const float ueast = s_ru[sc][8 + tid * 4], veast = s_rv[sc][8 + tid * 4];
+                float qu[4], qv[4];
+                float rowdot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = x + e;
+                    const float pwu = (e == 0) ? uwest : pcu[(e + 3) & 3], pwv = (e == 0) ? vwest : pcv[(e + 3) & 3];
+                    const float peu = (e == 3) ? ueast : pcu[(e + 1) & 3], pev = (e == 3) ? veast : pcv[(e + 1) & 3];
+                    const float a5 = (e == 0) ? wxw : wxc[(e + 3) & 3];
+                    const float wS = (y == h - 1) ? wym[e] + wyc[e] : wym[e];
+                    const float wW = (i == w - 1) ? a5 + wxc[e] : a5;
+                    const float wE = (i == 0) ? wxc[e] + wxc[e] : wxc[e];
+                    const float wN = (y == 0) ? wyc[e] + wyc[e] : wyc[e];
+                    float sumu = 0.f, sumv = 0.f;
+                    if (y > 0) { sumu += wS * pmu[e]; sumv += wS * pmv[e]; }
+                    if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
+                    sumu += a1c[e] * pcu[e]; sumv += a2c[e] * pcu[e];
+                    sumu += a2c[e] * pcv[e]; sumv += a4c[e] * pcv[e];
+                    if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
+                    if (y < h - 1) { sumu += wN * pnu[e]; sumv += wN * pnv[e]; }
+                    qu[e] = sumu; qv[e] = sumv;
+                    if (i < w) { rowdot += pcu[e] * sumu; rowdot += pcv[e] * sumv; }
+                }
+                const size_t o = (size_t)y * pitch + x;
+                st4(pout_u + o, *(float4 *)pcu);
+                st4(pout_v + o, *(float4 *)pcv);
+                st4(L.qu + o, *(float4 *)qu);
+                st4(L.qv + o, *(float4 *)qv);
+                acc += (double)rowdot;
+            }
+            // roll to the next row
+#pragma unroll
+            for (int e = 0; e < 4; e++) wym[e] = wyc[e];
+            *(float4 *)a1c = a1n; *(float4 *)a4c = a4n;
+            *(float4 *)a2c = a2n; *(float4 *)wxc = wxn; *(float4 *)wyc = wyn;
+            wx_side_c = wx_side_n;
+            if (have_next && lane == 63) s_wxe[(y + 1) & 1][wave] = wxc[3];
+        }
+    }
+    const double tot = block_sum_256(acc, s_red);
+    if (tid == 0) L.part_pq[blockIdx.x] = tot;
+}
+
 struct BOperands {
     float4 ru, rv, pu, pv, qu, qv, mu, mv, xu, xv, ou, ov;   // ou/ov: the previous iteration's p (deferred x update)
     size_t o;
@@ -686,17 +1031,26 @@ static int pass_b_grid_size(int w, int h)
     return g;
 }
 
-static int g_pass_a_variant = 0;   // 0 = LDS-tiled (default), 1 = row-rolling (experimental, slower so far)
+static int g_pass_a_variant = 4;   // 4 = LDS-tiled 128x16 (default), 0 = 128x8, 5 = 128x32, 1/2/3 = experimental marching forms
 void set_pass_a_variant(int v) { g_pass_a_variant = v; }
 
 int pcg_grid_size(int w, int h)
 {
     if (g_pass_a_variant == 0) return pcg_tiled_grid_size(w, h);
-    if (g_pass_a_variant == 2) {   // marching: at least 8 rows per workgroup, at most 1024 workgroups (4 per CU resident)
+    if (g_pass_a_variant == 4 || g_pass_a_variant == 5) {
+        const int ty = kTileY * (g_pass_a_variant == 4 ? 2 : 4);
+        const long cap = (g_pass_a_variant == 4) ? 768 : 512;    // resident workgroups at 148 / 236 VGPRs
+        const long items = (long)((w + kTileX - 1) / kTileX) * ((h + ty - 1) / ty);
+        if (items <= cap) return (int)items;
+        const long rounds = (items + cap - 1) / cap;
+        return (int)((items + rounds - 1) / rounds);
+    }
+    if (g_pass_a_variant == 2 || g_pass_a_variant == 3) {   // marching: at least 8 rows per workgroup, at most 1024 workgroups (4 per CU resident)
         long rows = (long)((w + kMarchW - 1) / kMarchW) * h;
         long g = rows / 8;
         if (g < 1) g = 1;
-        return (int)(g > 1024 ? 1024 : g);
+        const long cap = (g_pass_a_variant == 3) ? 768 : 1024;   // resident workgroups: 3 resp. 4 per CU
+        return (int)(g > cap ? cap : g);
     }
     long items = (long)((w + kStripW - 1) / kStripW) * ((h + kSegRows - 1) / kSegRows);
     return balanced_grid((items + 3) / 4);
@@ -708,6 +1062,12 @@ void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev
         hipLaunchKernelGGL(k_pcg_pass_a, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
     else if (g_pass_a_variant == 2)
         hipLaunchKernelGGL(k_pcg_pass_a_march, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    else if (g_pass_a_variant == 4)
+        hipLaunchKernelGGL(k_pcg_pass_a_tall<2>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    else if (g_pass_a_variant == 5)
+        hipLaunchKernelGGL(k_pcg_pass_a_tall<4>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    else if (g_pass_a_variant == 3)
+        hipLaunchKernelGGL(k_pcg_pass_a_ring, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
     else
         hipLaunchKernelGGL(k_pcg_pass_a_rows, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
 }

@@ -29,16 +29,20 @@ def _check(capi, oracle, a, b, prm_kwargs, u0=None, v0=None, bar=INVESTIGATE):
     P = oracle.FlowParams(**prm_kwargs)
     uo, vo, its_o = oracle.flow(a, b, P, u0=u0, v0=v0, dot_threads=g)
     uf, vf, _ = oracle.flow(a, b, P, u0=u0, v0=v0, flavour="fma", dot_threads=g)
-    bar = max(bar, 2.0 * rel_l2(uf, vf, uo, vo))
     nc, ny, nx = (1,) + a.shape if a.ndim == 2 else a.shape
+    floor = rel_l2(uf, vf, uo, vo)
+    us = vs = None
+    if nx * ny <= 100_000:       # the reference's own spread also includes its two dot-product schedules
+        us, vs, _ = oracle.flow(a, b, P, u0=u0, v0=v0)
+        floor = max(floor, rel_l2(us, vs, uo, vo))
+    bar = max(bar, 2.0 * floor)
     pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm_kwargs))
     ug, vg = pl.run_host(a, b, u0, v0)
     its_g = pl.last_iterations()
     pl.close()
     assert np.isfinite(ug).all() and np.isfinite(vg).all()
     d = rel_l2(ug, vg, uo, vo)
-    if d >= bar and nx * ny <= 100_000:
-        us, vs, _ = oracle.flow(a, b, P, u0=u0, v0=v0)          # one-thread schedule
+    if us is not None:
         d = min(d, rel_l2(ug, vg, us, vs))
     assert d < bar, f"relative L2 {d:.3e} vs oracle (bar {bar:.1e})"
     return d, its_o, its_g

@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 
-def pmc_section(d, size, kiters, per_level):
+def pmc_section(d, size, kiters, per_level, two_pass_levels):
     """HBM traffic of the finest level from the FETCH_SIZE / WRITE_SIZE passes (sub-directories fetch/ and
     write/ of the profile directory).  Units and the gfx950 correction follow MI355X_MICROARCH.md 'HBM':
     both counters are in KiB; FETCH_SIZE reads exactly half the bytes of a wide (16 B/lane) coalesced
@@ -35,10 +35,11 @@ def pmc_section(d, size, kiters, per_level):
             if k not in agg:
                 continue
             v = [x for _, x in sorted(agg[k])]
-            per_pyr = n * kiters
+            nl = len(two_pass_levels[k])
+            per_pyr = n * nl
             sel = []
             for p in range(len(v) // per_pyr):
-                sel += v[p * per_pyr + (kiters - 1) * n:(p + 1) * per_pyr]
+                sel += v[p * per_pyr + (nl - 1) * n:(p + 1) * per_pyr]
             vals[(k, cname)] = sum(sel) / len(sel)
     px = size * size
     alg = {"k_pcg_pass_a": (36, 16), "k_pcg_pass_b": (40, 16), "k_assemble": (52, 36), "k_flow_update": (16, 8)}
@@ -76,6 +77,12 @@ def main():
             meta[short] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Workgroup_Size_X"])
     per_level = {"k_pcg_pass_a": 3 * liters * cgiters, "k_pcg_pass_b": 3 * liters * cgiters,
                  "k_assemble": 3 * liters, "k_flow_update": 3 * liters}
+    # levels of at most 6144 pixels are solved by k_pcg_solve_small (one launch per solve, flow update included)
+    def lev_w(lev):
+        return int(size * 0.5 ** (kiters - 1 - lev) + 0.5)
+    small = [lev for lev in range(kiters) if lev_w(lev) ** 2 <= 6144]
+    two_pass_levels = {k: ([l for l in range(kiters) if l not in small] if k != "k_assemble" else list(range(kiters)))
+                       for k in per_level}
     lines = [f"# rocprofv3 kernel-trace summary: bench.py, {size}x{size}, kiters={kiters} liters={liters} cgiters={cgiters}", "",
              "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...` on one MI355X;",
              "durations are End-Start of each dispatch in ns, averaged over every pyramid in the run (warm-up included).", "",
@@ -85,12 +92,13 @@ def main():
         if k not in rows:
             continue
         v = sorted(rows[k])
-        per_pyr = n_per_level * kiters
+        levs = two_pass_levels[k]
+        per_pyr = n_per_level * len(levs)
         npyr = len(v) // per_pyr
-        for lev in range(kiters):
+        for li, lev in enumerate(levs):
             sel = []
             for p in range(npyr):
-                sel += v[p * per_pyr + lev * n_per_level: p * per_pyr + (lev + 1) * n_per_level]
+                sel += v[p * per_pyr + li * n_per_level: p * per_pyr + (li + 1) * n_per_level]
             durs = [s[1] for s in sel]
             f = 0.5 ** (kiters - 1 - lev)
             lw = int(size * f + 0.5)
@@ -106,10 +114,10 @@ def main():
     fin = {k: None for k in ("k_pcg_pass_a", "k_pcg_pass_b")}
     for k in fin:
         if k in rows:
-            v = sorted(rows[k]); n = per_level[k]; per_pyr = n * kiters; npyr = len(v) // per_pyr
+            v = sorted(rows[k]); n = per_level[k]; nl = len(two_pass_levels[k]); per_pyr = n * nl; npyr = len(v) // per_pyr
             d_ = []
             for p in range(npyr):
-                d_ += [s[1] for s in v[p * per_pyr + (kiters - 1) * n: (p + 1) * per_pyr]]
+                d_ += [s[1] for s in v[p * per_pyr + (nl - 1) * n: (p + 1) * per_pyr]]
             fin[k] = sum(d_) / len(d_)
     if all(fin.values()):
         px = size * size
@@ -120,7 +128,7 @@ def main():
                   f"**{56 * px / fin['k_pcg_pass_b']:.0f} GB/s** ({56 * px / fin['k_pcg_pass_b'] / 80:.1f} % of 8 TB/s)",
                   f"* one PCG iteration at SURVEY 8(d)'s 116 B/px: {116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']):.0f} GB/s "
                   f"({116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']) / 80:.1f} % of 8 TB/s)"]
-    lines += pmc_section(d, size, kiters, per_level)
+    lines += pmc_section(d, size, kiters, per_level, two_pass_levels)
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
