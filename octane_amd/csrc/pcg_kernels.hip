@@ -1,25 +1,28 @@
 // pcg_kernels.hip -- the inner linear solver: Jacobi-preconditioned CG, matrix-free, gfx950.
 //
-// Behavioural spec: ref src/oct_variational_optical_flow.cu:1105-1195 (PCG on an assembled CSR
-// matrix, 12 grid barriers and 5 atomics-based dot products per iteration, A*p computed
-// twice).  The iterates here are the same -- same operator, same preconditioner, same
-// recurrences, same iteration count, same stop test -- but one iteration is two streaming
-// kernels over row-pitched planes:
+// Behavioural spec: ref src/oct_variational_optical_flow.cu:1105-1195 (PCG on an assembled CSR matrix, 12 grid
+// barriers and 5 atomics-based dot products per iteration, A*p computed twice).  The iterates here are the same --
+// same operator, same preconditioner, same recurrences, same iteration count, same stop test -- but one iteration
+// is two streaming kernels over row-pitched planes:
 //
 //   pass A(k):  beta = (r.z)_k / (r.z)_{k-1};  p <- M^-1 r + beta p;  q <- A p;  partials of p.q
 //   pass B(k):  alpha = (r.z)_k / (p.q);  x <- x + alpha p;  r <- r - alpha q;  partials of r.M^-1 r, r.r
 //
-// (the reference's z0.bcu and bcu.z0 products are the previous/current r.z, so three of its
-// five dot products are redundant).  A acts through five coefficient planes (see k_assemble).
+// (the reference's z0.bcu and bcu.z0 products are the previous/current r.z, so three of its five dot products are
+// redundant).  A acts through five coefficient planes (see k_assemble).
 //
-// Reductions are two-stage and deterministic with no atomics, fences or extra launches: each
-// persistent block writes one double partial; every block of the NEXT kernel folds the (at most
-// 1024) partials in the same fixed order (device_util.hpp), so all blocks agree bitwise on
-// alpha/beta and on the stop decision.  The kernel boundary provides the visibility.
+// Reductions are two-stage and deterministic with no atomics, fences or extra launches: each persistent workgroup
+// writes one double partial; every workgroup of the NEXT kernel folds the (at most 2048) partials in the same fixed
+// order (device_util.hpp), so all of them agree bitwise on alpha/beta and on the stop decision.  The kernel
+// boundary provides the visibility.
 //
-// Algorithmic HBM bytes per pixel per iteration: A reads r(2) p(2) a1 a2 a4 wx wy
-// = 36 B, writes p(2) q(2) = 16 B; B reads x(2) r(2) p(2) q(2) a1 a4 = 40 B, writes x(2) r(2)
-// = 16 B.  Halo re-reads of A are L2/MALL hits.
+// HBM bytes per pixel per iteration: A reads r(2) p(2) a1 a2 a4 wx wy = 36 B and writes p(2) q(2)
+// = 16 B; B reads r(2) p(2) q(2) mu mv = 32 B (+ x(2) p_prev(2) = 16 B every second iteration) and writes r(2)
+// (+ x(2) every second iteration).  Single-use planes (x, q, mu/mv, a2) move with streaming hints so that the
+// planes both passes share (r, p) keep the Infinity Cache; pass B walks the frame backwards for the same reason.
+//
+// Also here: k_pcg_solve_small (a whole solve in one workgroup for the coarsest levels), k_flow_update, and
+// k_pcg_pass_a_ring, a marching form of pass A with 8 % instead of 30 % re-fetch that is not faster.
 #include "vof_kernels.hpp"
 #include "device_util.hpp"
 
@@ -58,164 +61,13 @@ __device__ __forceinline__ float direction(float r, float pold, float diag, floa
     return first ? z : beta * pold + z;
 }
 
-__global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int nparts_prev, float tol)
-{
-    __shared__ __attribute__((aligned(16))) float s_pu[(kTileY + 2) * kLRow];
-    __shared__ __attribute__((aligned(16))) float s_pv[(kTileY + 2) * kLRow];
-    __shared__ double s_red[8];
-    const int tid = threadIdx.x;
-
-    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
-    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
-    const PcgState prev = L.st[k & 1];
-    // the reference's loop test: while (residc > tol && ki < iters)   (ref .cu:1131)
-    const bool active = (prev.stopped == 0) && (rr > tol);
-    if (!active) {
-        if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
-        return;
-    }
-    const bool first = (k == 0);
-    const float beta = first ? 0.f : rz_new / prev.rz;
-    if (blockIdx.x == 0 && tid == 0) {
-        PcgState n; n.rz = rz_new; n.stopped = 0; n.iters = prev.iters + 1; n.pad = 0;
-        L.st[(k + 1) & 1] = n;
-    }
-
-    const int w = L.w, h = L.h, pitch = L.pitch;
-    const int tiles_x = (w + kTileX - 1) / kTileX, tiles_y = (h + kTileY - 1) / kTileY;
-    const int ntiles = tiles_x * tiles_y;
-    const int lx = tid & 31, ly = tid >> 5;
-    double acc = 0.;
-    // p is updated out of place: neighbouring tiles re-read the OLD p for their halo while this
-    // block writes the new one, so in-place would race across workgroups.
-    const float *__restrict__ pin_u = L.pu[k & 1];
-    const float *__restrict__ pin_v = L.pv[k & 1];
-    float *__restrict__ pout_u = L.pu[(k + 1) & 1];
-    float *__restrict__ pout_v = L.pv[(k + 1) & 1];
-
-    const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
-    for (int t = tr.first; t < tr.end; t += tr.step) {
-        const int tx0 = (t % tiles_x) * kTileX, ty0 = (t / tiles_x) * kTileY;
-        const int x = tx0 + lx * 4, y = ty0 + ly;
-        const bool rowok = (y < h) && (x < w);
-        const size_t o = (size_t)y * pitch + x;
-
-        float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0}, a1[4] = {1, 1, 1, 1}, a4[4] = {1, 1, 1, 1};
-        float a2[4], wxc[4], wyc[4], wys[4] = {0, 0, 0, 0};
-        float npu[4], npv[4];
-        float wxw = 0.f;
-        if (rowok) {
-            *(float4 *)ru = ld4(L.ru + o);
-            *(float4 *)rv = ld4(L.rv + o);
-            *(float4 *)a1 = ld4_if(L.a1 + o, L.nt_hints & 16);
-            *(float4 *)a4 = ld4_if(L.a4 + o, L.nt_hints & 16);
-            *(float4 *)a2 = ld4_if(L.a2 + o, L.nt_hints & 8);
-            *(float4 *)wxc = ld4_if(L.wx + o, L.nt_hints & 32);
-            *(float4 *)wyc = ld4_if(L.wy + o, L.nt_hints & 32);
-            if (y > 0) *(float4 *)wys = ld4(L.wy + o - pitch);
-            if (x > 0) wxw = L.wx[o - 1];
-            float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
-            if (!first) { *(float4 *)pu = ld4(pin_u + o); *(float4 *)pv = ld4(pin_v + o); }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const bool ok = (x + e) < w;
-                npu[e] = ok ? direction(ru[e], pu[e], a1[e], beta, first) : 0.f;
-                npv[e] = ok ? direction(rv[e], pv[e], a4[e], beta, first) : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) { npu[e] = 0.f; npv[e] = 0.f; a2[e] = 0.f; wxc[e] = 0.f; wyc[e] = 0.f; }
-        }
-        st4(&s_pu[(ly + 1) * kLRow + kLInt + lx * 4], *(float4 *)npu);
-        st4(&s_pv[(ly + 1) * kLRow + kLInt + lx * 4], *(float4 *)npv);
-
-        // one-pixel halo of p_new, recomputed from r, p_old and the diagonal
-        if (tid < 64) {                                  // rows above and below the tile
-            const int hy = (tid < 32) ? ty0 - 1 : ty0 + kTileY;
-            const int hx = tx0 + (tid & 31) * 4;
-            const int lrow = (tid < 32) ? 0 : kTileY + 1;
-            float hu[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0};
-            if (hy >= 0 && hy < h && hx < w) {
-                const size_t ho = (size_t)hy * pitch + hx;
-                float r0[4], r1[4], d0[4], d1[4], q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
-                *(float4 *)r0 = ld4(L.ru + ho); *(float4 *)r1 = ld4(L.rv + ho);
-                *(float4 *)d0 = ld4(L.a1 + ho); *(float4 *)d1 = ld4(L.a4 + ho);
-                if (!first) { *(float4 *)q0 = ld4(pin_u + ho); *(float4 *)q1 = ld4(pin_v + ho); }
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const bool ok = (hx + e) < w;
-                    hu[e] = ok ? direction(r0[e], q0[e], d0[e], beta, first) : 0.f;
-                    hv[e] = ok ? direction(r1[e], q1[e], d1[e], beta, first) : 0.f;
-                }
-            }
-            st4(&s_pu[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hu);
-            st4(&s_pv[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hv);
-        } else if (tid < 64 + 2 * kTileY) {              // columns left and right of the tile
-            const int side = (tid - 64) / kTileY, row = (tid - 64) % kTileY;
-            const int hy = ty0 + row;
-            const int hx = side ? tx0 + kTileX : tx0 - 1;
-            float hu = 0.f, hv = 0.f;
-            if (hy < h && hx >= 0 && hx < w) {
-                const size_t ho = (size_t)hy * pitch + hx;
-                const float q0 = first ? 0.f : pin_u[ho], q1 = first ? 0.f : pin_v[ho];
-                hu = direction(L.ru[ho], q0, L.a1[ho], beta, first);
-                hv = direction(L.rv[ho], q1, L.a4[ho], beta, first);
-            }
-            const int lcol = side ? kLInt + kTileX : kLInt - 1;
-            s_pu[(row + 1) * kLRow + lcol] = hu;
-            s_pv[(row + 1) * kLRow + lcol] = hv;
-        }
-        __syncthreads();
-
-        if (rowok) {
-            float su[4], sv[4], nu[4], nv[4];
-            *(float4 *)su = ld4(&s_pu[ly * kLRow + kLInt + lx * 4]);
-            *(float4 *)sv = ld4(&s_pv[ly * kLRow + kLInt + lx * 4]);
-            *(float4 *)nu = ld4(&s_pu[(ly + 2) * kLRow + kLInt + lx * 4]);
-            *(float4 *)nv = ld4(&s_pv[(ly + 2) * kLRow + kLInt + lx * 4]);
-            const float uwest = s_pu[(ly + 1) * kLRow + kLInt + lx * 4 - 1];
-            const float vwest = s_pv[(ly + 1) * kLRow + kLInt + lx * 4 - 1];
-            const float ueast = s_pu[(ly + 1) * kLRow + kLInt + lx * 4 + 4];
-            const float veast = s_pv[(ly + 1) * kLRow + kLInt + lx * 4 + 4];
-            float qu[4], qv[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int i = x + e;
-                const float pwu = (e == 0) ? uwest : npu[e - 1], pwv = (e == 0) ? vwest : npv[e - 1];
-                const float peu = (e == 3) ? ueast : npu[(e + 1) & 3], pev = (e == 3) ? veast : npv[(e + 1) & 3];
-                // row entries in the reference's storage order: south, west, block, east, north
-                // with the merged border weights of ref .cu:929-1001
-                const float a5 = (e == 0) ? wxw : wxc[(e + 3) & 3];
-                const float wS = (y == h - 1) ? wys[e] + wyc[e] : wys[e];
-                const float wW = (i == w - 1) ? a5 + wxc[e] : a5;
-                const float wE = (i == 0) ? wxc[e] + wxc[e] : wxc[e];
-                const float wN = (y == 0) ? wyc[e] + wyc[e] : wyc[e];
-                float sumu = 0.f, sumv = 0.f;
-                if (y > 0) { sumu += wS * su[e]; sumv += wS * sv[e]; }
-                if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
-                sumu += a1[e] * npu[e]; sumv += a2[e] * npu[e];
-                sumu += a2[e] * npv[e]; sumv += a4[e] * npv[e];
-                if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
-                if (y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
-                qu[e] = sumu; qv[e] = sumv;
-                if (i < w) acc += (double)(npu[e] * sumu) + (double)(npv[e] * sumv);
-            }
-            st4(pout_u + o, *(float4 *)npu);
-            st4(pout_v + o, *(float4 *)npv);
-            st4(L.qu + o, *(float4 *)qu);
-            st4(L.qv + o, *(float4 *)qv);
-        }
-        __syncthreads();
-    }
-    const double tot = block_sum_256(acc, s_red);
-    if (tid == 0) L.part_pq[blockIdx.x] = tot;
-}
-
-// Tall-tile form of the LDS-tiled pass A (OCTANE_TUNE_PASS_A=4): the same kernel with R rows per thread, i.e. a
-// 128 x 8R tile per workgroup iteration: the two halo rows are amortised over 8R rows and there are R times fewer
-// barriers per pixel.
+// Pass A.  A 256-thread workgroup iteration covers a 128 x 8R tile: thread (lx, ly) owns the 4 pixels at columns
+// 4*lx.. of rows ly, ly+8, ..  p_new = M^-1 r + beta p goes into an LDS tile with a one-pixel halo (recomputed from
+// r, p_old and the diagonal of the neighbouring pixels), then q = A p_new is formed from LDS + registers.  R = 2
+// (128 x 16) is the default: against R = 1 the two halo rows are amortised over 16 rows and there are half as many
+// barriers per pixel (-6 % time); R = 4 needs 236 VGPRs and loses more in occupancy than it saves.
 template <int R>
-__global__ __launch_bounds__(256) void k_pcg_pass_a_tall(LevelPtrs L, int k, int nparts_prev, float tol)
+__global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int nparts_prev, float tol)
 {
     constexpr int TY = kTileY * R;
     __shared__ __attribute__((aligned(16))) float s_pu[(TY + 2) * kLRow];
@@ -373,319 +225,6 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a_tall(LevelPtrs L, int k, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pass A, row-rolling form (experimental: OCTANE_TUNE_PASS_A=1; measured slower than the tiled form).
-//
-// One wavefront owns a strip of 62 lanes x 4 pixels = 248 columns (lanes 0 and 63 are halo lanes
-// that recompute p_new for the neighbouring strips' edge columns) and marches down kSegRows rows.
-// The three rows of p_new that the 5-point operator needs (j-1, j, j+1) stay in registers, the
-// vertical neighbours therefore cost nothing, and the horizontal ones come from the adjacent
-// lanes with wavefront shuffles.  No LDS tile, no workgroup barrier inside the loop, every
-// global access is a 16-byte-per-lane row segment (1 KiB per wave instruction), the row above's
-// wy and the west wx ride along in registers.  Halo recomputation costs 2/64 of the columns and
-// 2 reduced rows (r, p, diagonal only) per kSegRows -- all L2 / Infinity-Cache hits.
-// ---------------------------------------------------------------------------------------------
-constexpr int kStripLanes = 62;
-constexpr int kStripW = kStripLanes * 4;
-constexpr int kSegRows = 16;
-
-struct RowDir { float u[4], v[4]; };
-
-__device__ __forceinline__ RowDir row_direction(const LevelPtrs &L, const float *__restrict__ pin_u,
-                                                const float *__restrict__ pin_v, size_t o, int x, int w,
-                                                float beta, bool first, bool colok, float *a1out, float *a4out)
-{
-    RowDir d;
-    float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0}, a1[4] = {1, 1, 1, 1}, a4[4] = {1, 1, 1, 1};
-    float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
-    if (colok) {
-        *(float4 *)ru = ld4(L.ru + o); *(float4 *)rv = ld4(L.rv + o);
-        *(float4 *)a1 = ld4(L.a1 + o); *(float4 *)a4 = ld4(L.a4 + o);
-        if (!first) { *(float4 *)pu = ld4(pin_u + o); *(float4 *)pv = ld4(pin_v + o); }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const bool ok = colok && (x + e) < w;
-        d.u[e] = ok ? direction(ru[e], pu[e], a1[e], beta, first) : 0.f;
-        d.v[e] = ok ? direction(rv[e], pv[e], a4[e], beta, first) : 0.f;
-        if (a1out) { a1out[e] = a1[e]; a4out[e] = a4[e]; }
-    }
-    return d;
-}
-
-__global__ __launch_bounds__(256, 4) void k_pcg_pass_a_rows(LevelPtrs L, int k, int nparts_prev, float tol)
-{
-    __shared__ double s_red[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
-    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
-    const PcgState prev = L.st[k & 1];
-    const bool active = (prev.stopped == 0) && (rr > tol);          // ref .cu:1131
-    if (!active) {
-        if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
-        return;
-    }
-    const bool first = (k == 0);
-    const float beta = first ? 0.f : rz_new / prev.rz;
-    if (blockIdx.x == 0 && tid == 0) {
-        PcgState n; n.rz = rz_new; n.stopped = 0; n.iters = prev.iters + 1; n.pad = 0;
-        L.st[(k + 1) & 1] = n;
-    }
-
-    const int w = L.w, h = L.h, pitch = L.pitch;
-    const int strips = (w + kStripW - 1) / kStripW, segs = (h + kSegRows - 1) / kSegRows;
-    const int nitems = strips * segs;
-    const float *__restrict__ pin_u = L.pu[k & 1];
-    const float *__restrict__ pin_v = L.pv[k & 1];
-    float *__restrict__ pout_u = L.pu[(k + 1) & 1];
-    float *__restrict__ pout_v = L.pv[(k + 1) & 1];
-    double acc = 0.;
-
-    for (int item = blockIdx.x * 4 + wave; item < nitems; item += gridDim.x * 4) {
-        const int sidx = item % strips, gidx = item / strips;
-        const int x = sidx * kStripW - 4 + lane * 4;
-        const int j0 = gidx * kSegRows, j1 = min(j0 + kSegRows, h);
-        const bool colok = (x >= 0) && (x < w);
-        const bool owner = colok && (lane >= 1) && (lane <= kStripLanes);
-
-        RowDir pm, pc, pn;
-        float a1c[4], a4c[4], a2c[4] = {0, 0, 0, 0}, wxc[4] = {0, 0, 0, 0}, wyc[4] = {0, 0, 0, 0}, wym[4] = {0, 0, 0, 0};
-        float a1n[4], a4n[4], a2n[4] = {0, 0, 0, 0}, wxn[4] = {0, 0, 0, 0}, wyn[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int e = 0; e < 4; e++) { pm.u[e] = 0.f; pm.v[e] = 0.f; }
-        if (j0 > 0) {
-            const size_t om = (size_t)(j0 - 1) * pitch + x;
-            pm = row_direction(L, pin_u, pin_v, om, x, w, beta, first, colok, nullptr, nullptr);
-            if (colok) *(float4 *)wym = ld4(L.wy + om);
-        }
-        {
-            const size_t oc = (size_t)j0 * pitch + x;
-            pc = row_direction(L, pin_u, pin_v, oc, x, w, beta, first, colok, a1c, a4c);
-            if (colok) { *(float4 *)a2c = ld4(L.a2 + oc); *(float4 *)wxc = ld4(L.wx + oc); *(float4 *)wyc = ld4(L.wy + oc); }
-        }
-        for (int y = j0; y < j1; ++y) {
-            // next row: full operands if this wave also owns it, otherwise just enough for p_new
-            const size_t on = (size_t)(y + 1) * pitch + x;
-            if (y + 1 < h) {
-                pn = row_direction(L, pin_u, pin_v, on, x, w, beta, first, colok, a1n, a4n);
-                if (y + 1 < j1 && colok) {
-                    *(float4 *)a2n = ld4(L.a2 + on); *(float4 *)wxn = ld4(L.wx + on); *(float4 *)wyn = ld4(L.wy + on);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) { pn.u[e] = 0.f; pn.v[e] = 0.f; }
-            }
-            // horizontal neighbours from the adjacent lanes
-            const float uwest = __shfl_up(pc.u[3], 1, 64), vwest = __shfl_up(pc.v[3], 1, 64);
-            const float ueast = __shfl_down(pc.u[0], 1, 64), veast = __shfl_down(pc.v[0], 1, 64);
-            const float wxw = __shfl_up(wxc[3], 1, 64);
-            if (owner) {
-                float qu[4], qv[4];
-                float rowdot = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int i = x + e;
-                    const float pwu = (e == 0) ? uwest : pc.u[(e + 3) & 3], pwv = (e == 0) ? vwest : pc.v[(e + 3) & 3];
-                    const float peu = (e == 3) ? ueast : pc.u[(e + 1) & 3], pev = (e == 3) ? veast : pc.v[(e + 1) & 3];
-                    const float a5 = (e == 0) ? wxw : wxc[(e + 3) & 3];
-                    const float wS = (y == h - 1) ? wym[e] + wyc[e] : wym[e];
-                    const float wW = (i == w - 1) ? a5 + wxc[e] : a5;
-                    const float wE = (i == 0) ? wxc[e] + wxc[e] : wxc[e];
-                    const float wN = (y == 0) ? wyc[e] + wyc[e] : wyc[e];
-                    float sumu = 0.f, sumv = 0.f;
-                    if (y > 0) { sumu += wS * pm.u[e]; sumv += wS * pm.v[e]; }
-                    if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
-                    sumu += a1c[e] * pc.u[e]; sumv += a2c[e] * pc.u[e];
-                    sumu += a2c[e] * pc.v[e]; sumv += a4c[e] * pc.v[e];
-                    if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
-                    if (y < h - 1) { sumu += wN * pn.u[e]; sumv += wN * pn.v[e]; }
-                    qu[e] = sumu; qv[e] = sumv;
-                    if (i < w) { rowdot += pc.u[e] * sumu; rowdot += pc.v[e] * sumv; }
-                }
-                const size_t o = (size_t)y * pitch + x;
-                st4(pout_u + o, *(float4 *)pc.u);
-                st4(pout_v + o, *(float4 *)pc.v);
-                st4(L.qu + o, *(float4 *)qu);
-                st4(L.qv + o, *(float4 *)qv);
-                acc += (double)rowdot;
-            }
-            // roll the window down one row
-            pm = pc; pc = pn;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                wym[e] = wyc[e];
-                a1c[e] = a1n[e]; a4c[e] = a4n[e]; a2c[e] = a2n[e]; wxc[e] = wxn[e]; wyc[e] = wyn[e];
-            }
-        }
-    }
-    const double tot = block_sum_256(acc, s_red);
-    if (tid == 0) L.part_pq[blockIdx.x] = tot;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Pass A, marching form (OCTANE_TUNE_PASS_A=2).
-//
-// A workgroup owns a strip 1024 pixels wide (256 lanes x 4 px) and marches down a run of rows.  Each
-// lane keeps p_new of rows y-1, y, y+1 of its four columns in registers, so the vertical neighbours are
-// free and no row is ever loaded twice inside a run; horizontal neighbours come from the adjacent lane
-// (wavefront shuffle), from the adjacent wave (a 4-entry LDS edge table, one barrier per row) or, at the
-// two ends of the strip, from one recomputed pixel.  Re-fetch through the fabric is then ~4 % (strip
-// ends) + 2 reduced rows per run instead of the 44 % of the 128x8 tiles.
-// ---------------------------------------------------------------------------------------------
-constexpr int kMarchW = 1024;
-
-__global__ __launch_bounds__(256, 4) void k_pcg_pass_a_march(LevelPtrs L, int k, int nparts_prev, float tol)
-{
-    __shared__ double s_red[8];
-    __shared__ float s_edge[2][4][6];   // [row parity][wave]{u,v of first px, u,v,wx of last px}
-    __shared__ float s_side[2][4];      // [row parity]{u,v just west of the strip, u,v just east}
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
-    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
-    const PcgState prev = L.st[k & 1];
-    const bool active = (prev.stopped == 0) && (rr > tol);          // ref .cu:1131
-    if (!active) {
-        if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
-        return;
-    }
-    const bool first = (k == 0);
-    const float beta = first ? 0.f : rz_new / prev.rz;
-    if (blockIdx.x == 0 && tid == 0) {
-        PcgState n; n.rz = rz_new; n.stopped = 0; n.iters = prev.iters + 1; n.pad = 0;
-        L.st[(k + 1) & 1] = n;
-    }
-
-    const int w = L.w, h = L.h, pitch = L.pitch;
-    const int strips = (w + kMarchW - 1) / kMarchW;
-    const long total_rows = (long)strips * h;
-    const float *__restrict__ pin_u = L.pu[k & 1];
-    const float *__restrict__ pin_v = L.pv[k & 1];
-    float *__restrict__ pout_u = L.pu[(k + 1) & 1];
-    float *__restrict__ pout_v = L.pv[(k + 1) & 1];
-    double acc = 0.;
-
-    // this workgroup's share of the (strip-major) list of strip rows: equal for all workgroups (+-1)
-    long vr = total_rows * blockIdx.x / gridDim.x;
-    const long vr_end = total_rows * (blockIdx.x + 1) / gridDim.x;
-    while (vr < vr_end) {
-        const int sidx = (int)(vr / h);
-        const int y0 = (int)(vr - (long)sidx * h);
-        const int y1 = (int)min((long)h, y0 + (vr_end - vr));
-        vr += y1 - y0;
-        const int x0 = sidx * kMarchW;
-        const int x = x0 + tid * 4;
-        const bool colok = x < w;
-        const bool west_side = (tid == 0) && (x0 > 0);
-        const bool east_side = (tid == 255) && (x0 + kMarchW < w);
-        const int xs = west_side ? x0 - 1 : x0 + kMarchW;     // the one pixel outside the strip this lane recomputes
-
-        auto side_dir = [&](int yy, float &su, float &sv) {
-            const size_t so = (size_t)yy * pitch + xs;
-            const float q0 = first ? 0.f : pin_u[so], q1 = first ? 0.f : pin_v[so];
-            su = direction(L.ru[so], q0, L.a1[so], beta, first);
-            sv = direction(L.rv[so], q1, L.a4[so], beta, first);
-        };
-        auto publish = [&](const RowDir &d, const float *wx4, int yy) {     // edges of row yy for the other waves
-            const int par = yy & 1;
-            if (lane == 0) { s_edge[par][wave][0] = d.u[0]; s_edge[par][wave][1] = d.v[0]; }
-            if (lane == 63) { s_edge[par][wave][2] = d.u[3]; s_edge[par][wave][3] = d.v[3]; s_edge[par][wave][4] = wx4[3]; }
-            if (west_side || east_side) {
-                float su, sv;
-                side_dir(yy, su, sv);
-                s_side[par][west_side ? 0 : 2] = su; s_side[par][west_side ? 1 : 3] = sv;
-            }
-        };
-
-        RowDir pm, pc, pn;
-        float a1c[4], a4c[4], a2c[4] = {0, 0, 0, 0}, wxc[4] = {0, 0, 0, 0}, wyc[4] = {0, 0, 0, 0}, wym[4] = {0, 0, 0, 0};
-        float a1n[4], a4n[4], a2n[4] = {0, 0, 0, 0}, wxn[4] = {0, 0, 0, 0}, wyn[4] = {0, 0, 0, 0};
-        float wx_side_c = 0.f, wx_side_n = 0.f;     // wx just west of the strip (lane 0 of wave 0 only)
-#pragma unroll
-        for (int e = 0; e < 4; e++) { pm.u[e] = 0.f; pm.v[e] = 0.f; }
-        __syncthreads();                             // the edge tables may still be read by a previous run
-        if (y0 > 0) {
-            const size_t om = (size_t)(y0 - 1) * pitch + x;
-            pm = row_direction(L, pin_u, pin_v, om, x, w, beta, first, colok, nullptr, nullptr);
-            if (colok) *(float4 *)wym = ld4(L.wy + om);
-        }
-        {
-            const size_t oc = (size_t)y0 * pitch + x;
-            pc = row_direction(L, pin_u, pin_v, oc, x, w, beta, first, colok, a1c, a4c);
-            if (colok) { *(float4 *)a2c = ld4(L.a2 + oc); *(float4 *)wxc = ld4(L.wx + oc); *(float4 *)wyc = ld4(L.wy + oc); }
-            if (west_side) wx_side_c = L.wx[oc - 1];
-            publish(pc, wxc, y0);
-        }
-        for (int y = y0; y < y1; ++y) {
-            const size_t on = (size_t)(y + 1) * pitch + x;
-            if (y + 1 < h) {
-                pn = row_direction(L, pin_u, pin_v, on, x, w, beta, first, colok, a1n, a4n);
-                if (y + 1 < y1) {
-                    if (colok) { *(float4 *)a2n = ld4(L.a2 + on); *(float4 *)wxn = ld4(L.wx + on); *(float4 *)wyn = ld4(L.wy + on); }
-                    if (west_side) wx_side_n = L.wx[on - 1];
-                    publish(pn, wxn, y + 1);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) { pn.u[e] = 0.f; pn.v[e] = 0.f; }
-            }
-            __syncthreads();                         // row y's edge entries (written one step ago) are visible
-            const int par = y & 1;
-            float uwest = __shfl_up(pc.u[3], 1, 64), vwest = __shfl_up(pc.v[3], 1, 64);
-            float ueast = __shfl_down(pc.u[0], 1, 64), veast = __shfl_down(pc.v[0], 1, 64);
-            float wxw = __shfl_up(wxc[3], 1, 64);
-            if (lane == 0) {
-                if (wave > 0) { uwest = s_edge[par][wave - 1][2]; vwest = s_edge[par][wave - 1][3]; wxw = s_edge[par][wave - 1][4]; }
-                else { uwest = s_side[par][0]; vwest = s_side[par][1]; wxw = wx_side_c; }
-            }
-            if (lane == 63) {
-                if (wave < 3) { ueast = s_edge[par][wave + 1][0]; veast = s_edge[par][wave + 1][1]; }
-                else { ueast = s_side[par][2]; veast = s_side[par][3]; }
-            }
-            if (colok) {
-                float qu[4], qv[4];
-                float rowdot = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int i = x + e;
-                    const float pwu = (e == 0) ? uwest : pc.u[(e + 3) & 3], pwv = (e == 0) ? vwest : pc.v[(e + 3) & 3];
-                    const float peu = (e == 3) ? ueast : pc.u[(e + 1) & 3], pev = (e == 3) ? veast : pc.v[(e + 1) & 3];
-                    const float a5 = (e == 0) ? wxw : wxc[(e + 3) & 3];
-                    const float wS = (y == h - 1) ? wym[e] + wyc[e] : wym[e];
-                    const float wW = (i == w - 1) ? a5 + wxc[e] : a5;
-                    const float wE = (i == 0) ? wxc[e] + wxc[e] : wxc[e];
-                    const float wN = (y == 0) ? wyc[e] + wyc[e] : wyc[e];
-                    float sumu = 0.f, sumv = 0.f;
-                    if (y > 0) { sumu += wS * pm.u[e]; sumv += wS * pm.v[e]; }
-                    if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
-                    sumu += a1c[e] * pc.u[e]; sumv += a2c[e] * pc.u[e];
-                    sumu += a2c[e] * pc.v[e]; sumv += a4c[e] * pc.v[e];
-                    if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
-                    if (y < h - 1) { sumu += wN * pn.u[e]; sumv += wN * pn.v[e]; }
-                    qu[e] = sumu; qv[e] = sumv;
-                    if (i < w) { rowdot += pc.u[e] * sumu; rowdot += pc.v[e] * sumv; }
-                }
-                const size_t o = (size_t)y * pitch + x;
-                st4(pout_u + o, *(float4 *)pc.u);
-                st4(pout_v + o, *(float4 *)pc.v);
-                st4(L.qu + o, *(float4 *)qu);
-                st4(L.qv + o, *(float4 *)qv);
-                acc += (double)rowdot;
-            }
-            pm = pc; pc = pn;
-            wx_side_c = wx_side_n;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                wym[e] = wyc[e];
-                a1c[e] = a1n[e]; a4c[e] = a4n[e]; a2c[e] = a2n[e]; wxc[e] = wxn[e]; wyc[e] = wyn[e];
-            }
-        }
-    }
-    const double tot = block_sum_256(acc, s_red);
-    if (tid == 0) L.part_pq[blockIdx.x] = tot;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Pass A, marching form with an LDS row ring (OCTANE_TUNE_PASS_A=3).
 //
 // Same decomposition as k_pcg_pass_a_march (1024-pixel strips, contiguous runs of rows, equal shares), but
@@ -695,6 +234,7 @@ __global__ __launch_bounds__(256, 4) void k_pcg_pass_a_march(LevelPtrs L, int k,
 // Nothing is fetched twice inside a run; re-fetch is 2 pixels per row (strip ends) + 2 reduced rows per
 // run.
 // ---------------------------------------------------------------------------------------------
+constexpr int kMarchW = 1024;
 constexpr int kRingRow = kMarchW + 8;     // [3 pad][west px][1024 interior][east px][3 pad]
 
 struct RawRow { float4 ru, rv, pu, pv, a1, a4; float s[6]; };   // s: the strip-end pixel's r,p,a (2 lanes only)
@@ -1010,11 +550,6 @@ __global__ __launch_bounds__(256) void k_flow_update(LevelPtrs L, int nlaunched)
     }
 }
 
-static int pcg_tiled_grid_size(int w, int h)
-{
-    return balanced_grid((long)((w + kTileX - 1) / kTileX) * ((h + kTileY - 1) / kTileY));
-}
-
 static int stream_grid_size(int w, int h)
 {
     long groups = (long)((w + 3) / 4) * h;
@@ -1031,45 +566,34 @@ static int pass_b_grid_size(int w, int h)
     return g;
 }
 
-static int g_pass_a_variant = 4;   // 4 = LDS-tiled 128x16 (default), 0 = 128x8, 5 = 128x32, 1/2/3 = experimental marching forms
-void set_pass_a_variant(int v) { g_pass_a_variant = v; }
+static int g_pass_a_variant = 2;   // rows per thread of the tiled kernel: 1, 2 (default) or 4; 3 = LDS-ring marching (experiment)
+void set_pass_a_variant(int v) { g_pass_a_variant = (v == 1 || v == 2 || v == 3 || v == 4) ? v : 2; }
 
 int pcg_grid_size(int w, int h)
 {
-    if (g_pass_a_variant == 0) return pcg_tiled_grid_size(w, h);
-    if (g_pass_a_variant == 4 || g_pass_a_variant == 5) {
-        const int ty = kTileY * (g_pass_a_variant == 4 ? 2 : 4);
-        const long cap = (g_pass_a_variant == 4) ? 768 : 512;    // resident workgroups at 148 / 236 VGPRs
-        const long items = (long)((w + kTileX - 1) / kTileX) * ((h + ty - 1) / ty);
-        if (items <= cap) return (int)items;
-        const long rounds = (items + cap - 1) / cap;
-        return (int)((items + rounds - 1) / rounds);
-    }
-    if (g_pass_a_variant == 2 || g_pass_a_variant == 3) {   // marching: at least 8 rows per workgroup, at most 1024 workgroups (4 per CU resident)
+    if (g_pass_a_variant == 3) {   // marching: at least 8 rows per workgroup, 3 workgroups per CU resident (168 VGPRs)
         long rows = (long)((w + kMarchW - 1) / kMarchW) * h;
         long g = rows / 8;
         if (g < 1) g = 1;
-        const long cap = (g_pass_a_variant == 3) ? 768 : 1024;   // resident workgroups: 3 resp. 4 per CU
-        return (int)(g > cap ? cap : g);
+        return (int)(g > 768 ? 768 : g);
     }
-    long items = (long)((w + kStripW - 1) / kStripW) * ((h + kSegRows - 1) / kSegRows);
-    return balanced_grid((items + 3) / 4);
+    const int R = g_pass_a_variant;
+    const long items = (long)((w + kTileX - 1) / kTileX) * ((h + kTileY * R - 1) / (kTileY * R));
+    if (R == 1) return balanced_grid(items);             // 52 VGPRs: 8 workgroups per CU resident
+    const long cap = (R == 2) ? 768 : 512;               // 148 / 236 VGPRs: 3 / 2 workgroups per CU resident
+    if (items <= cap) return (int)items;
+    const long rounds = (items + cap - 1) / cap;
+    return (int)((items + rounds - 1) / rounds);
 }
 
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
-    if (g_pass_a_variant == 0)
-        hipLaunchKernelGGL(k_pcg_pass_a, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-    else if (g_pass_a_variant == 2)
-        hipLaunchKernelGGL(k_pcg_pass_a_march, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-    else if (g_pass_a_variant == 4)
-        hipLaunchKernelGGL(k_pcg_pass_a_tall<2>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-    else if (g_pass_a_variant == 5)
-        hipLaunchKernelGGL(k_pcg_pass_a_tall<4>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-    else if (g_pass_a_variant == 3)
-        hipLaunchKernelGGL(k_pcg_pass_a_ring, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-    else
-        hipLaunchKernelGGL(k_pcg_pass_a_rows, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    switch (g_pass_a_variant) {
+    case 1: hipLaunchKernelGGL(k_pcg_pass_a<1>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    case 4: hipLaunchKernelGGL(k_pcg_pass_a<4>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    case 3: hipLaunchKernelGGL(k_pcg_pass_a_ring, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    default: hipLaunchKernelGGL(k_pcg_pass_a<2>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    }
 }
 
 void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid)

@@ -71,7 +71,7 @@ void set_max_blocks(int n);
 void set_grid_multiple(int m);           // tuning knob (<= kMaxParts)
 int  balanced_grid(long work_items);   // persistent grid: every block gets the same number of items (+-1)
 int  pcg_grid_size(int w, int h);
-void set_pass_a_variant(int v);       // tuning knob: 0 LDS-tiled (default), 1 row-rolling
+void set_pass_a_variant(int v);       // tuning knob: tile rows per thread 1 | 2 (default) | 4; 3 = LDS-ring marching experiment
 int  assemble_grid_size(int w, int h);
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid);
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);

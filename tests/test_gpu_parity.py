@@ -255,3 +255,26 @@ def test_full_size_properties_2000(capi):
     pl.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr(), s)
     torch.cuda.synchronize()
     assert torch.equal(u, u1) and torch.equal(v, v1)
+
+
+def test_full_disk_frame_runs_on_one_gpu(capi):
+    """BASELINE.json configs[3] shape: a 10848 x 10848 ABI full-disk pair.  The plan needs ~17 GB of the 288 GB, so
+    the frame runs whole on ONE GPU (the reference's managed CSR would need 33 GB).  Properties only: the result is
+    finite, follows the analytic displacement and the solver did its fixed amount of work."""
+    import torch
+    n = 10848
+    a, b = synth.lattice_scene(n, n, seed=20240616, device="cuda")
+    prm = capi.FlowParams(kiters=8, liters=1, cgiters=10)
+    pl = capi.Plan(n, n, 1, prm)
+    assert 10e9 < pl.device_bytes < 30e9
+    u = torch.zeros(n, n, device="cuda"); v = torch.zeros(n, n, device="cuda")
+    torch.cuda.synchronize()
+    pl.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert pl.last_iterations() == 8 * 3 * 1 * 10
+    assert bool(torch.isfinite(u).all()) and bool(torch.isfinite(v).all())
+    m = n // 8
+    cu = u[m:-m:16, m:-m:16].double().cpu(); cv = v[m:-m:16, m:-m:16].double().cpu()
+    tu, tv = synth.true_lattice_flow(n, n, xp=torch)
+    assert (cu - tu[m:-m:16, m:-m:16]).abs().mean() < 0.1 and (cv - tv[m:-m:16, m:-m:16]).abs().mean() < 0.1
+    pl.close()

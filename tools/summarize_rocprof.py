@@ -30,6 +30,8 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
                 if "octane::" not in r["Kernel_Name"] or r["Counter_Name"] != cname:
                     continue
                 short = r["Kernel_Name"].split("octane::")[1].split("(")[0]
+                if short.startswith("k_pcg_pass_a"):
+                    short = "k_pcg_pass_a"
                 agg[short].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         for k, n in per_level.items():
             if k not in agg:
@@ -73,6 +75,8 @@ def main():
             if "octane::" not in name:
                 continue
             short = name.split("octane::")[1].split("(")[0]
+            if short.startswith("k_pcg_pass_a"):
+                short = "k_pcg_pass_a"
             rows[short].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])))
             meta[short] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Workgroup_Size_X"])
     per_level = {"k_pcg_pass_a": 3 * liters * cgiters, "k_pcg_pass_b": 3 * liters * cgiters,
