@@ -101,10 +101,19 @@ def main():
             dom, dms, bpp = "k_pcg_pass_a", a_ms, PASS_A_BYTES_PER_PIXEL
         else:
             dom, dms, bpp = "k_pcg_pass_b", b_ms, PASS_B_BYTES_PER_PIXEL
+        # HBM-side traffic of that kernel from the PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be
+        # collected inside this run; tools/profile_round.sh + tools/summarize_rocprof.py produce the file)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get(dom, {}).get("size") == n:
+                traffic = tj[dom]["read_bytes"] + tj[dom]["write_bytes"]
+        except (OSError, ValueError):
+            pass
         achieved = bpp * n * n / (dms * 1e-3) / 1e9
         iter_gbs = (PASS_A_BYTES_PER_PIXEL + PASS_B_BYTES_PER_PIXEL + 8) * n * n / ((a_ms + b_ms) * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(dms, 4), "bytes_per_launch": bpp * n * n,
                 "pass_a_ms": round(a_ms, 4), "pass_b_ms": round(b_ms, 4),
                 "pcg_iteration_gbs_at_116B_per_pixel": round(iter_gbs, 1),

@@ -51,13 +51,21 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
             "bound on HBM bytes.", "",
             "| kernel | read MB (FETCH_SIZE x 2) | algorithmic read MB | write MB (WRITE_SIZE) | algorithmic write MB | total / algorithmic |",
             "|---|---|---|---|---|---|"]
+    traffic = {}
     for k in ("k_pcg_pass_a", "k_pcg_pass_b", "k_assemble", "k_flow_update"):
         if (k, "FETCH_SIZE") not in vals:
             continue
         rd = vals[(k, "FETCH_SIZE")] * 1024 * 2
         wr = vals[(k, "WRITE_SIZE")] * 1024
         ar, aw = alg[k][0] * px, alg[k][1] * px
+        traffic[k] = {"read_bytes": round(rd), "write_bytes": round(wr), "size": size,
+                      "how": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) and --pmc WRITE_SIZE, separate passes, "
+                             "mean over the finest-level launches of bench.py"}
         out.append(f"| {k} | {rd / 1e6:.0f} | {ar / 1e6:.0f} | {wr / 1e6:.0f} | {aw / 1e6:.0f} | {(rd + wr) / (ar + aw):.3f} |")
+    if traffic:
+        import json
+        with open(os.path.join(os.path.dirname(os.path.abspath(sys.argv[2])), "traffic.json"), "w") as f:
+            json.dump(traffic, f, indent=1)
     return out
 
 
