@@ -22,6 +22,17 @@ void oct_pix2uv_cuda(GOESVar &goesData, double t2, float *uarr, float *varr, sho
 // pix2uv.  -sosm, -firstguess and -srsal belong to components outside this library's scope and are reported.
 int oct_optical_flow(GOESVar &goesData, GOESVar &goesData2, OFFlags &args);
 
+// ref src/oct_navcal_cuda.cu:100 (called by the GOES reader, src/oct_fileread.cc): raw counts -> calibrated, navigated,
+// 0..255-normalised image of the window [minx,maxx) x [miny,maxy).  cal is "RAW" | "TEMP" | "REF" | "BRIT".
+void oct_navcal_cuda(short *data2, short *data2s, short *x, short *y, short *xs, short *ys, int nx, int ny,
+                     int minx, int maxx, int miny, int maxy, float *data3, float *lat, float *lon, std::string cal,
+                     int datf, float xScale, float xOffset, float yScale, float yOffset, float radScale,
+                     float radOffset, float rpol, float req, float H, float lam0, float fk1, float fk2, float bc1,
+                     float bc2, float kap1, float maxin, float minin, float maxout, float minout, int donav,
+                     OFFlags args);
+// ref src/oct_normalize_geo.cc:9: per-band radiance range; leaves the outputs untouched for an unknown band
+void oct_bandminmax(int gb, float &maxch, float &minch);
+
 // The `octane` command line (ref src/main.cc:42-50 spellings, :53-108 defaults, :166-350 scan), including
 // its quirks: -scsig squares its argument, -set_device is 1-based, -corn clears docorn, -cgiters is not parsed.
 struct OctaneCommandLine {

@@ -120,6 +120,30 @@ int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, const float *
                       int pixuv, int mode, short *ur, short *vr, short *ur2, short *vr2,
                       float *dT, int *sector_moved, int device);
 
+/* ---- navcal: raw ABI counts -> navigated, calibrated, 0..255-normalised solver input ----
+ * Replaces void oct_navcal_cuda(short*,short*,short*,short*,short*,short*,int,int,int,int,int,int,float*,float*,
+ * float*,string,int,float x19,int,OFFlags), src/oct_navcal_cuda.cu:100; called from src/oct_fileread.cc. */
+#define OCTANE_CAL_RAW  0
+#define OCTANE_CAL_TEMP 1   /* Planck brightness temperature (fk1, fk2, bc1, bc2) */
+#define OCTANE_CAL_REF  2   /* reflectance factor (kap1)                           */
+#define OCTANE_CAL_BRIT 3
+typedef struct octane_navcal_params {
+    float xScale, xOffset, yScale, yOffset, radScale, radOffset;
+    float rpol, req, H, lam0;                  /* H = perspective point height + req */
+    float fk1, fk2, bc1, bc2, kap1;
+    float maxin, minin, maxout, minout;        /* normalisation: [minin,maxin] -> [minout,maxout] */
+    int cal, donav;
+    int minx, maxx, miny, maxy;                /* output window [minx,maxx) x [miny,maxy) of the nx x ny frame */
+} octane_navcal_params;
+/* Host buffers.  data2: nx*ny raw counts; x: nx, y: ny scaled fixed-grid coordinates.  Outputs sized for the
+ * window: data3/lat/lon/data2s (maxx-minx)*(maxy-miny), xs (maxx-minx), ys (maxy-miny). */
+int octane_navcal_run(const short *data2, const short *x, const short *y, int nx, int ny,
+                      const octane_navcal_params *p, float *data3, float *lat, float *lon,
+                      short *data2s, short *xs, short *ys, int device);
+/* Per-band radiance range used for the normalisation when the user gives none (src/oct_normalize_geo.cc:9-88).
+ * Returns 0, or OCTANE_E_INVALID for a band outside 1..16 (the reference leaves the outputs untouched then). */
+int octane_bandminmax(int band, float *maxch, float *minch);
+
 const char *octane_last_error(void);
 int octane_device_count(void);
 

@@ -23,7 +23,8 @@ EXPORTS = (
     "octane_vof_default_params", "octane_vof_run", "octane_vof_plan_create", "octane_vof_plan_destroy",
     "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_last_iterations",
     "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile",
-    "octane_vof_batch_run", "octane_pix2uv_run", "octane_last_error", "octane_device_count",
+    "octane_vof_batch_run", "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
+    "octane_last_error", "octane_device_count",
 )
 
 
@@ -48,6 +49,14 @@ class Nav(C.Structure):
                 ("lat1", C.c_float), ("lon1", C.c_float), ("lon0", C.c_float), ("R", C.c_float),
                 ("minX", C.c_int), ("minY", C.c_int), ("nx", C.c_int), ("ny", C.c_int)]
 
+
+class NavcalParams(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("xScale", "xOffset", "yScale", "yOffset", "radScale", "radOffset", "rpol", "req", "H",
+                                         "lam0", "fk1", "fk2", "bc1", "bc2", "kap1", "maxin", "minin", "maxout", "minout")] + \
+               [(k, C.c_int) for k in ("cal", "donav", "minx", "maxx", "miny", "maxy")]
+
+
+CAL_RAW, CAL_TEMP, CAL_REF, CAL_BRIT = 0, 1, 2, 3
 
 TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                        C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int)
@@ -112,6 +121,8 @@ def lib() -> C.CDLL:
                                        C.POINTER(C.c_int)]
     L.octane_pix2uv_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, C.c_int, C.c_int,
                                     vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
+    L.octane_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(NavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
+    L.octane_bandminmax.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.octane_last_error.restype = C.c_char_p
     L.octane_device_count.restype = C.c_int
     _lib = L
@@ -272,3 +283,28 @@ def pix2uv(nav: Nav, t1: float, t2: float, u, v, pixuv: int = 0, mode: int = NAV
         raise OctaneError(rc, "octane_pix2uv_run")
     shp = uu.shape
     return ur.reshape(shp), vr.reshape(shp), ur2.reshape(shp), vr2.reshape(shp), dT.value, moved.value
+
+
+def bandminmax(band: int):
+    """(max, min) radiance of an ABI band, ref src/oct_normalize_geo.cc:9-88."""
+    mx, mn = C.c_float(), C.c_float()
+    rc = lib().octane_bandminmax(band, C.byref(mx), C.byref(mn))
+    if rc != OK:
+        raise OctaneError(rc, "octane_bandminmax")
+    return mx.value, mn.value
+
+
+def navcal(data2, x, y, prm: NavcalParams, device: int = 0):
+    """Raw counts [ny, nx] int16 + scaled grid coordinates -> (data3, lat, lon, data2s, xs, ys) of prm's window."""
+    d2 = np.ascontiguousarray(data2, np.int16)
+    ny, nx = d2.shape
+    xx, yy = np.ascontiguousarray(x, np.int16), np.ascontiguousarray(y, np.int16)
+    ww, wh = prm.maxx - prm.minx, prm.maxy - prm.miny
+    data3, lat, lon = (np.zeros((max(wh, 0), max(ww, 0)), np.float32) for _ in range(3))
+    d2s = np.zeros((max(wh, 0), max(ww, 0)), np.int16)
+    xs, ys = np.zeros(max(ww, 0), np.int16), np.zeros(max(wh, 0), np.int16)
+    rc = lib().octane_navcal_run(_ptr(d2), _ptr(xx), _ptr(yy), nx, ny, C.byref(prm), _ptr(data3), _ptr(lat), _ptr(lon),
+                                 _ptr(d2s), _ptr(xs), _ptr(ys), device)
+    if rc != OK:
+        raise OctaneError(rc, "octane_navcal_run")
+    return data3, lat, lon, d2s, xs, ys

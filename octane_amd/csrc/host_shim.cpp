@@ -98,6 +98,41 @@ int oct_optical_flow(GOESVar &goesData, GOESVar &goesData2, OFFlags &args)
     return 1;
 }
 
+void oct_navcal_cuda(short *data2, short *data2s, short *x, short *y, short *xs, short *ys, int nx, int ny,
+                     int minx, int maxx, int miny, int maxy, float *data3, float *lat, float *lon, std::string cal,
+                     int datf, float xScale, float xOffset, float yScale, float yOffset, float radScale,
+                     float radOffset, float rpol, float req, float H, float lam0, float fk1, float fk2, float bc1,
+                     float bc2, float kap1, float maxin, float minin, float maxout, float minout, int donav,
+                     OFFlags args)
+{
+    (void)datf;   // every calibration the reference accepts sets it to 1 (ref nav:52-75)
+    octane_navcal_params p;
+    p.xScale = xScale; p.xOffset = xOffset; p.yScale = yScale; p.yOffset = yOffset;
+    p.radScale = radScale; p.radOffset = radOffset; p.rpol = rpol; p.req = req; p.H = H; p.lam0 = lam0;
+    p.fk1 = fk1; p.fk2 = fk2; p.bc1 = bc1; p.bc2 = bc2; p.kap1 = kap1;
+    p.maxin = maxin; p.minin = minin; p.maxout = maxout; p.minout = minout;
+    p.cal = (cal == "TEMP") ? OCTANE_CAL_TEMP : (cal == "REF") ? OCTANE_CAL_REF : (cal == "BRIT") ? OCTANE_CAL_BRIT : OCTANE_CAL_RAW;
+    p.donav = donav; p.minx = minx; p.maxx = maxx; p.miny = miny; p.maxy = maxy;
+    const int ndev = octane_device_count();
+    if (ndev == 0) {
+        std::cout << "No gpus available for use, exiting\n";
+        exit(0);
+    }
+    int dev = args.setdevice;
+    if (dev > ndev - 1) {
+        std::cout << "Warning: setdevice set to non-existent GPU, setting to default GPU 1\n";
+        dev = 0;
+    }
+    const int rc = octane_navcal_run(data2, x, y, nx, ny, &p, data3, lat, lon, data2s, xs, ys, dev);
+    if (rc != OCTANE_OK) std::cerr << "oct_navcal_cuda: " << octane_last_error() << " (code " << rc << ")\n";
+}
+
+void oct_bandminmax(int gb, float &maxch, float &minch)
+{
+    float mx, mn;
+    if (octane_bandminmax(gb, &mx, &mn) == OCTANE_OK) { maxch = mx; minch = mn; }
+}
+
 void octane_default_flags(OFFlags &a)         // ref src/main.cc:53-108
 {
     a.farn = 0; a.pixuv = 0; a.dosrsal = 0; a.dopolar = 0; a.domerc = 0; a.ftype = "GOES";

@@ -90,4 +90,12 @@ struct NavArgs {
 void launch_pix2uv(hipStream_t s, const NavArgs &nav, double t1, double t2, const float *u, const float *v,
                    int mode, short *ur, short *vr, short *ur2, short *vr2, long n);
 
+struct NavcalArgs {
+    float xScale, xOffset, yScale, yOffset, radScale, radOffset, rpol, req, H, lam0, fk1, fk2, bc1, bc2, kap1;
+    float maxin, minin, maxout, minout, subpoint_slope, subpoint_int;
+    int cal, donav, nx, ny, minx, maxx, miny, maxy;
+};
+void launch_navcal(hipStream_t s, const NavcalArgs &A, const short *x, const short *y, const short *data2,
+                   float *data3, float *lat, float *lon, short *data2s);
+
 }  // namespace octane

@@ -680,3 +680,78 @@ extern "C" int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, co
     if (dout) (void)hipFree(dout);
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------
+// navcal (ref src/oct_navcal_cuda.cu:100-207) and the band range table (ref src/oct_normalize_geo.cc:9-88)
+// ---------------------------------------------------------------------------------------------
+extern "C" int octane_bandminmax(int band, float *maxch, float *minch)
+{
+    // {max, min} radiance per ABI band 1..16; bands 7 and 8 carry the reference's "meteorological" ranges
+    static const float tab[16][2] = {
+        {804.03605737f, -25.93664701f}, {628.98723908f, -20.28991094f}, {373.16695681f, -12.03764377f},
+        {140.19342584f, -4.52236858f},  {94.84802665f, -3.05961376f},   {29.78947040f, -0.96095066f},
+        {2.f, 0.f},                     {6.f, 3.f},                     {44.998f, -0.2472f},
+        {79.831f, -0.2871f},            {134.93f, -0.3909f},            {108.44f, -0.4617f},
+        {185.5699f, -1.6443f},          {198.71f, -0.5154f},            {212.28f, -0.5262f},
+        {170.19f, -1.5726f}};
+    if (band < 1 || band > 16 || !maxch || !minch) return OCTANE_E_INVALID;
+    *maxch = tab[band - 1][0];
+    *minch = tab[band - 1][1];
+    return OCTANE_OK;
+}
+
+extern "C" int octane_navcal_run(const short *data2, const short *x, const short *y, int nx, int ny,
+                                 const octane_navcal_params *p, float *data3, float *lat, float *lon,
+                                 short *data2s, short *xs, short *ys, int device)
+{
+    if (!data2 || !x || !y || !p || !data3 || !lat || !lon || !data2s || !xs || !ys || nx < 1 || ny < 1 ||
+        p->minx < 0 || p->miny < 0 || p->maxx > nx || p->maxy > ny || p->maxx <= p->minx || p->maxy <= p->miny ||
+        p->cal < 0 || p->cal > 3) {
+        g_last_error = "octane_navcal_run: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    int ndev = octane_device_count();
+    if (ndev == 0) { g_last_error = "No gpus available for use"; return OCTANE_E_NODEVICE; }
+    if (device > ndev - 1 || device < 0) device = 0;
+    HIP_TRY(hipSetDevice(device));
+    const long n = (long)nx * ny, n2 = (long)(p->maxx - p->minx) * (p->maxy - p->miny);
+    for (int i = p->minx; i < p->maxx; i++) xs[i - p->minx] = x[i];       // ref nav:155-162
+    for (int j = p->miny; j < p->maxy; j++) ys[j - p->miny] = y[j];
+    NavcalArgs A;
+    A.xScale = p->xScale; A.xOffset = p->xOffset; A.yScale = p->yScale; A.yOffset = p->yOffset;
+    A.radScale = p->radScale; A.radOffset = p->radOffset; A.rpol = p->rpol; A.req = p->req; A.H = p->H; A.lam0 = p->lam0;
+    A.fk1 = p->fk1; A.fk2 = p->fk2; A.bc1 = p->bc1; A.bc2 = p->bc2; A.kap1 = p->kap1;
+    A.maxin = p->maxin; A.minin = p->minin; A.maxout = p->maxout; A.minout = p->minout;
+    A.subpoint_slope = (float)(1. / (0.021 - 0.0212));                     // ref nav:168-169
+    A.subpoint_int = (float)(1. - 0.021 * (double)A.subpoint_slope);
+    A.cal = p->cal; A.donav = p->donav; A.nx = nx; A.ny = ny;
+    A.minx = p->minx; A.maxx = p->maxx; A.miny = p->miny; A.maxy = p->maxy;
+    short *d_in = nullptr, *d_xy = nullptr, *d_s = nullptr;
+    float *d_out = nullptr;
+    hipStream_t s = nullptr;
+    int rc = OCTANE_OK;
+    do {
+        if (hipMalloc((void **)&d_in, n * sizeof(short)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&d_xy, (size_t)(nx + ny) * sizeof(short)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&d_s, n2 * sizeof(short)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&d_out, 3 * n2 * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipStreamCreate(&s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(d_in, data2, n * sizeof(short), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(d_xy, x, nx * sizeof(short), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(d_xy + nx, y, ny * sizeof(short), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        launch_navcal(s, A, d_xy, d_xy + nx, d_in, d_out, d_out + n2, d_out + 2 * n2, d_s);
+        if (hipGetLastError() != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(data3, d_out, n2 * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(lat, d_out + n2, n2 * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(lon, d_out + 2 * n2, n2 * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(data2s, d_s, n2 * sizeof(short), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+    } while (0);
+    if (rc != OCTANE_OK) g_last_error = "octane_navcal_run: HIP failure";
+    if (s) (void)hipStreamDestroy(s);
+    if (d_in) (void)hipFree(d_in);
+    if (d_xy) (void)hipFree(d_xy);
+    if (d_s) (void)hipFree(d_s);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}

@@ -32,6 +32,12 @@ class Nav(C.Structure):
                 ("minX", C.c_int), ("minY", C.c_int), ("nx", C.c_int), ("ny", C.c_int)]
 
 
+class NavcalParams(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("xScale", "xOffset", "yScale", "yOffset", "radScale", "radOffset", "rpol", "req", "H",
+                                         "lam0", "fk1", "fk2", "bc1", "bc2", "kap1", "maxin", "minin", "maxout", "minout")] + \
+               [(k, C.c_int) for k in ("cal", "donav", "minx", "maxx", "miny", "maxy")]
+
+
 _TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                         C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int)
 
@@ -166,3 +172,19 @@ def pix2uv(nav: Nav, t1: float, t2: float, u: np.ndarray, v: np.ndarray, pixuv: 
     moved = lib().oct_oracle_pix2uv(C.byref(nav), t1, t2, u.ravel(), v.ravel(), pixuv, mode, ur, vr, ur2, vr2, C.byref(dT))
     shp = u.shape
     return ur.reshape(shp), vr.reshape(shp), ur2.reshape(shp), vr2.reshape(shp), dT.value, moved
+
+
+def navcal(data2: np.ndarray, x: np.ndarray, y: np.ndarray, prm: NavcalParams):
+    """Returns (data3, lat, lon, data2s, xs, ys) for the window of prm."""
+    d2 = np.ascontiguousarray(data2, np.int16)
+    ny, nx = d2.shape
+    ww, wh = prm.maxx - prm.minx, prm.maxy - prm.miny
+    data3, lat, lon = (np.zeros((wh, ww), np.float32) for _ in range(3))
+    d2s = np.zeros((wh, ww), np.int16)
+    xs, ys = np.zeros(ww, np.int16), np.zeros(wh, np.int16)
+    L = lib()
+    L.oct_oracle_navcal.argtypes = [_S, _S, _S, C.c_int, C.c_int, C.POINTER(NavcalParams), _F, _F, _F, _S, _S, _S]
+    L.oct_oracle_navcal.restype = None
+    L.oct_oracle_navcal(d2.ravel(), np.ascontiguousarray(x, np.int16), np.ascontiguousarray(y, np.int16), nx, ny, C.byref(prm),
+                        data3.ravel(), lat.ravel(), lon.ravel(), d2s.ravel(), xs, ys)
+    return data3, lat, lon, d2s, xs, ys

@@ -70,6 +70,19 @@ typedef struct oct_oracle_nav {   /* the GOESNAVVar fields ref oct_pix2uv_cuda.c
 int oct_oracle_pix2uv(const oct_oracle_nav *nav, double t1, double t2, const float *u, const float *v,
                       int pixuv, int mode, short *ur, short *vr, short *ur2, short *vr2, float *dT);
 
+/* ---- navcal (navcal_oracle.c) ---- */
+typedef struct oct_oracle_navcal_params {
+    float xScale, xOffset, yScale, yOffset, radScale, radOffset;
+    float rpol, req, H, lam0;
+    float fk1, fk2, bc1, bc2, kap1;
+    float maxin, minin, maxout, minout;
+    int cal, donav;
+    int minx, maxx, miny, maxy;
+} oct_oracle_navcal_params;
+void oct_oracle_navcal(const short *data2, const short *x, const short *y, int nx, int ny,
+                       const oct_oracle_navcal_params *p, float *data3, float *lat, float *lon,
+                       short *data2s, short *xs, short *ys);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,84 @@
+"""navcal: raw ABI counts -> the 0..255 input the solver sees.  GPU vs CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(capi, nx, ny, band=13, cal=0):
+    rng = np.random.RandomState(5)
+    data2 = rng.randint(0, 4095, (ny, nx)).astype(np.int16)
+    # CONUS-like 2 km grid: x/y are the file's scaled shorts, xVal = x*scale + offset (radians)
+    x = np.arange(nx, dtype=np.int16)
+    y = np.arange(ny, dtype=np.int16)
+    mx, mn = capi.bandminmax(band)
+    kw = dict(xScale=5.6e-05, xOffset=-0.101332, yScale=-5.6e-05, yOffset=0.128212, radScale=0.04572892, radOffset=-1.6443,
+              rpol=6356752.31414, req=6378137.0, H=42164160.0, lam0=-1.308996939,
+              fk1=10803.3, fk2=1392.74, bc1=0.07550, bc2=0.99975, kap1=0.0015839,
+              maxin=mx, minin=mn, maxout=255.0, minout=0.0, cal=cal, donav=1, minx=0, maxx=nx, miny=0, maxy=ny)
+    return data2, x, y, kw
+
+
+def _params(cls, kw):
+    return cls(**kw)
+
+
+@pytest.mark.parametrize("cal", [0, 1, 2, 3])
+def test_navcal_matches_oracle(capi, oracle, cal):
+    nx, ny = 600, 400
+    data2, x, y, kw = _setup(capi, nx, ny, cal=cal)
+    if cal == 1:
+        data2 = np.maximum(data2, 50)            # keep radiances positive for the Planck inversion
+        kw.update(maxin=340.0, minin=180.0)
+    got = capi.navcal(data2, x, y, _params(capi.NavcalParams, kw))
+    want = oracle.navcal(data2, x, y, _params(oracle.NavcalParams, kw))
+    assert np.array_equal(got[0], want[0]), f"data3: {(got[0] != want[0]).sum()} of {got[0].size} differ"
+    for g, w, nm in zip(got[1:3], want[1:3], ("lat", "lon")):
+        assert np.array_equal(np.isnan(g), np.isnan(w)), nm       # off-earth pixels: sqrt of a negative
+        ok = ~np.isnan(w)
+        ulp = np.abs(g[ok].view(np.int32).astype(np.int64) - w[ok].view(np.int32))
+        assert ulp.max() <= 1, f"{nm}: up to {ulp.max()} ulp"
+        assert (ulp == 0).mean() > 0.999
+    for g, w in zip(got[3:], want[3:]):
+        assert np.array_equal(g, w)
+    assert 0 <= got[0].min() and got[0].max() <= 260 or cal == 1
+
+
+def test_window_and_limb_taper(capi, oracle):
+    """A full-disk-like coarse grid: the limb taper (0.021 .. 0.0212 rad^2) and off-disk pixels, on a sub-window."""
+    nx, ny = 500, 500
+    data2, x, y, kw = _setup(capi, nx, ny)
+    kw.update(xScale=6.2e-04, xOffset=-0.1547, yScale=-6.2e-04, yOffset=0.1547, donav=0, minx=37, maxx=411, miny=20, maxy=489)
+    got = capi.navcal(data2, x, y, _params(capi.NavcalParams, kw))
+    want = oracle.navcal(data2, x, y, _params(oracle.NavcalParams, kw))
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert got[0].shape == (469, 374) and not got[1].any()          # donav=0 -> lat/lon zero
+    assert (got[0] == 0).any() and (got[0] > 0).any()                # tapered to zero outside the disk
+    assert np.array_equal(got[3], data2[20:489, 37:411])
+
+
+def test_band_table(capi):
+    assert capi.bandminmax(13) == (pytest.approx(185.5699), pytest.approx(-1.6443))   # C13, SURVEY 8d
+    assert capi.bandminmax(7) == (2.0, 0.0) and capi.bandminmax(8) == (6.0, 3.0)     # "meteorological" ranges
+    with pytest.raises(capi.OctaneError):
+        capi.bandminmax(17)
+
+
+def test_counts_to_winds_chain(capi, oracle):
+    """navcal -> flow -> pix2uv, all through the C-ABI, against the oracle chain."""
+    from conftest import rel_l2
+    from octane_amd import synth
+    nx, ny = 160, 128
+    a, b = synth.lattice_scene(nx, ny, seed=3)
+    _, x, y, kw = _setup(capi, nx, ny)
+    inv = lambda img: np.round((img[0] / 255.0 * (kw["maxin"] - kw["minin"]) + kw["minin"] - kw["radOffset"]) / kw["radScale"]).astype(np.int16)
+    c1, c2 = inv(a), inv(b)
+    g1 = capi.navcal(c1, x, y, _params(capi.NavcalParams, kw))[0]
+    g2 = capi.navcal(c2, x, y, _params(capi.NavcalParams, kw))[0]
+    o1 = oracle.navcal(c1, x, y, _params(oracle.NavcalParams, kw))[0]
+    o2 = oracle.navcal(c2, x, y, _params(oracle.NavcalParams, kw))[0]
+    assert np.array_equal(g1, o1) and np.array_equal(g2, o2)
+    u, v = capi.flow(g1, g2, capi.FlowParams(kiters=3))
+    uo, vo, _ = oracle.flow(o1, o2, oracle.FlowParams(kiters=3), dot_threads=oracle.REF_GRID_THREADS)
+    assert rel_l2(u, v, uo, vo) < 2e-5
