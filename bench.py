@@ -48,8 +48,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs (not used by the driver): OCTANE_BENCH_BACKEND=gloo and OCTANE_BENCH_ONE_DEVICE=1 let several
+    # ranks share one GPU so that the N>1 control flow can be exercised on a one-GPU box.
+    backend = os.environ.get("OCTANE_BENCH_BACKEND", "nccl")
+    if os.environ.get("OCTANE_BENCH_ONE_DEVICE") == "1":
+        local = 0
     if world > 1:   # one process per GPU over RCCL; only the barrier and the max-over-ranks time use it
-        shard.init_from_env("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            shard.init_from_env("nccl", device_id=torch.device("cuda", local))
+        else:
+            shard.init_from_env(backend)
     if capi.lib().octane_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -80,7 +88,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev if backend == "nccl" else None)
     iters = plan.last_iterations()
     expect = args.kiters * 3 * args.liters * args.cgiters
     ms_per_step = elapsed * 1e3 / args.steps
@@ -142,7 +150,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan=1 "
-                                      f"alpha=5 lambda=1 (BASELINE.json configs[2], SURVEY 8d run R1), "
+                                      f"alpha=5 lambda=1" + (" (BASELINE.json configs[2], SURVEY 8d run R1), " if (n, args.kiters, args.liters, args.cgiters) == (5000, 8, 3, 30) else ", ") + 
                                       f"{iters} PCG iterations per pyramid (expected {expect}), one pair per GPU",
                           "sharding": "independent pairs, no data-path collective"},
                "roofline": roof, "cpu_baseline": cpu}

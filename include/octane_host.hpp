@@ -18,9 +18,14 @@ void oct_variational_optical_flow(Image geo1i, Image geo2i, float *CTH, float *u
 void oct_pix2uv_cuda(GOESVar &goesData, double t2, float *uarr, float *varr, short *ur, short *vr,
                      short *ur2, short *vr2, OFFlags args);
 
-// ref src/oct_optical_flow.cc:21-111: zero / first-guess initialisation, solver dispatch, CTP scaling,
-// pix2uv.  -sosm, -firstguess and -srsal belong to components outside this library's scope and are reported.
+// ref src/oct_optical_flow.cc:21-111: zero / first-guess initialisation (oct_uv2pix), solver dispatch, CTP scaling,
+// pix2uv, optional -srsal.  -sosm (patch matching) is outside this library's scope and is reported.
 int oct_optical_flow(GOESVar &goesData, GOESVar &goesData2, OFFlags &args);
+
+// ref src/oct_pix2uv_cuda.cu:372: first-guess winds in u/v (m/s) -> pixel displacements, using goesData.latVal/lonVal/x/y
+void oct_uv2pix(GOESVar &goesData, float *u, float *v, double t2, OFFlags args);
+// ref src/oct_srsal_cuda.cu:73: bilateral smoothing of the flow, in place
+void oct_srsal_cu(float *upix, float *vpix, float *CTHsub21, int nx, int ny, OFFlags args);
 
 // ref src/oct_navcal_cuda.cu:100 (called by the GOES reader, src/oct_fileread.cc): raw counts -> calibrated, navigated,
 // 0..255-normalised image of the window [minx,maxx) x [miny,maxy).  cal is "RAW" | "TEMP" | "REF" | "BRIT".

@@ -144,6 +144,17 @@ int octane_navcal_run(const short *data2, const short *x, const short *y, int nx
  * Returns 0, or OCTANE_E_INVALID for a band outside 1..16 (the reference leaves the outputs untouched then). */
 int octane_bandminmax(int band, float *maxch, float *minch);
 
+/* ---- optional steps next to the path ----
+ * octane_uv2pix_run <- void oct_uv2pix(GOESVar&,float*,float*,double,OFFlags), src/oct_pix2uv_cuda.cu:372:
+ *   first-guess winds u,v (m/s, in place -> pixel displacements) at lat/lon (degrees) of an nx x ny GOES fixed-grid
+ *   frame whose scaled coordinates are gx[nx], gy[ny].  If the two frames' offsets differ (sector moved) or the
+ *   projected point is off the disk, the displacement is 0.
+ * octane_srsal_run  <- void oct_srsal_cu(float*,float*,float*,int,int,OFFlags), src/oct_srsal_cuda.cu:73:
+ *   37x37 bilateral smoothing of u,v (in place) guided by the cloud-top-height image (sigma 9 px / 20 units). */
+int octane_uv2pix_run(const octane_nav *nav, double t1, double t2, float *u_inout, float *v_inout,
+                      const float *lat, const float *lon, const short *gx, const short *gy, int device);
+int octane_srsal_run(float *u_inout, float *v_inout, const float *cth, int nx, int ny, int device);
+
 const char *octane_last_error(void);
 int octane_device_count(void);
 

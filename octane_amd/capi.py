@@ -24,6 +24,7 @@ EXPORTS = (
     "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_last_iterations",
     "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile",
     "octane_vof_batch_run", "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
+    "octane_uv2pix_run", "octane_srsal_run",
     "octane_last_error", "octane_device_count",
 )
 
@@ -123,6 +124,8 @@ def lib() -> C.CDLL:
                                     vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     L.octane_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(NavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
     L.octane_bandminmax.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.octane_uv2pix_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.octane_srsal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
     L.octane_last_error.restype = C.c_char_p
     L.octane_device_count.restype = C.c_int
     _lib = L
@@ -308,3 +311,25 @@ def navcal(data2, x, y, prm: NavcalParams, device: int = 0):
     if rc != OK:
         raise OctaneError(rc, "octane_navcal_run")
     return data3, lat, lon, d2s, xs, ys
+
+
+def uv2pix(nav: Nav, t1: float, t2: float, u, v, lat, lon, gx, gy, device: int = 0):
+    """First-guess winds (m/s) -> pixel displacements; returns new (u, v)."""
+    uu = np.array(u, np.float32, order="C", copy=True); vv = np.array(v, np.float32, order="C", copy=True)
+    la, lo = _f32(lat), _f32(lon)
+    xx, yy = np.ascontiguousarray(gx, np.int16), np.ascontiguousarray(gy, np.int16)
+    rc = lib().octane_uv2pix_run(C.byref(nav), t1, t2, _ptr(uu), _ptr(vv), _ptr(la), _ptr(lo), _ptr(xx), _ptr(yy), device)
+    if rc != OK:
+        raise OctaneError(rc, "octane_uv2pix_run")
+    return uu, vv
+
+
+def srsal(u, v, cth, device: int = 0):
+    """37x37 bilateral smoothing of the flow guided by cth; returns new (u, v)."""
+    uu = np.array(u, np.float32, order="C", copy=True); vv = np.array(v, np.float32, order="C", copy=True)
+    cc = _f32(cth)
+    ny, nx = uu.shape
+    rc = lib().octane_srsal_run(_ptr(uu), _ptr(vv), _ptr(cc), nx, ny, device)
+    if rc != OK:
+        raise OctaneError(rc, "octane_srsal_run")
+    return uu, vv

@@ -71,13 +71,8 @@ int oct_optical_flow(GOESVar &goesData, GOESVar &goesData2, OFFlags &args)
         goesData.uPix = new float[n];
         goesData.vPix = new float[n];
         for (long i = 0; i < n; i++) { goesData.uPix[i] = 0.f; goesData.vPix[i] = 0.f; }
-    } else {
-        // oct_uv2pix (de-navigation of a first-guess wind file) is outside this library:
-        // the caller must have filled uPix/vPix in pixels already.
-        if (!goesData.uPix || !goesData.vPix) {
-            printf("First guess requested but uPix/vPix are not set (oct_uv2pix is not part of this library), exiting\n");
-            exit(0);
-        }
+    } else {                                 // first-guess file holds navigated winds: ref oct_optical_flow.cc:49-53
+        oct_uv2pix(goesData, goesData.uPix, goesData.vPix, goesData2.t, args);
     }
     const int nc = 1 + args.doc2 + args.doc3;
     if (args.dososm == 1) {
@@ -93,9 +88,46 @@ int oct_optical_flow(GOESVar &goesData, GOESVar &goesData2, OFFlags &args)
     }
     oct_pix2uv_cuda(goesData, goesData2.t, goesData.uPix, goesData.vPix, ur, vr, ur2, vr2, args);
     goesData.uVal = ur; goesData.vVal = vr; goesData.uVal2 = ur2; goesData.vVal2 = vr2;
-    if (args.dosrsal == 1) std::cout << "-srsal smoothing is not part of this library; flow left unsmoothed\n";
+    if (args.dosrsal == 1) {                 // ref oct_optical_flow.cc:100-105
+        std::cout << "Beginning anisotropic smoothing\n";
+        oct_srsal_cu(goesData.uPix, goesData.vPix, goesData.CTHVal, nx, ny, args);
+        std::cout << "Finished\n";
+    }
     if (args.doCTH == 1) goesData.CTP = CTP;
     return 1;
+}
+
+static int pick_device(const OFFlags &args)
+{
+    const int ndev = octane_device_count();
+    if (ndev == 0) {
+        std::cout << "No gpus available for use, exiting\n";
+        exit(0);
+    }
+    int dev = args.setdevice;
+    if (dev > ndev - 1) {
+        std::cout << "Warning: setdevice set to non-existent GPU, setting to default GPU 1\n";
+        dev = 0;
+    }
+    return dev;
+}
+
+void oct_uv2pix(GOESVar &g, float *u, float *v, double t2, OFFlags args)
+{
+    octane_nav nav;
+    nav.pph = g.nav.pph; nav.req = g.nav.req; nav.rpol = g.nav.rpol; nav.lam0 = g.nav.lam0;
+    nav.xScale = g.nav.xScale; nav.xOffset = g.nav.xOffset; nav.yScale = g.nav.yScale; nav.yOffset = g.nav.yOffset;
+    nav.g2xOffset = g.nav.g2xOffset; nav.g2yOffset = g.nav.g2yOffset;
+    nav.lat1 = g.nav.lat1; nav.lon1 = g.nav.lon1; nav.lon0 = g.nav.lon0; nav.R = g.nav.R;
+    nav.minX = g.nav.minX; nav.minY = g.nav.minY; nav.nx = (int)g.nav.nx; nav.ny = (int)g.nav.ny;
+    const int rc = octane_uv2pix_run(&nav, g.t, t2, u, v, g.latVal, g.lonVal, g.x, g.y, pick_device(args));
+    if (rc != OCTANE_OK) std::cerr << "oct_uv2pix: " << octane_last_error() << " (code " << rc << ")\n";
+}
+
+void oct_srsal_cu(float *upix, float *vpix, float *CTHsub21, int nx, int ny, OFFlags args)
+{
+    const int rc = octane_srsal_run(upix, vpix, CTHsub21, nx, ny, pick_device(args));
+    if (rc != OCTANE_OK) std::cerr << "oct_srsal_cu: " << octane_last_error() << " (code " << rc << ")\n";
 }
 
 void oct_navcal_cuda(short *data2, short *data2s, short *x, short *y, short *xs, short *ys, int nx, int ny,

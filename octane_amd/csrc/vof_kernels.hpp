@@ -98,4 +98,16 @@ struct NavcalArgs {
 void launch_navcal(hipStream_t s, const NavcalArgs &A, const short *x, const short *y, const short *data2,
                    float *data3, float *lat, float *lon, short *data2s);
 
+struct Uv2pixArgs {
+    double secs, req, req2, rpol, rpol2, eval, lam0, pph;
+    float xscale, xoffset, yscale, yoffset;
+    int nx, ny;
+};
+void launch_uv2pix(hipStream_t s, const Uv2pixArgs &A, const float *u, const float *v, const float *lat, const float *lon,
+                   const short *gx, const short *gy, float *upix, float *vpix);
+
+struct SrsalArgs { double gk[37]; double sigpix2; };
+void launch_srsal(hipStream_t s, const float *u, const float *v, const float *cth, int nx, int ny, const SrsalArgs &A,
+                  float *uo, float *vo);
+
 }  // namespace octane

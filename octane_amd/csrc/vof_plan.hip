@@ -755,3 +755,103 @@ extern "C" int octane_navcal_run(const short *data2, const short *x, const short
     if (d_out) (void)hipFree(d_out);
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------
+// uv2pix (ref src/oct_pix2uv_cuda.cu:372-476) and srsal (ref src/oct_srsal_cuda.cu:73-147)
+// ---------------------------------------------------------------------------------------------
+extern "C" int octane_uv2pix_run(const octane_nav *nav, double t1, double t2, float *u, float *v,
+                                 const float *lat, const float *lon, const short *gx, const short *gy, int device)
+{
+    if (!nav || !u || !v || !lat || !lon || !gx || !gy || nav->nx < 1 || nav->ny < 1) {
+        g_last_error = "octane_uv2pix_run: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    const long n = (long)nav->nx * nav->ny;
+    if (!((nav->xOffset == nav->g2xOffset) && (nav->yOffset == nav->g2yOffset))) {   // ref p2u:421,457-467
+        for (long k = 0; k < n; k++) { u[k] = 0.f; v[k] = 0.f; }
+        return OCTANE_OK;
+    }
+    int ndev = octane_device_count();
+    if (ndev == 0) { g_last_error = "No gpus available for use"; return OCTANE_E_NODEVICE; }
+    if (device > ndev - 1 || device < 0) device = 0;
+    HIP_TRY(hipSetDevice(device));
+    Uv2pixArgs A;
+    A.secs = t2 - t1; A.req = nav->req; A.rpol = nav->rpol; A.lam0 = nav->lam0; A.pph = nav->pph;
+    A.req2 = nav->req * nav->req; A.rpol2 = nav->rpol * nav->rpol;
+    const double e = std::sqrt((A.req2 - A.rpol2) / (A.req2));           // ref p2u:417-419,428
+    A.eval = e * e;
+    A.xscale = nav->xScale; A.xoffset = nav->xOffset; A.yscale = nav->yScale; A.yoffset = nav->yOffset;
+    A.nx = nav->nx; A.ny = nav->ny;
+    float *d = nullptr;
+    short *dxy = nullptr;
+    hipStream_t s = nullptr;
+    int rc = OCTANE_OK;
+    do {
+        if (hipMalloc((void **)&d, 6 * n * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&dxy, (size_t)(nav->nx + nav->ny) * sizeof(short)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipStreamCreate(&s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        const float *src[4] = {u, v, lat, lon};
+        bool ok = true;
+        for (int i = 0; i < 4 && ok; i++) ok = hipMemcpyAsync(d + i * n, src[i], n * sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(dxy, gx, nav->nx * sizeof(short), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(dxy + nav->nx, gy, nav->ny * sizeof(short), hipMemcpyHostToDevice, s) == hipSuccess;
+        if (!ok) { rc = OCTANE_E_HIP; break; }
+        launch_uv2pix(s, A, d, d + n, d + 2 * n, d + 3 * n, dxy, dxy + nav->nx, d + 4 * n, d + 5 * n);
+        if (hipGetLastError() != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(u, d + 4 * n, n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(v, d + 5 * n, n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+    } while (0);
+    if (rc != OCTANE_OK) g_last_error = "octane_uv2pix_run: HIP failure";
+    if (s) (void)hipStreamDestroy(s);
+    if (d) (void)hipFree(d);
+    if (dxy) (void)hipFree(dxy);
+    return rc;
+}
+
+extern "C" int octane_srsal_run(float *u, float *v, const float *cth, int nx, int ny, int device)
+{
+    if (!u || !v || !cth || nx < 1 || ny < 1) {
+        g_last_error = "octane_srsal_run: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    int ndev = octane_device_count();
+    if (ndev == 0) { g_last_error = "No gpus available for use"; return OCTANE_E_NODEVICE; }
+    if (device > ndev - 1 || device < 0) device = 0;
+    HIP_TRY(hipSetDevice(device));
+    SrsalArgs A;
+    {   // ref srsal:75-82 with oct_getGaussian_1D (ref src/oct_gaussian.cc:34-47): 37 taps, sigma 9, normalised
+        const double sigpix = 20.;
+        A.sigpix2 = -1. / (sigpix * sigpix * 2.);
+        const double sigma = 9;
+        const int wk2 = 18;
+        const double sg = 2.0 * sigma * sigma;
+        double sum = 0.0;
+        for (int x = -wk2; x <= wk2; x++) {
+            const double r = x;
+            A.gk[x + wk2] = (std::exp(-(r * r) / sg)) / (M_PI * sg);
+            sum += A.gk[x + wk2];
+        }
+        for (int i = 0; i < 37; ++i) A.gk[i] /= sum;
+    }
+    const long n = (long)nx * ny;
+    float *d = nullptr;
+    hipStream_t s = nullptr;
+    int rc = OCTANE_OK;
+    do {
+        if (hipMalloc((void **)&d, 5 * n * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipStreamCreate(&s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(d, u, n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(d + n, v, n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(d + 2 * n, cth, n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        launch_srsal(s, d, d + n, d + 2 * n, nx, ny, A, d + 3 * n, d + 4 * n);
+        if (hipGetLastError() != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(u, d + 3 * n, n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(v, d + 4 * n, n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+    } while (0);
+    if (rc != OCTANE_OK) g_last_error = "octane_srsal_run: HIP failure";
+    if (s) (void)hipStreamDestroy(s);
+    if (d) (void)hipFree(d);
+    return rc;
+}

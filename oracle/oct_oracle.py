@@ -188,3 +188,24 @@ def navcal(data2: np.ndarray, x: np.ndarray, y: np.ndarray, prm: NavcalParams):
     L.oct_oracle_navcal(d2.ravel(), np.ascontiguousarray(x, np.int16), np.ascontiguousarray(y, np.int16), nx, ny, C.byref(prm),
                         data3.ravel(), lat.ravel(), lon.ravel(), d2s.ravel(), xs, ys)
     return data3, lat, lon, d2s, xs, ys
+
+
+def uv2pix(nav: Nav, t1: float, t2: float, u, v, lat, lon, gx, gy):
+    uu = np.array(u, np.float32, order="C", copy=True); vv = np.array(v, np.float32, order="C", copy=True)
+    L = lib()
+    L.oct_oracle_uv2pix.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, _F, _F, _F, _F, _S, _S]
+    L.oct_oracle_uv2pix.restype = None
+    L.oct_oracle_uv2pix(C.byref(nav), t1, t2, uu.ravel(), vv.ravel(), np.ascontiguousarray(lat, np.float32).ravel(),
+                        np.ascontiguousarray(lon, np.float32).ravel(), np.ascontiguousarray(gx, np.int16), np.ascontiguousarray(gy, np.int16))
+    return uu, vv
+
+
+def srsal(u, v, cth):
+    uu = np.ascontiguousarray(u, np.float32); vv = np.ascontiguousarray(v, np.float32); cc = np.ascontiguousarray(cth, np.float32)
+    ny, nx = uu.shape
+    uo, vo = np.zeros_like(uu), np.zeros_like(vv)
+    L = lib()
+    L.oct_oracle_srsal.argtypes = [_F, _F, _F, C.c_int, C.c_int, _F, _F]
+    L.oct_oracle_srsal.restype = None
+    L.oct_oracle_srsal(uu.ravel(), vv.ravel(), cc.ravel(), nx, ny, uo.ravel(), vo.ravel())
+    return uo, vo

@@ -83,6 +83,11 @@ void oct_oracle_navcal(const short *data2, const short *x, const short *y, int n
                        const oct_oracle_navcal_params *p, float *data3, float *lat, float *lon,
                        short *data2s, short *xs, short *ys);
 
+/* ---- uv2pix / srsal (post_oracle.c) ---- */
+void oct_oracle_uv2pix(const oct_oracle_nav *nav, double t1, double t2, float *u_inout, float *v_inout,
+                       const float *lat, const float *lon, const short *gx, const short *gy);
+void oct_oracle_srsal(float *u, float *v, const float *cth, int nx, int ny, float *uo, float *vo);
+
 #ifdef __cplusplus
 }
 #endif
