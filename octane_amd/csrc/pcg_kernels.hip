@@ -566,18 +566,27 @@ static int pass_b_grid_size(int w, int h)
     return g;
 }
 
-static int g_pass_a_variant = 2;   // rows per thread of the tiled kernel: 1, 2 (default) or 4; 3 = LDS-ring marching (experiment)
-void set_pass_a_variant(int v) { g_pass_a_variant = (v == 1 || v == 2 || v == 3 || v == 4) ? v : 2; }
+// Tile height of pass A.  Default (0): 128 x 16 tiles (R = 2) from one Mpixel up, 128 x 8 (R = 1) below -- measured
+// per level at 5000^2: R = 2 is 5 % faster at 5000^2 and 7 % at 1250^2, R = 1 is 7-15 % faster at 156^2 .. 625^2
+// where the taller tile leaves too few workgroups.  OCTANE_TUNE_PASS_A forces 1, 2, 4 or 3 (= LDS-ring marching).
+static int g_pass_a_variant = 0;
+void set_pass_a_variant(int v) { g_pass_a_variant = (v >= 0 && v <= 4) ? v : 0; }
+static int pass_a_choice(int w, int h)
+{
+    if (g_pass_a_variant != 0) return g_pass_a_variant;
+    return ((long)w * h >= (1L << 20)) ? 2 : 1;
+}
 
 int pcg_grid_size(int w, int h)
 {
-    if (g_pass_a_variant == 3) {   // marching: at least 8 rows per workgroup, 3 workgroups per CU resident (168 VGPRs)
+    const int variant = pass_a_choice(w, h);
+    if (variant == 3) {   // marching: at least 8 rows per workgroup, 3 workgroups per CU resident (168 VGPRs)
         long rows = (long)((w + kMarchW - 1) / kMarchW) * h;
         long g = rows / 8;
         if (g < 1) g = 1;
         return (int)(g > 768 ? 768 : g);
     }
-    const int R = g_pass_a_variant;
+    const int R = variant;
     const long items = (long)((w + kTileX - 1) / kTileX) * ((h + kTileY * R - 1) / (kTileY * R));
     if (R == 1) return balanced_grid(items);             // 52 VGPRs: 8 workgroups per CU resident
     const long cap = (R == 2) ? 768 : 512;               // 148 / 236 VGPRs: 3 / 2 workgroups per CU resident
@@ -588,7 +597,7 @@ int pcg_grid_size(int w, int h)
 
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
-    switch (g_pass_a_variant) {
+    switch (pass_a_choice(L.w, L.h)) {
     case 1: hipLaunchKernelGGL(k_pcg_pass_a<1>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
     case 4: hipLaunchKernelGGL(k_pcg_pass_a<4>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
     case 3: hipLaunchKernelGGL(k_pcg_pass_a_ring, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
