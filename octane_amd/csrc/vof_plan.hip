@@ -139,6 +139,62 @@ extern "C" int octane_vof_plan_destroy(octane_vof_plan *pl)
     return OCTANE_OK;
 }
 
+static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, const float *lev1, const float *lev2,
+                            const float *ut, const float *vt, LevelPtrs &L)
+{
+    L.w = li.w; L.h = li.h; L.pitch = li.pitch; L.nc = pl->nc; L.cstride = pl->plane0;
+    L.img1 = lev1; L.img2 = lev2;
+    L.gx1 = pl->gx1; L.gy1 = pl->gy1; L.gx2 = pl->gx2; L.gy2 = pl->gy2;
+    L.gxx = pl->gxx; L.gxy = pl->gxy; L.gyy = pl->gyy;
+    L.u = pl->U[cur]; L.v = pl->V[cur]; L.ut = ut; L.vt = vt;
+    L.a1 = pl->a1; L.a2 = pl->a2; L.a4 = pl->a4; L.wx = pl->wx; L.wy = pl->wy; L.mu = pl->mu; L.mv = pl->mv;
+    L.ru = pl->ru; L.rv = pl->rv;
+    L.pu[0] = pl->pu[0]; L.pu[1] = pl->pu[1]; L.pv[0] = pl->pv[0]; L.pv[1] = pl->pv[1];
+    L.qu = pl->qu; L.qv = pl->qv; L.xu = pl->xu; L.xv = pl->xv;
+    L.part_rz = pl->d_parts; L.part_rr = pl->d_parts + kMaxParts; L.part_pq = pl->d_parts + 2 * kMaxParts;
+    L.st = pl->d_state; L.iter_total = pl->d_iters; L.alpha = pl->d_alpha; L.defer_x = pl->defer_x;
+    L.reverse_b = pl->reverse_b;
+    L.xcd_bands = pl->xcd_bands;
+    L.nt_hints = pl->nt_hints;
+}
+
+// Times a few PCG iterations of the finest level on whatever the arena holds (the values do not matter, only
+// the addresses).  Returns milliseconds per iteration, or -1 on failure.
+static double probe_placement(octane_vof_plan *pl)
+{
+    const LevelInfo &li = pl->lev.back();
+    LevelPtrs L;
+    fill_level_ptrs(pl, li, 0, pl->img1p, pl->img2p, pl->uh, pl->vh, L);
+    const int g_a = pcg_grid_size(li.w, li.h), g_b = pcg_b_grid_size(li.w, li.h);
+    std::vector<double> ones(2 * kMaxParts, 1.0);
+    PcgState st[2];
+    st[0].rz = 1.f; st[0].stopped = 0; st[0].iters = 0; st[0].pad = 0;
+    st[1] = st[0];
+    hipStream_t s = pl->own_stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.;
+    double ms_out = -1.;
+    const int reps = 5;
+    bool ok = true;
+    for (int it = 1; it <= reps && ok; it++) {     // it = 1 is a warm-up
+        if (it == 2) ok = hipEventRecord(e0, s) == hipSuccess;
+        // keep the stop test open whatever the previous pass wrote
+        ok = ok && hipMemcpyAsync(pl->d_parts, ones.data(), 2 * kMaxParts * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(pl->d_state, st, sizeof(st), hipMemcpyHostToDevice, s) == hipSuccess;
+        launch_pcg_pass_a(s, L, it, g_b, g_a, 0.f);
+        launch_pcg_pass_b(s, L, it, g_a, g_b);
+    }
+    ok = ok && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess;
+    if (ok) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ms_out = ms / (reps - 1);
+    } else {
+        (void)hipGetLastError();
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms_out;
+}
+
 extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int nchan, const octane_vof_params *p)
 {
     if (!out || !p || nx < 2 || ny < 2 || nchan < 1 || nchan > kMaxChan || p->kiters < 1 || p->kiters > 24 ||
@@ -200,7 +256,14 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
 
     const int nc = nchan;
     const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 17 + 1;
-    pl->arena_bytes = nplanes * pl->plane0 * sizeof(float);
+    size_t skew = 0;                              // developer knob: stagger the planes' base addresses (floats)
+    if (const char *e = getenv("OCTANE_TUNE_SKEW")) skew = (size_t)atol(e) / 64 * 64;
+    size_t align_f = 0;                           // developer knob: round the plane stride up to a multiple (bytes)
+    if (const char *e = getenv("OCTANE_TUNE_PLANE_ALIGN")) align_f = (size_t)atol(e) / 4;
+    size_t stride = pl->plane0;
+    if (align_f) stride = (stride + align_f - 1) / align_f * align_f;
+    stride += skew;
+    pl->arena_bytes = nplanes * stride * sizeof(float) + (size_t)(4 << 20);
     hipError_t e = hipMalloc((void **)&pl->arena, pl->arena_bytes);
     if (e != hipSuccess) {
         g_last_error = std::string("hipMalloc of the plan arena failed: ") + hipGetErrorString(e);
@@ -214,19 +277,28 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
         octane_vof_plan_destroy(pl);
         return OCTANE_E_HIP;
     }
-    float *cur = pl->arena;
-    auto take = [&](size_t n) { float *r = cur; cur += n * pl->plane0; return r; };
-    pl->img1p = take(nc); pl->img2p = take(nc); pl->uh = take(1); pl->vh = take(1);
-    pl->lev1 = take(nc); pl->lev2 = take(nc);
-    pl->gx1 = take(nc); pl->gy1 = take(nc); pl->gx2 = take(nc); pl->gy2 = take(nc);
-    pl->gxx = take(nc); pl->gxy = take(nc); pl->gyy = take(nc);
-    pl->U[0] = take(1); pl->U[1] = take(1); pl->V[0] = take(1); pl->V[1] = take(1);
-    pl->ut = take(1); pl->vt = take(1);
-    pl->a1 = take(1); pl->a2 = take(1); pl->a4 = take(1); pl->wx = take(1); pl->wy = take(1); pl->mu = take(1); pl->mv = take(1);
-    pl->ru = take(1); pl->rv = take(1);
-    pl->pu[0] = take(1); pl->pu[1] = take(1); pl->pv[0] = take(1); pl->pv[1] = take(1);
-    pl->qu = take(1); pl->qv = take(1); pl->xu = take(1); pl->xv = take(1);
-    pl->tmp = take(1);
+    // plane pointers for an arena starting at `base`
+    auto carve = [&](float *base) {
+        float *cur = base;
+        if (align_f) {   // start the first plane on the same alignment
+            uintptr_t a = (uintptr_t)cur, al = align_f * 4 > (4u << 20) ? (4u << 20) : align_f * 4;
+            cur = (float *)((a + al - 1) / al * al);
+        }
+        // multi-channel fields are addressed as base + c * plane0, so their planes stay plane0 apart
+        auto take = [&](size_t n) { float *r = cur; cur += (n - 1) * pl->plane0 + stride; return r; };
+        pl->img1p = take(nc); pl->img2p = take(nc); pl->uh = take(1); pl->vh = take(1);
+        pl->lev1 = take(nc); pl->lev2 = take(nc);
+        pl->gx1 = take(nc); pl->gy1 = take(nc); pl->gx2 = take(nc); pl->gy2 = take(nc);
+        pl->gxx = take(nc); pl->gxy = take(nc); pl->gyy = take(nc);
+        pl->U[0] = take(1); pl->U[1] = take(1); pl->V[0] = take(1); pl->V[1] = take(1);
+        pl->ut = take(1); pl->vt = take(1);
+        pl->a1 = take(1); pl->a2 = take(1); pl->a4 = take(1); pl->wx = take(1); pl->wy = take(1); pl->mu = take(1); pl->mv = take(1);
+        pl->ru = take(1); pl->rv = take(1);
+        pl->pu[0] = take(1); pl->pu[1] = take(1); pl->pv[0] = take(1); pl->pv[1] = take(1);
+        pl->qu = take(1); pl->qv = take(1); pl->xu = take(1); pl->xv = take(1);
+        pl->tmp = take(1);
+    };
+    carve(pl->arena);
 
     int rc = OCTANE_OK;
     do {
@@ -249,6 +321,39 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
         g_last_error = "octane_vof_plan_create: device allocation failed";
         octane_vof_plan_destroy(pl);
         return rc;
+    }
+    // Placement trials.  Where the arena lands in physical memory decides how the 13 concurrent streams of a PCG
+    // pass spread over the HBM channels: the same binary runs pass A at 245 or 264 us at 5000^2 depending on the
+    // allocation alone.  For large frames a few candidate arenas are therefore allocated, a short
+    // pass A / pass B sequence is timed on each, the fastest is kept and the others are freed.
+    int trials = 4;
+    if (const char *e = getenv("OCTANE_TUNE_PLACEMENT_TRIALS")) trials = atoi(e);
+    if (trials > 4) trials = 4;
+    if (trials > 1 && (long)nx * ny >= (1L << 22) && pl->arena_bytes < ((size_t)24 << 30)) {
+        float *cand[4] = {pl->arena, nullptr, nullptr, nullptr};
+        double ms[4] = {0, 0, 0, 0};
+        int ncand = 1;
+        for (int t = 1; t < trials; t++) {
+            if (hipMalloc((void **)&cand[t], pl->arena_bytes) != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
+            ncand = t + 1;
+        }
+        int best = 0;
+        for (int t = 0; t < ncand; t++) {
+            carve(cand[t]);
+            ms[t] = probe_placement(pl);
+            if (ms[t] > 0 && (ms[best] <= 0 || ms[t] < ms[best])) best = t;
+        }
+        if (getenv("OCTANE_TUNE_VERBOSE"))
+            fprintf(stderr, "[octane] placement trials: %.4f %.4f %.4f %.4f ms per PCG iteration -> candidate %d\n", ms[0], ms[1], ms[2], ms[3], best);
+        for (int t = 0; t < ncand; t++)
+            if (t != best) (void)hipFree(cand[t]);
+        pl->arena = cand[best];
+        carve(pl->arena);
+        if (hipMemset(pl->arena, 0xFF, pl->arena_bytes) != hipSuccess) {      // restore the poison the probe disturbed
+            g_last_error = "hipMemset of the plan arena failed";
+            octane_vof_plan_destroy(pl);
+            return OCTANE_E_HIP;
+        }
     }
     *out = pl;
     return OCTANE_OK;
@@ -394,20 +499,7 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         }
 
         LevelPtrs L;
-        L.w = li.w; L.h = li.h; L.pitch = li.pitch; L.nc = nc; L.cstride = pl->plane0;
-        L.img1 = lev1; L.img2 = lev2;
-        L.gx1 = pl->gx1; L.gy1 = pl->gy1; L.gx2 = pl->gx2; L.gy2 = pl->gy2;
-        L.gxx = pl->gxx; L.gxy = pl->gxy; L.gyy = pl->gyy;
-        L.u = pl->U[cur]; L.v = pl->V[cur]; L.ut = ut; L.vt = vt;
-        L.a1 = pl->a1; L.a2 = pl->a2; L.a4 = pl->a4; L.wx = pl->wx; L.wy = pl->wy; L.mu = pl->mu; L.mv = pl->mv;
-        L.ru = pl->ru; L.rv = pl->rv;
-        L.pu[0] = pl->pu[0]; L.pu[1] = pl->pu[1]; L.pv[0] = pl->pv[0]; L.pv[1] = pl->pv[1];
-        L.qu = pl->qu; L.qv = pl->qv; L.xu = pl->xu; L.xv = pl->xv;
-        L.part_rz = pl->d_parts; L.part_rr = pl->d_parts + kMaxParts; L.part_pq = pl->d_parts + 2 * kMaxParts;
-        L.st = pl->d_state; L.iter_total = pl->d_iters; L.alpha = pl->d_alpha; L.defer_x = pl->defer_x;
-        L.reverse_b = pl->reverse_b;
-        L.xcd_bands = pl->xcd_bands;
-        L.nt_hints = pl->nt_hints;
+        fill_level_ptrs(pl, li, cur, lev1, lev2, ut, vt, L);
 
         const int g_asm = assemble_grid_size(li.w, li.h);
         const int g_a = pcg_grid_size(li.w, li.h);
