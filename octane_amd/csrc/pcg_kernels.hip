@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
     __shared__ double s_red[8];
     const int tid = threadIdx.x;
 
+    const PcgState prev = L.st[k & 1];                               // requested together with the partials
     const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
     const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
-    const PcgState prev = L.st[k & 1];
     const bool active = (prev.stopped == 0) && (rr > tol);          // ref .cu:1131
     if (!active) {
         if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
@@ -205,6 +205,210 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
                     if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
                     sumu += a1[q][e] * npu[q][e]; sumv += a2[q][e] * npu[q][e];
                     sumu += a2[q][e] * npv[q][e]; sumv += a4[q][e] * npv[q][e];
+                    if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
+                    if (y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
+                    qu[e] = sumu; qv[e] = sumv;
+                    if (i < w) { rowdot += npu[q][e] * sumu; rowdot += npv[q][e] * sumv; }
+                }
+                const size_t o = (size_t)y * pitch + x;
+                st4(pout_u + o, *(float4 *)npu[q]);
+                st4(pout_v + o, *(float4 *)npv[q]);
+                st4(L.qu + o, *(float4 *)qu);
+                st4(L.qv + o, *(float4 *)qv);
+                acc += (double)rowdot;
+            }
+        }
+        __syncthreads();
+    }
+    const double tot = block_sum_256(acc, s_red);
+    if (tid == 0) L.part_pq[blockIdx.x] = tot;
+}
+
+template <int R>
+struct PassATile {            // everything one workgroup iteration loads, per thread
+    float ru[R][4], rv[R][4], pu[R][4], pv[R][4];
+    float a1[R][4], a4[R][4], a2[R][4], wxc[R][4], wyc[R][4], wys[R][4];
+    float wxw[R];
+    float hr[6][4];           // halo-row lanes (tid < 64): r_u r_v a1 a4 p_u p_v of one float4 group
+    float hs[6];              // halo-column lanes: the same six values of one pixel
+};
+
+// Latency-oriented form of pass A for the levels below one Mpixel (R = 1 there): loads and arithmetic are separate
+// phases so that the first tile's operands can be requested before the reduction partials and the solve state --
+// one memory round trip instead of three.  It holds everything in registers at once (185 VGPRs), which does not
+// matter at these sizes (one or two workgroups per CU).
+template <int R>
+__global__ __launch_bounds__(256) void k_pcg_pass_a_lat(LevelPtrs L, int k, int nparts_prev, float tol)
+{
+    constexpr int TY = kTileY * R;
+    __shared__ __attribute__((aligned(16))) float s_pu[(TY + 2) * kLRow];
+    __shared__ __attribute__((aligned(16))) float s_pv[(TY + 2) * kLRow];
+    __shared__ double s_red[8];
+    const int tid = threadIdx.x;
+    const bool first = (k == 0);
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int tiles_x = (w + kTileX - 1) / kTileX, tiles_y = (h + TY - 1) / TY;
+    const int ntiles = tiles_x * tiles_y;
+    const int lx = tid & 31, ly = tid >> 5;
+    const float *__restrict__ pin_u = L.pu[k & 1];
+    const float *__restrict__ pin_v = L.pv[k & 1];
+    float *__restrict__ pout_u = L.pu[(k + 1) & 1];
+    float *__restrict__ pout_v = L.pv[(k + 1) & 1];
+    const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
+
+    // Phase 1 of a tile: nothing but loads -- none of them depends on beta or on the stop decision.
+    auto load_tile = [&](int t, PassATile<R> &g) {
+        const int tx0 = (t % tiles_x) * kTileX, ty0 = (t / tiles_x) * TY;
+        const int x = tx0 + lx * 4;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int y = ty0 + ly + kTileY * q;
+            const size_t o = (size_t)y * pitch + x;
+            g.wxw[q] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                g.ru[q][e] = 0.f; g.rv[q][e] = 0.f; g.pu[q][e] = 0.f; g.pv[q][e] = 0.f;
+                g.a1[q][e] = 1.f; g.a4[q][e] = 1.f; g.a2[q][e] = 0.f; g.wxc[q][e] = 0.f; g.wyc[q][e] = 0.f; g.wys[q][e] = 0.f;
+            }
+            if ((y < h) && (x < w)) {
+                *(float4 *)g.ru[q] = ld4(L.ru + o);
+                *(float4 *)g.rv[q] = ld4(L.rv + o);
+                *(float4 *)g.a1[q] = ld4(L.a1 + o);
+                *(float4 *)g.a4[q] = ld4(L.a4 + o);
+                *(float4 *)g.a2[q] = ld4_if(L.a2 + o, L.nt_hints & 8);
+                *(float4 *)g.wxc[q] = ld4(L.wx + o);
+                *(float4 *)g.wyc[q] = ld4(L.wy + o);
+                if (y > 0) *(float4 *)g.wys[q] = ld4(L.wy + o - pitch);
+                if (x > 0) g.wxw[q] = L.wx[o - 1];
+                if (!first) { *(float4 *)g.pu[q] = ld4(pin_u + o); *(float4 *)g.pv[q] = ld4(pin_v + o); }
+            }
+        }
+        if (tid < 64) {                                  // rows above and below the tile
+            const int hy = (tid < 32) ? ty0 - 1 : ty0 + TY;
+            const int hx = tx0 + (tid & 31) * 4;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) g.hr[c][e] = (c == 2 || c == 3) ? 1.f : 0.f;
+            if (hy >= 0 && hy < h && hx < w) {
+                const size_t ho = (size_t)hy * pitch + hx;
+                *(float4 *)g.hr[0] = ld4(L.ru + ho); *(float4 *)g.hr[1] = ld4(L.rv + ho);
+                *(float4 *)g.hr[2] = ld4(L.a1 + ho); *(float4 *)g.hr[3] = ld4(L.a4 + ho);
+                if (!first) { *(float4 *)g.hr[4] = ld4(pin_u + ho); *(float4 *)g.hr[5] = ld4(pin_v + ho); }
+            }
+        } else if (tid < 64 + 2 * TY) {                  // columns left and right of the tile
+            const int side = (tid - 64) / TY, row = (tid - 64) % TY;
+            const int hy = ty0 + row;
+            const int hx = side ? tx0 + kTileX : tx0 - 1;
+            g.hs[0] = 0.f; g.hs[1] = 0.f; g.hs[2] = 1.f; g.hs[3] = 1.f; g.hs[4] = 0.f; g.hs[5] = 0.f;
+            if (hy < h && hx >= 0 && hx < w) {
+                const size_t ho = (size_t)hy * pitch + hx;
+                g.hs[0] = L.ru[ho]; g.hs[1] = L.rv[ho]; g.hs[2] = L.a1[ho]; g.hs[3] = L.a4[ho];
+                if (!first) { g.hs[4] = pin_u[ho]; g.hs[5] = pin_v[ho]; }
+            }
+        }
+    };
+
+    // At the coarse levels a pass is a chain of memory round trips; the first tile's operands are therefore
+    // requested before the reduction partials and the solve state, so that all of it is one round trip.
+    PassATile<R> g;
+    bool preloaded = false;
+    if (tr.first < tr.end) { load_tile(tr.first, g); preloaded = true; }
+
+    const PcgState prev = L.st[k & 1];
+    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
+    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
+    // the reference's loop test: while (residc > tol && ki < iters)   (ref .cu:1131)
+    const bool active = (prev.stopped == 0) && (rr > tol);
+    if (!active) {
+        if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
+        return;
+    }
+    const float beta = first ? 0.f : rz_new / prev.rz;
+    if (blockIdx.x == 0 && tid == 0) {
+        PcgState n; n.rz = rz_new; n.stopped = 0; n.iters = prev.iters + 1; n.pad = 0;
+        L.st[(k + 1) & 1] = n;
+    }
+    double acc = 0.;
+
+    for (int t = tr.first; t < tr.end; t += tr.step) {
+        if (!(preloaded && t == tr.first)) load_tile(t, g);
+        const int tx0 = (t % tiles_x) * kTileX, ty0 = (t / tiles_x) * TY;
+        const int x = tx0 + lx * 4;
+        // Phase 2: p_new = M^-1 r + beta p for the tile and its one-pixel halo, into LDS
+        float npu[R][4], npv[R][4];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int y = ty0 + ly + kTileY * q;
+            const bool rowok = (y < h) && (x < w);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool ok = rowok && (x + e) < w;
+                npu[q][e] = ok ? direction(g.ru[q][e], g.pu[q][e], g.a1[q][e], beta, first) : 0.f;
+                npv[q][e] = ok ? direction(g.rv[q][e], g.pv[q][e], g.a4[q][e], beta, first) : 0.f;
+            }
+            st4(&s_pu[(ly + kTileY * q + 1) * kLRow + kLInt + lx * 4], *(float4 *)npu[q]);
+            st4(&s_pv[(ly + kTileY * q + 1) * kLRow + kLInt + lx * 4], *(float4 *)npv[q]);
+        }
+        if (tid < 64) {
+            const int hy = (tid < 32) ? ty0 - 1 : ty0 + TY;
+            const int hx = tx0 + (tid & 31) * 4;
+            const int lrow = (tid < 32) ? 0 : TY + 1;
+            const bool in = hy >= 0 && hy < h && hx < w;
+            float hu[4], hv[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool ok = in && (hx + e) < w;
+                hu[e] = ok ? direction(g.hr[0][e], g.hr[4][e], g.hr[2][e], beta, first) : 0.f;
+                hv[e] = ok ? direction(g.hr[1][e], g.hr[5][e], g.hr[3][e], beta, first) : 0.f;
+            }
+            st4(&s_pu[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hu);
+            st4(&s_pv[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hv);
+        } else if (tid < 64 + 2 * TY) {
+            const int side = (tid - 64) / TY, row = (tid - 64) % TY;
+            const int hy = ty0 + row;
+            const int hx = side ? tx0 + kTileX : tx0 - 1;
+            const bool in = hy < h && hx >= 0 && hx < w;
+            const float hu = in ? direction(g.hs[0], g.hs[4], g.hs[2], beta, first) : 0.f;
+            const float hv = in ? direction(g.hs[1], g.hs[5], g.hs[3], beta, first) : 0.f;
+            const int lcol = side ? kLInt + kTileX : kLInt - 1;
+            s_pu[(row + 1) * kLRow + lcol] = hu;
+            s_pv[(row + 1) * kLRow + lcol] = hv;
+        }
+        __syncthreads();
+        // Phase 3: q = A p_new.  Row entries in the reference's storage order -- south, west, block, east, north --
+        // with the merged border weights of ref .cu:929-1001
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int y = ty0 + ly + kTileY * q;
+            const int lrow = ly + kTileY * q;
+            if ((y < h) && (x < w)) {
+                float su[4], sv[4], nu[4], nv[4];
+                *(float4 *)su = ld4(&s_pu[lrow * kLRow + kLInt + lx * 4]);
+                *(float4 *)sv = ld4(&s_pv[lrow * kLRow + kLInt + lx * 4]);
+                *(float4 *)nu = ld4(&s_pu[(lrow + 2) * kLRow + kLInt + lx * 4]);
+                *(float4 *)nv = ld4(&s_pv[(lrow + 2) * kLRow + kLInt + lx * 4]);
+                const float uwest = s_pu[(lrow + 1) * kLRow + kLInt + lx * 4 - 1];
+                const float vwest = s_pv[(lrow + 1) * kLRow + kLInt + lx * 4 - 1];
+                const float ueast = s_pu[(lrow + 1) * kLRow + kLInt + lx * 4 + 4];
+                const float veast = s_pv[(lrow + 1) * kLRow + kLInt + lx * 4 + 4];
+                float qu[4], qv[4];
+                float rowdot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = x + e;
+                    const float pwu = (e == 0) ? uwest : npu[q][(e + 3) & 3], pwv = (e == 0) ? vwest : npv[q][(e + 3) & 3];
+                    const float peu = (e == 3) ? ueast : npu[q][(e + 1) & 3], pev = (e == 3) ? veast : npv[q][(e + 1) & 3];
+                    const float a5 = (e == 0) ? g.wxw[q] : g.wxc[q][(e + 3) & 3];
+                    const float wS = (y == h - 1) ? g.wys[q][e] + g.wyc[q][e] : g.wys[q][e];
+                    const float wW = (i == w - 1) ? a5 + g.wxc[q][e] : a5;
+                    const float wE = (i == 0) ? g.wxc[q][e] + g.wxc[q][e] : g.wxc[q][e];
+                    const float wN = (y == 0) ? g.wyc[q][e] + g.wyc[q][e] : g.wyc[q][e];
+                    float sumu = 0.f, sumv = 0.f;
+                    if (y > 0) { sumu += wS * su[e]; sumv += wS * sv[e]; }
+                    if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
+                    sumu += g.a1[q][e] * npu[q][e]; sumv += g.a2[q][e] * npu[q][e];
+                    sumu += g.a2[q][e] * npv[q][e]; sumv += g.a4[q][e] * npv[q][e];
                     if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
                     if (y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
                     qu[e] = sumu; qv[e] = sumv;
@@ -470,9 +674,9 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
     BOperands cur, nxt;
     pass_b_issue(L, k, xmode, cr, cr.first, ngroups, gw, pitch, cur);
 
-    const PcgState st = L.st[(k + 1) & 1];
-    if (st.stopped) return;
+    const PcgState st = L.st[(k + 1) & 1];          // requested together with the partials: one round trip
     const float pq = (float)fold_partials_256(L.part_pq, nparts_a, s_red);
+    if (st.stopped) return;
     const float alpha = st.rz / pq;                        // ref .cu:1169
     const float nalpha = (float)(-1. * (double)alpha);     // ref .cu:1174
     const float alpha_prev = (xmode >= XMODE_PAIR_FIRST) ? L.alpha[(k - 1) & 1] : 0.f;
@@ -588,8 +792,7 @@ int pcg_grid_size(int w, int h)
     }
     const int R = variant;
     const long items = (long)((w + kTileX - 1) / kTileX) * ((h + kTileY * R - 1) / (kTileY * R));
-    if (R == 1) return balanced_grid(items);             // 52 VGPRs: 8 workgroups per CU resident
-    const long cap = (R == 2) ? 768 : 512;               // 148 / 236 VGPRs: 3 / 2 workgroups per CU resident
+    const long cap = (R == 2) ? 768 : 512;               // 185 / 148 / 236 VGPRs: 2 / 3 / 2 workgroups per CU resident
     if (items <= cap) return (int)items;
     const long rounds = (items + cap - 1) / cap;
     return (int)((items + rounds - 1) / rounds);
@@ -598,7 +801,7 @@ int pcg_grid_size(int w, int h)
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
     switch (pass_a_choice(L.w, L.h)) {
-    case 1: hipLaunchKernelGGL(k_pcg_pass_a<1>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    case 1: hipLaunchKernelGGL(k_pcg_pass_a_lat<1>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
     case 4: hipLaunchKernelGGL(k_pcg_pass_a<4>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
     case 3: hipLaunchKernelGGL(k_pcg_pass_a_ring, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
     default: hipLaunchKernelGGL(k_pcg_pass_a<2>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;

@@ -685,28 +685,34 @@ extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const 
         g_last_error = "octane_vof_batch_run: invalid argument";
         return OCTANE_E_INVALID;
     }
-    std::vector<int> rcs(ndevices, OCTANE_OK);
-    std::vector<std::string> errs(ndevices);
+    // Frames up to ~8 Mpixel leave the GPU latency-bound on their coarse levels, so each device gets two lanes (two
+    // plans, two streams, two host threads) whose kernels interleave; larger frames are bandwidth-bound and get one.
+    int lanes = ((long)nx * ny <= (8L << 20)) ? 2 : 1;
+    if (const char *e = getenv("OCTANE_TUNE_BATCH_LANES")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
+    const int nworkers = ndevices * lanes;
+    std::vector<int> rcs(nworkers, OCTANE_OK);
+    std::vector<std::string> errs(nworkers);
     std::vector<std::thread> workers;
-    for (int d = 0; d < ndevices; d++) {
-        workers.emplace_back([&, d]() {
+    for (int wk = 0; wk < nworkers; wk++) {
+        workers.emplace_back([&, wk]() {
+            const int d = wk % ndevices, lane = wk / ndevices;
             octane_vof_params prm = *p;
             prm.device = devices ? devices[d] : d;
             octane_vof_plan *pl = nullptr;
-            bool any = false;
-            for (int b = d; b < npairs; b += ndevices) { any = true; break; }
-            if (!any) return;
+            // pair b belongs to device b % ndevices; a device's pairs alternate between its lanes
+            const int first = d + ndevices * lane, step = ndevices * lanes;
+            if (first >= npairs) return;
             int rc = octane_vof_plan_create(&pl, nx, ny, nchan, &prm);
-            for (int b = d; rc == OCTANE_OK && b < npairs; b += ndevices)
+            for (int b = first; rc == OCTANE_OK && b < npairs; b += step)
                 rc = octane_vof_plan_run(pl, img1[b], img2[b], u[b], v[b], OCTANE_MEM_HOST, nullptr);
-            if (rc != OCTANE_OK) errs[d] = g_last_error;
-            rcs[d] = rc;
+            if (rc != OCTANE_OK) errs[wk] = g_last_error;
+            rcs[wk] = rc;
             octane_vof_plan_destroy(pl);
         });
     }
     for (auto &t : workers) t.join();
-    for (int d = 0; d < ndevices; d++)
-        if (rcs[d] != OCTANE_OK) { g_last_error = errs[d]; return rcs[d]; }
+    for (int wk = 0; wk < nworkers; wk++)
+        if (rcs[wk] != OCTANE_OK) { g_last_error = errs[wk]; return rcs[wk]; }
     return OCTANE_OK;
 }
 

@@ -33,6 +33,11 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
                 if short.startswith("k_pcg_pass_a"):
                     short = "k_pcg_pass_a"
                 agg[short].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        if "k_assemble" in agg:      # placement-trial launches precede the first assembly
+            d_first = min(d for d, _ in agg["k_assemble"])
+            for k in ("k_pcg_pass_a", "k_pcg_pass_b"):
+                if k in agg:
+                    agg[k] = [x for x in agg[k] if x[0] > d_first]
         for k, n in per_level.items():
             if k not in agg:
                 continue
@@ -87,6 +92,13 @@ def main():
                 short = "k_pcg_pass_a"
             rows[short].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])))
             meta[short] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Workgroup_Size_X"])
+    # the plan's placement trials (vof_plan.hip) launch a few PCG passes before the first pyramid: drop everything
+    # that starts before the first assembly
+    if "k_assemble" in rows:
+        t_first = min(r[0] for r in rows["k_assemble"])
+        for k in ("k_pcg_pass_a", "k_pcg_pass_b"):
+            if k in rows:
+                rows[k] = [r for r in rows[k] if r[0] > t_first]
     per_level = {"k_pcg_pass_a": 3 * liters * cgiters, "k_pcg_pass_b": 3 * liters * cgiters,
                  "k_assemble": 3 * liters, "k_flow_update": 3 * liters}
     # levels of at most 6144 pixels are solved by k_pcg_solve_small (one launch per solve, flow update included)
