@@ -95,6 +95,12 @@ typedef struct octane_vof_profile {
 } octane_vof_profile;
 int octane_vof_plan_set_profiling(octane_vof_plan *plan, int enable);
 int octane_vof_plan_get_profile(octane_vof_plan *plan, octane_vof_profile *out);
+/* Diagnostic: time `iterations` (>= 2) PCG iterations of pyramid level `level` (0 = coarsest) in isolation, on
+ * whatever the plan's planes hold (the stop test is held open, values are irrelevant, the planes are clobbered). */
+/* Developer knob (what the OCTANE_TUNE_* environment variables set): key in {pass_a, max_blocks, reverse_b, xcd, nt,
+ * defer_x, small}.  Results are the same for every setting; only speed changes. */
+int octane_vof_tune(octane_vof_plan *plan, const char *key, int value);
+int octane_vof_plan_probe(octane_vof_plan *plan, int level, int iterations, double *pass_a_ms, double *pass_b_ms);
 
 /* Independent pairs sharded over GPUs: pair b runs on devices[b % ndevices]; one host thread per
  * device; no collective.  Pointer arrays have npairs entries of host buffers laid out as above. */

@@ -22,7 +22,7 @@ NAV_GEOS, NAV_POLAR, NAV_MERC = 0, 1, 2
 EXPORTS = (
     "octane_vof_default_params", "octane_vof_run", "octane_vof_plan_create", "octane_vof_plan_destroy",
     "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_last_iterations",
-    "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile",
+    "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_probe", "octane_vof_tune",
     "octane_vof_batch_run", "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
     "octane_uv2pix_run", "octane_srsal_run",
     "octane_last_error", "octane_device_count",
@@ -117,6 +117,8 @@ def lib() -> C.CDLL:
     L.octane_vof_plan_set_trace.argtypes = [vp, TRACE_FN, vp]
     L.octane_vof_plan_set_profiling.argtypes = [vp, C.c_int]
     L.octane_vof_plan_get_profile.argtypes = [vp, C.POINTER(VofProfile)]
+    L.octane_vof_tune.argtypes = [vp, C.c_char_p, C.c_int]
+    L.octane_vof_plan_probe.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.octane_vof_batch_run.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int,
                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(VofParams), C.c_int,
                                        C.POINTER(C.c_int)]
@@ -227,6 +229,19 @@ class Plan:
 
     def set_profiling(self, on: bool):
         lib().octane_vof_plan_set_profiling(self._h, 1 if on else 0)
+
+    def tune(self, key: str, value: int):
+        rc = lib().octane_vof_tune(self._h, key.encode(), value)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_tune")
+
+    def probe(self, level: int, iterations: int = 20):
+        """(pass A ms, pass B ms) of one pyramid level timed in isolation (diagnostic; clobbers the planes)."""
+        a, b = C.c_double(), C.c_double()
+        rc = lib().octane_vof_plan_probe(self._h, level, iterations, C.byref(a), C.byref(b))
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_plan_probe")
+        return a.value, b.value
 
     def profile(self) -> VofProfile:
         p = VofProfile()

@@ -66,12 +66,15 @@ __device__ __forceinline__ float direction(float r, float pold, float diag, floa
 // r, p_old and the diagonal of the neighbouring pixels), then q = A p_new is formed from LDS + registers.  R = 2
 // (128 x 16) is the default: against R = 1 the two halo rows are amortised over 16 rows and there are half as many
 // barriers per pixel (-6 % time); R = 4 needs 236 VGPRs and loses more in occupancy than it saves.
-template <int R>
+template <int R, bool WIDE>
 __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int nparts_prev, float tol)
 {
-    constexpr int TY = kTileY * R;
-    __shared__ __attribute__((aligned(16))) float s_pu[(TY + 2) * kLRow];
-    __shared__ __attribute__((aligned(16))) float s_pv[(TY + 2) * kLRow];
+    constexpr int TY = WIDE ? kTileY : kTileY * R;          // tile rows
+    constexpr int TX = WIDE ? kTileX * R : kTileX;          // tile columns
+    constexpr int LROW = TX + 8;                             // LDS row: [3 pad][west][TX interior][east][3 pad]
+    constexpr int HL = TX / 4;                               // float4 lanes per halo row
+    __shared__ __attribute__((aligned(16))) float s_pu[(TY + 2) * LROW];
+    __shared__ __attribute__((aligned(16))) float s_pv[(TY + 2) * LROW];
     __shared__ double s_red[8];
     const int tid = threadIdx.x;
 
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
     }
 
     const int w = L.w, h = L.h, pitch = L.pitch;
-    const int tiles_x = (w + kTileX - 1) / kTileX, tiles_y = (h + TY - 1) / TY;
+    const int tiles_x = (w + TX - 1) / TX, tiles_y = (h + TY - 1) / TY;
     const int ntiles = tiles_x * tiles_y;
     const int lx = tid & 31, ly = tid >> 5;
     double acc = 0.;
@@ -102,13 +105,14 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
 
     const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
     for (int t = tr.first; t < tr.end; t += tr.step) {
-        const int tx0 = (t % tiles_x) * kTileX, ty0 = (t / tiles_x) * TY;
-        const int x = tx0 + lx * 4;
+        const int tx0 = (t % tiles_x) * TX, ty0 = (t / tiles_x) * TY;
         float a1[R][4], a4[R][4], a2[R][4], wxc[R][4], wyc[R][4], wys[R][4], npu[R][4], npv[R][4];
         float wxw[R];
 #pragma unroll
         for (int q = 0; q < R; q++) {
-            const int y = ty0 + ly + kTileY * q;
+            const int x = tx0 + lx * 4 + (WIDE ? kTileX * q : 0);
+            const int y = ty0 + ly + (WIDE ? 0 : kTileY * q);
+            const int lrow1 = ly + (WIDE ? 0 : kTileY * q) + 1, lcol = kLInt + lx * 4 + (WIDE ? kTileX * q : 0);
             const bool rowok = (y < h) && (x < w);
             const size_t o = (size_t)y * pitch + x;
             float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0};
@@ -134,14 +138,14 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
                     npv[q][e] = ok ? direction(rv[e], pv[e], a4[q][e], beta, first) : 0.f;
                 }
             }
-            st4(&s_pu[(ly + kTileY * q + 1) * kLRow + kLInt + lx * 4], *(float4 *)npu[q]);
-            st4(&s_pv[(ly + kTileY * q + 1) * kLRow + kLInt + lx * 4], *(float4 *)npv[q]);
+            st4(&s_pu[lrow1 * LROW + lcol], *(float4 *)npu[q]);
+            st4(&s_pv[lrow1 * LROW + lcol], *(float4 *)npv[q]);
         }
         // one-pixel halo of p_new, recomputed from r, p_old and the diagonal
-        if (tid < 64) {                                  // rows above and below the tile
-            const int hy = (tid < 32) ? ty0 - 1 : ty0 + TY;
-            const int hx = tx0 + (tid & 31) * 4;
-            const int lrow = (tid < 32) ? 0 : TY + 1;
+        if (tid < 2 * HL) {                              // rows above and below the tile
+            const int hy = (tid < HL) ? ty0 - 1 : ty0 + TY;
+            const int hx = tx0 + (tid % HL) * 4;
+            const int lrow = (tid < HL) ? 0 : TY + 1;
             float hu[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0};
             if (hy >= 0 && hy < h && hx < w) {
                 const size_t ho = (size_t)hy * pitch + hx;
@@ -156,12 +160,12 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
                     hv[e] = ok ? direction(r1[e], q1[e], d1[e], beta, first) : 0.f;
                 }
             }
-            st4(&s_pu[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hu);
-            st4(&s_pv[lrow * kLRow + kLInt + (tid & 31) * 4], *(float4 *)hv);
-        } else if (tid < 64 + 2 * TY) {                  // columns left and right of the tile
-            const int side = (tid - 64) / TY, row = (tid - 64) % TY;
+            st4(&s_pu[lrow * LROW + kLInt + (tid % HL) * 4], *(float4 *)hu);
+            st4(&s_pv[lrow * LROW + kLInt + (tid % HL) * 4], *(float4 *)hv);
+        } else if (tid < 2 * HL + 2 * TY) {              // columns left and right of the tile
+            const int side = (tid - 2 * HL) / TY, row = (tid - 2 * HL) % TY;
             const int hy = ty0 + row;
-            const int hx = side ? tx0 + kTileX : tx0 - 1;
+            const int hx = side ? tx0 + TX : tx0 - 1;
             float hu = 0.f, hv = 0.f;
             if (hy < h && hx >= 0 && hx < w) {
                 const size_t ho = (size_t)hy * pitch + hx;
@@ -169,25 +173,26 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
                 hu = direction(L.ru[ho], q0, L.a1[ho], beta, first);
                 hv = direction(L.rv[ho], q1, L.a4[ho], beta, first);
             }
-            const int lcol = side ? kLInt + kTileX : kLInt - 1;
-            s_pu[(row + 1) * kLRow + lcol] = hu;
-            s_pv[(row + 1) * kLRow + lcol] = hv;
+            const int lcol = side ? kLInt + TX : kLInt - 1;
+            s_pu[(row + 1) * LROW + lcol] = hu;
+            s_pv[(row + 1) * LROW + lcol] = hv;
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < R; q++) {
-            const int y = ty0 + ly + kTileY * q;
-            const int lrow = ly + kTileY * q;
+            const int x = tx0 + lx * 4 + (WIDE ? kTileX * q : 0);
+            const int y = ty0 + ly + (WIDE ? 0 : kTileY * q);
+            const int lrow = ly + (WIDE ? 0 : kTileY * q), lc = kLInt + lx * 4 + (WIDE ? kTileX * q : 0);
             if ((y < h) && (x < w)) {
                 float su[4], sv[4], nu[4], nv[4];
-                *(float4 *)su = ld4(&s_pu[lrow * kLRow + kLInt + lx * 4]);
-                *(float4 *)sv = ld4(&s_pv[lrow * kLRow + kLInt + lx * 4]);
-                *(float4 *)nu = ld4(&s_pu[(lrow + 2) * kLRow + kLInt + lx * 4]);
-                *(float4 *)nv = ld4(&s_pv[(lrow + 2) * kLRow + kLInt + lx * 4]);
-                const float uwest = s_pu[(lrow + 1) * kLRow + kLInt + lx * 4 - 1];
-                const float vwest = s_pv[(lrow + 1) * kLRow + kLInt + lx * 4 - 1];
-                const float ueast = s_pu[(lrow + 1) * kLRow + kLInt + lx * 4 + 4];
-                const float veast = s_pv[(lrow + 1) * kLRow + kLInt + lx * 4 + 4];
+                *(float4 *)su = ld4(&s_pu[lrow * LROW + lc]);
+                *(float4 *)sv = ld4(&s_pv[lrow * LROW + lc]);
+                *(float4 *)nu = ld4(&s_pu[(lrow + 2) * LROW + lc]);
+                *(float4 *)nv = ld4(&s_pv[(lrow + 2) * LROW + lc]);
+                const float uwest = s_pu[(lrow + 1) * LROW + lc - 1];
+                const float vwest = s_pv[(lrow + 1) * LROW + lc - 1];
+                const float ueast = s_pu[(lrow + 1) * LROW + lc + 4];
+                const float veast = s_pv[(lrow + 1) * LROW + lc + 4];
                 float qu[4], qv[4];
                 float rowdot = 0.f;
 #pragma unroll
@@ -774,7 +779,7 @@ static int pass_b_grid_size(int w, int h)
 // per level at 5000^2: R = 2 is 5 % faster at 5000^2 and 7 % at 1250^2, R = 1 is 7-15 % faster at 156^2 .. 625^2
 // where the taller tile leaves too few workgroups.  OCTANE_TUNE_PASS_A forces 1, 2, 4 or 3 (= LDS-ring marching).
 static int g_pass_a_variant = 0;
-void set_pass_a_variant(int v) { g_pass_a_variant = (v >= 0 && v <= 4) ? v : 0; }
+void set_pass_a_variant(int v) { g_pass_a_variant = (v >= 0 && v <= 5) ? v : 0; }
 static int pass_a_choice(int w, int h)
 {
     if (g_pass_a_variant != 0) return g_pass_a_variant;
@@ -790,8 +795,9 @@ int pcg_grid_size(int w, int h)
         if (g < 1) g = 1;
         return (int)(g > 768 ? 768 : g);
     }
-    const int R = variant;
-    const long items = (long)((w + kTileX - 1) / kTileX) * ((h + kTileY * R - 1) / (kTileY * R));
+    const int R = (variant == 5) ? 2 : variant;          // 5 = two sub-tiles side by side (256 x 8)
+    const long items = (variant == 5) ? (long)((w + 2 * kTileX - 1) / (2 * kTileX)) * ((h + kTileY - 1) / kTileY)
+                                      : (long)((w + kTileX - 1) / kTileX) * ((h + kTileY * R - 1) / (kTileY * R));
     const long cap = (R == 2) ? 768 : 512;               // 185 / 148 / 236 VGPRs: 2 / 3 / 2 workgroups per CU resident
     if (items <= cap) return (int)items;
     const long rounds = (items + cap - 1) / cap;
@@ -802,9 +808,10 @@ void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev
 {
     switch (pass_a_choice(L.w, L.h)) {
     case 1: hipLaunchKernelGGL(k_pcg_pass_a_lat<1>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
-    case 4: hipLaunchKernelGGL(k_pcg_pass_a<4>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    case 5: hipLaunchKernelGGL((k_pcg_pass_a<2, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    case 4: hipLaunchKernelGGL((k_pcg_pass_a<4, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
     case 3: hipLaunchKernelGGL(k_pcg_pass_a_ring, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
-    default: hipLaunchKernelGGL(k_pcg_pass_a<2>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    default: hipLaunchKernelGGL((k_pcg_pass_a<2, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
     }
 }
 

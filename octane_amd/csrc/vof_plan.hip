@@ -160,9 +160,19 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
 
 // Times a few PCG iterations of the finest level on whatever the arena holds (the values do not matter, only
 // the addresses).  Returns milliseconds per iteration, or -1 on failure.
+static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms, double *b_ms);
+
 static double probe_placement(octane_vof_plan *pl)
 {
-    const LevelInfo &li = pl->lev.back();
+    return probe_level(pl, (int)pl->lev.size() - 1, 5, nullptr, nullptr);
+}
+
+// Times `reps` PCG iterations (pass A + pass B) of one pyramid level on whatever the planes hold; the stop test is
+// kept open by rewriting the partials before every pass A.  Returns ms per iteration (first iteration excluded);
+// with a_ms/b_ms non-null the two passes are also timed separately (one event pair per launch).
+static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms, double *b_ms)
+{
+    const LevelInfo &li = pl->lev[level];
     LevelPtrs L;
     fill_level_ptrs(pl, li, 0, pl->img1p, pl->img2p, pl->uh, pl->vh, L);
     const int g_a = pcg_grid_size(li.w, li.h), g_b = pcg_b_grid_size(li.w, li.h);
@@ -174,23 +184,41 @@ static double probe_placement(octane_vof_plan *pl)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.;
     double ms_out = -1.;
-    const int reps = 5;
     bool ok = true;
+    std::vector<hipEvent_t> ev;
+    const bool split = a_ms && b_ms;
+    if (split) {
+        ev.resize(3 * (size_t)reps);
+        for (auto &e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    }
     for (int it = 1; it <= reps && ok; it++) {     // it = 1 is a warm-up
         if (it == 2) ok = hipEventRecord(e0, s) == hipSuccess;
         // keep the stop test open whatever the previous pass wrote
         ok = ok && hipMemcpyAsync(pl->d_parts, ones.data(), 2 * kMaxParts * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
         ok = ok && hipMemcpyAsync(pl->d_state, st, sizeof(st), hipMemcpyHostToDevice, s) == hipSuccess;
+        if (split) ok = ok && hipEventRecord(ev[3 * (it - 1)], s) == hipSuccess;
         launch_pcg_pass_a(s, L, it, g_b, g_a, 0.f);
+        if (split) ok = ok && hipEventRecord(ev[3 * (it - 1) + 1], s) == hipSuccess;
         launch_pcg_pass_b(s, L, it, g_a, g_b);
+        if (split) ok = ok && hipEventRecord(ev[3 * (it - 1) + 2], s) == hipSuccess;
     }
     ok = ok && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess;
     if (ok) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ms_out = ms / (reps - 1);
+        if (split) {
+            double sa = 0., sb = 0.;
+            for (int it = 2; it <= reps; it++) {
+                float x = 0.f;
+                (void)hipEventElapsedTime(&x, ev[3 * (it - 1)], ev[3 * (it - 1) + 1]); sa += x;
+                (void)hipEventElapsedTime(&x, ev[3 * (it - 1) + 1], ev[3 * (it - 1) + 2]); sb += x;
+            }
+            *a_ms = sa / (reps - 1); *b_ms = sb / (reps - 1);
+        }
     } else {
         (void)hipGetLastError();
     }
+    for (auto &e : ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms_out;
 }
@@ -952,4 +980,33 @@ extern "C" int octane_srsal_run(float *u, float *v, const float *cth, int nx, in
     if (s) (void)hipStreamDestroy(s);
     if (d) (void)hipFree(d);
     return rc;
+}
+
+// Diagnostic: time the two PCG passes of one pyramid level in isolation (values in the planes are irrelevant).
+extern "C" int octane_vof_plan_probe(octane_vof_plan *pl, int level, int iterations, double *pass_a_ms, double *pass_b_ms)
+{
+    if (!pl || level < 0 || level >= (int)pl->lev.size() || iterations < 2 || !pass_a_ms || !pass_b_ms) {
+        g_last_error = "octane_vof_plan_probe: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(pl->device));
+    if (probe_level(pl, level, iterations, pass_a_ms, pass_b_ms) < 0) { g_last_error = "octane_vof_plan_probe failed"; return OCTANE_E_HIP; }
+    return OCTANE_OK;
+}
+
+// Developer knob setter (the same knobs the OCTANE_TUNE_* environment variables set at plan creation).
+extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
+{
+    if (!key) return OCTANE_E_INVALID;
+    const std::string k(key);
+    if (k == "pass_a") { set_pass_a_variant(value); return OCTANE_OK; }
+    if (k == "max_blocks") { set_max_blocks(value); return OCTANE_OK; }
+    if (!pl) return OCTANE_E_INVALID;
+    if (k == "reverse_b") pl->reverse_b = value != 0;
+    else if (k == "xcd") { pl->xcd_bands = value != 0; set_grid_multiple(value ? 8 : 1); }
+    else if (k == "nt") pl->nt_hints = value;
+    else if (k == "defer_x") pl->defer_x = value != 0;
+    else if (k == "small") pl->use_small = value != 0;
+    else return OCTANE_E_INVALID;
+    return OCTANE_OK;
 }
