@@ -775,15 +775,22 @@ static int pass_b_grid_size(int w, int h)
     return g;
 }
 
-// Tile height of pass A.  Default (0): 128 x 16 tiles (R = 2) from one Mpixel up, 128 x 8 (R = 1) below -- measured
-// per level at 5000^2: R = 2 is 5 % faster at 5000^2 and 7 % at 1250^2, R = 1 is 7-15 % faster at 156^2 .. 625^2
-// where the taller tile leaves too few workgroups.  OCTANE_TUNE_PASS_A forces 1, 2, 4 or 3 (= LDS-ring marching).
+// Which form of pass A a level runs.  Default (0), from per-level timings of every form on the same arena
+// (octane_vof_plan_probe, several boxes):
+//   below 1 Mpixel        1  latency form, 128 x 8 tiles (7-15 % faster than taller tiles: more workgroups)
+//   1 .. 4 Mpixel         2  128 x 16 tiles
+//   4 .. 12 Mpixel        3  LDS-ring marching: 64.5-65.3 us at 2500^2 against 72-75 us for every tiled form
+//   12 Mpixel and up      2  128 x 16 tiles (the marching form is 3-8 % slower at 5000^2)
+// OCTANE_TUNE_PASS_A forces 1, 2, 4 (128 x 32), 5 (256 x 8) or 3.
 static int g_pass_a_variant = 0;
 void set_pass_a_variant(int v) { g_pass_a_variant = (v >= 0 && v <= 5) ? v : 0; }
 static int pass_a_choice(int w, int h)
 {
     if (g_pass_a_variant != 0) return g_pass_a_variant;
-    return ((long)w * h >= (1L << 20)) ? 2 : 1;
+    const long npix = (long)w * h;
+    if (npix < (1L << 20)) return 1;
+    if (npix >= (4L << 20) && npix < (12L << 20)) return 3;
+    return 2;
 }
 
 int pcg_grid_size(int w, int h)

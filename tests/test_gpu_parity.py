@@ -88,6 +88,14 @@ def test_one_thread_schedule_of_the_oracle_also_agrees_on_small_frames(capi, ora
     assert rel_l2(ug, vg, uo, vo) < INVESTIGATE
 
 
+def test_marching_pass_a_level_matches_oracle(capi, oracle):
+    """Levels of 4..12 Mpixel run the LDS-ring marching form of pass A (1024-pixel strips, runs of rows per
+    workgroup, strip ends and run ends recomputed).  2300 x 1900 has three strips, the last one 252 pixels wide."""
+    nx, ny = 2300, 1900
+    a, b = synth.lattice_scene(nx, ny, seed=55)
+    _check(capi, oracle, a, b, dict(kiters=1, liters=1, cgiters=4))
+
+
 def test_first_guess_and_hint_term(capi, oracle):
     """lambdac != 0 (only reachable with -firstguess): the hint term and its pyramid."""
     nx, ny = 120, 88

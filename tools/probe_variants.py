@@ -5,13 +5,12 @@ n = 5000
 os.environ['OCTANE_TUNE_PLACEMENT_TRIALS'] = '1'
 for plan_i in range(3):
     pl = capi.Plan(n, n, 1, capi.FlowParams(kiters=8))
-    print("plan", plan_i)
+    res = {}
     for rep in range(2):
-        for var in (2, 5, 1, 4, 3):
+        for var in (2, 1, 3, 5):
             pl.tune("pass_a", var)
-            out = []
             for lev in (5, 6, 7):
                 a, b = pl.probe(lev, 30)
-                out.append(f"L{lev} A {a*1e3:7.2f} B {b*1e3:7.2f}")
-            print(f"  variant {var}: " + " | ".join(out), flush=True)
+                res.setdefault((var, lev), []).append(a * 1e3)
+    print("plan", plan_i, " | ".join(f"L{lev}: " + " ".join(f"v{var}={min(res[(var, lev)]):.1f}" for var in (2, 1, 3, 5)) for lev in (5, 6, 7)), flush=True)
     pl.close()
