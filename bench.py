@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--workload", default="pair", choices=["pair", "batch64"],
                     help="pair (default): one --size pair per GPU; batch64: BASELINE.json configs[4], 64 pairs of "
                          "2000x2000 (kiters=6) shared by all ranks, two concurrent lanes per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=768, help="edge of the CPU-baseline sample pair")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="edge of the CPU-baseline sample pair")
     args = ap.parse_args()
 
     import torch
