@@ -49,7 +49,7 @@ class _Trace(C.Structure):
 def build(force: bool = False) -> None:
     """Compile the oracle (and, when /root/reference is present, oracle/_ref)."""
     need = force or not all(os.path.exists(os.path.join(_HERE, n))
-                            for n in ("liboct_oracle.so", "liboct_oracle_fma.so"))
+                            for n in ("liboct_oracle.so", "liboct_oracle_fma.so", "liboct_oracle_omp.so"))
     if need:
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     ref = os.environ.get("OCT_REFERENCE", "/root/reference")
@@ -65,12 +65,14 @@ _libs: dict[str, C.CDLL] = {}
 
 
 def lib(flavour: str = "strict") -> C.CDLL:
-    """flavour: 'strict' (no FMA contraction) or 'fma'."""
+    """flavour: 'strict' (no FMA contraction), 'fma', or 'omp' (strict arithmetic, loops spread over the host
+    cores with OpenMP; bit-identical to 'strict' under the grid dot schedule)."""
     if flavour in _libs:
         return _libs[flavour]
     build()
-    name = "liboct_oracle.so" if flavour == "strict" else "liboct_oracle_fma.so"
+    name = {"strict": "liboct_oracle.so", "fma": "liboct_oracle_fma.so", "omp": "liboct_oracle_omp.so"}[flavour]
     L = C.CDLL(os.path.join(_HERE, name))
+    L.oct_oracle_num_threads.restype = C.c_int
     L.oct_oracle_vof.restype = C.c_int
     L.oct_oracle_vof.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, _F, _F, C.POINTER(Params), C.c_void_p]
     L.oct_oracle_level_dims.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -112,6 +114,11 @@ class FlowParams:
     def c(self) -> Params:
         return Params(self.alpha, self.lambda_, self.lambdac, self.scaleF,
                       self.kiters, self.liters, self.cgiters, self.dozim)
+
+
+def num_threads(flavour: str = "strict") -> int:
+    """Host threads the given flavour spreads its loops over."""
+    return int(lib(flavour).oct_oracle_num_threads())
 
 
 REF_GRID_THREADS = 20 * 16 * 128   # the reference's launch: 20 SMs (hard-coded, ref .cu:1422) x 16 blocks x 128 threads

@@ -26,14 +26,32 @@
  * src/oct_variational_optical_flow.cu in /root/reference).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; a second flavour with
- * -mfma -ffp-contract=fast estimates the FMA-contraction noise floor).
+ * -mfma -ffp-contract=fast estimates the FMA-contraction noise floor; a third,
+ * -fopenmp, spreads the per-pixel / per-row loops over the host cores for the
+ * cpu_baseline leg -- every loop it splits is order-independent, and the grid
+ * dot-product schedule adds its block sums in block order, so that flavour is
+ * bit-identical to the strict one under that schedule).
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #include "vof_oracle.h"
+
+/* Host threads the loops of this build are spread over (1 unless built with -fopenmp). */
+int oct_oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* ---------------------------------------------------------------- helpers */
 
@@ -90,6 +108,7 @@ void oct_oracle_gauss_taps(float factor, int fs, float *gk)
 void oct_oracle_blur_rows(const float *in, float *out, const float *gk, int nx, int ny, int nc, int fs)
 {
     long plane = (long)nx * ny;
+#pragma omp parallel for schedule(static)
     for (long q = 0; q < plane * nc; q++) {
         long within = q % plane;
         int i = (int)(within % nx);
@@ -107,6 +126,7 @@ void oct_oracle_blur_rows(const float *in, float *out, const float *gk, int nx, 
 void oct_oracle_blur_cols(const float *in, float *out, const float *gk, int nx, int ny, int nc, int fs)
 {
     long plane = (long)nx * ny;
+#pragma omp parallel for schedule(static)
     for (long q = 0; q < plane * nc; q++) {
         long within = q % plane;
         int i = (int)(within % nx);
@@ -161,6 +181,7 @@ void oct_oracle_decimate(const float *blurred, float *out, int nx, int ny, int n
     int lx = (int)((double)nx * factor + 0.5);
     int ly = (int)((double)ny * factor + 0.5);
     long lplane = (long)lx * ly;
+    #pragma omp parallel for schedule(static)
     for (long q = 0; q < lplane * nc; q++) {
         int c = (int)(q / lplane);
         long within = q - c * lplane;
@@ -181,6 +202,7 @@ void oct_oracle_decimate(const float *blurred, float *out, int nx, int ny, int n
 void oct_oracle_gradient(const float *f, float *gx, float *gy, int xi, int yi, int nc)
 {
     long plane = (long)xi * yi;
+#pragma omp parallel for schedule(static)
     for (long q = 0; q < plane * nc; q++) {
         int c = (int)(q / plane);
         long within = q - c * plane;
@@ -209,6 +231,7 @@ void oct_oracle_upsample_flow(const float *coarse, float *fine, int nx, int ny, 
 {
     const float fx = ((float)nxx / nx);
     const float fy = ((float)nyy / ny);
+    #pragma omp parallel for schedule(static)
     for (long q = 0; q < (long)nxx * nyy; q++) {
         int ii = (int)(q % nxx);
         int jj = (int)((q - ii) / nxx);
@@ -255,6 +278,7 @@ void oct_oracle_assemble(const oct_oracle_level *L, const float *u, const float 
     const int xi = L->xi, yi = L->yi, nc = L->nc;
     const long npix = (long)xi * yi;
     const int xi2 = 2 * xi;
+    #pragma omp parallel for schedule(static)
     for (long n = 0; n < npix; n++) {
         int ii = (int)(n % xi);
         int jj = (int)((n - ii) / xi);
@@ -425,6 +449,7 @@ void oct_oracle_assemble(const oct_oracle_level *L, const float *u, const float 
 void oct_oracle_spmv(const float *val, const int *rowptr, const int *col, const float *x,
                      long nnz, int nrows, float *y)
 {
+    #pragma omp parallel for schedule(static)
     for (int k = 0; k < nrows; k++) {
         int b = rowptr[k];
         int e = (k < nrows - 1) ? rowptr[k + 1] : (int)nnz;
@@ -458,9 +483,11 @@ static float dotf(const float *a, const float *b, int n)
         return s;
     }
     const int G = g_dot_threads;
-    float result = 0.0f;
-    float tmp[128];
-    for (int blk = 0; blk < G / 128; blk++) {
+    const int nblk = G / 128;
+    float *blocksum = malloc(sizeof(float) * (size_t)nblk);
+    #pragma omp parallel for schedule(static)
+    for (int blk = 0; blk < nblk; blk++) {
+        float tmp[128];
         for (int t = 0; t < 128; t++) {                 /* per-thread grid-stride partial */
             float s = 0.0f;
             for (long i = (long)blk * 128 + t; i < n; i += G) s += (float)(a[i] * b[i]);
@@ -471,14 +498,18 @@ static float dotf(const float *a, const float *b, int n)
                 for (int r = 0; r < i; r++) tmp[tile + r] = tmp[tile + r] + tmp[tile + r + i];
         float beta = 0.0f;
         for (int i = 0; i < 128; i += 32) beta += tmp[i];
-        result += beta;                                  /* atomicAdd, block order */
+        blocksum[blk] = beta;
     }
+    float result = 0.0f;
+    for (int blk = 0; blk < nblk; blk++) result += blocksum[blk];   /* atomicAdd, block order */
+    free(blocksum);
     return result;
 }
 
 /* ref .cu:198-205 jVecPVec: c = d*a + b */
 static void axpy(const float *a, const float *b, float *c, float d, int n)
 {
+    #pragma omp parallel for schedule(static)
     for (int k = 0; k < n; k++) c[k] = d * a[k] + b[k];
 }
 
@@ -490,10 +521,14 @@ int oct_oracle_pcg(oct_oracle_system *S, float *x, float tol, int maxit, oct_ora
     float *b = S->rhs, *M = S->diag, *z = W->z, *p = W->p, *rk = W->rk, *tmp = W->tmp;
     int *ident = W->ident;
     oct_oracle_spmv(S->val, S->rowptr, S->col, x, S->nnz, n, tmp);
+    #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++) b[i] = b[i] - tmp[i];
+    #pragma omp parallel for schedule(static)
     for (int k = 0; k < n; k++) M[k] = (float)(1. / (double)M[k]);       /* ref .cu:141-149 */
+    #pragma omp parallel for schedule(static)
     for (int k = 0; k < n; k++) ident[k] = k;                           /* Mrow, ref .cu:973,1052 */
     oct_oracle_spmv(M, ident, ident, b, n, n, z);                       /* ref .cu:1117 */
+    #pragma omp parallel for schedule(static)
     for (int j = 0; j < n; j++) p[j] = z[j];
     float resid = dotf(b, b, n);
     int ki = 0;
@@ -504,6 +539,7 @@ int oct_oracle_pcg(oct_oracle_system *S, float *x, float tol, int maxit, oct_ora
             float zr_new = dotf(z, rk, n);
             float beta = zr_new / zr_old;
             axpy(p, z, p, beta, n);
+            #pragma omp parallel for schedule(static)
             for (int j = 0; j < n; j++) b[j] = rk[j];
         }
         float rz = dotf(b, z, n);
@@ -598,6 +634,7 @@ int oct_oracle_vof(const float *img1, const float *img2, int nx, int ny, int nc,
             oct_oracle_blur_rows(vh, vt, gk, nx, ny, 1, fs);
             oct_oracle_blur_cols(vt, scratch, gk, nx, ny, 1, fs);
             oct_oracle_decimate(scratch, vt, nx, ny, 1, factor);
+            #pragma omp parallel for schedule(static)
             for (long q = 0; q < npix; q++) { ut[q] *= factor; vt[q] *= factor; }
         }
         if (k == 0) { /* ref .cu:576-585 */
@@ -642,6 +679,7 @@ int oct_oracle_vof(const float *img1, const float *img2, int nx, int ny, int nc,
                 int its = oct_oracle_pcg(&S, x, tol, cgiters, &W);
                 total_cg += its;
                 if (pl) emit(tr, "dx", k, gnc, l, x, 2 * xi, yi, 1);
+                #pragma omp parallel for schedule(static)
                 for (long q = 0; q < npix; q++) {        /* ref .cu:1185-1195 */
                     u[q] = u[q] + x[2 * q];
                     v[q] = v[q] + x[2 * q + 1];

@@ -192,3 +192,15 @@ def test_multichannel_decimation_samples_channel_zero(oracle):
     oracle.lib().oct_oracle_decimate(img, out, nx, ny, 2, 0.5)
     assert np.array_equal(out[0], out[1])
     assert np.array_equal(out[0], img[0, ::2, ::2])
+
+
+def test_openmp_flavour_is_bit_identical_to_the_scalar_one(oracle):
+    """The multi-core build (bench.py's cpu_baseline) splits only order-independent loops and adds the block sums
+    of the launch-geometry dot product in block order: same bits as the scalar build, two channels included."""
+    a, b = synth.lattice_scene(97, 61, seed=5, nchan=2)
+    prm = oracle.FlowParams(kiters=3, liters=2, cgiters=12, lambdac=0.3)
+    us, vs, its = oracle.flow(a, b, prm, dot_threads=oracle.REF_GRID_THREADS)
+    uo, vo, ito = oracle.flow(a, b, prm, flavour="omp", dot_threads=oracle.REF_GRID_THREADS)
+    assert its == ito
+    assert np.array_equal(us, uo) and np.array_equal(vs, vo)
+    assert oracle.num_threads("strict") == 1 and oracle.num_threads("omp") >= 1
