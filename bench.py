@@ -78,6 +78,49 @@ def batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         dist.destroy_process_group()
 
 
+def tiled(args, capi, synth, torch):
+    """BASELINE.json configs[3]: ONE frame (--size, default 10848) solved by --bands row bands, band b on device
+    b % (visible devices).  A single process drives all bands (octane_vof_tiled_*: one host thread per band, peer reads
+    and event ordering between devices; no RCCL -- the path has no collective, only neighbour rows and partial sums
+    read in place).  On a one-GPU box the bands are virtual ranks sharing device 0: that run checks the whole
+    mechanism but says nothing about multi-GPU speed (the bands' persistent kernels then queue behind each other)."""
+    n = args.size
+    ndev = capi.lib().octane_device_count()
+    devices = [b % ndev for b in range(args.bands)]
+    dev = torch.device("cuda", devices[0])
+    torch.cuda.set_device(dev)
+    a, b = synth.lattice_scene(n, n, seed=20240613 + 3, device=dev)
+    z = torch.zeros(n, n, device=dev)
+    prm = capi.FlowParams(kiters=args.kiters, liters=args.liters, cgiters=args.cgiters)
+    torch.cuda.synchronize()
+    tp = capi.TiledPlan(n, n, 1, prm, nbands=args.bands, devices=devices)
+    tp.load_device(a.data_ptr(), b.data_ptr(), z.data_ptr(), z.data_ptr())     # the pair resident on every band's device
+    for _ in range(args.warmup):
+        tp.solve()
+    tp.wait()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tp.solve()
+    tp.wait()
+    elapsed = time.perf_counter() - t0
+    iters, expect = tp.last_iterations(), args.kiters * 3 * args.liters * args.cgiters
+    ngpu = len(set(devices))
+    out = {"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n),
+           "value": round(n * n * args.steps / elapsed / 1e6, 3), "unit": "Mpix/s", "n_gpus": ngpu, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan=1 alpha=5 "
+                                  f"lambda=1 (BASELINE.json configs[3]), {iters} PCG iterations per pyramid (expected {expect}); "
+                                  f"{args.bands} row bands on {ngpu} device(s)" + (" -- VIRTUAL bands sharing one GPU" if ngpu < args.bands else ""),
+                      "sharding": f"row bands of the {tp.banded_levels} finest level(s), coarser levels replicated; per PCG iteration "
+                                  "two event-ordered phase boundaries, partial sums and one residual row per inner edge read in "
+                                  "place from the neighbouring band",
+                      "device_bytes_per_band": tp.device_bytes},
+           "roofline": None, "cpu_baseline": None}
+    tp.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,9 +131,12 @@ def main():
     ap.add_argument("--liters", type=int, default=3)
     ap.add_argument("--cgiters", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="pair", choices=["pair", "batch64"],
+    ap.add_argument("--workload", default="pair", choices=["pair", "batch64", "tiled"],
                     help="pair (default): one --size pair per GPU; batch64: BASELINE.json configs[4], 64 pairs of "
-                         "2000x2000 (kiters=6) shared by all ranks, two concurrent lanes per GPU")
+                         "2000x2000 (kiters=6) shared by all ranks, two concurrent lanes per GPU; tiled: BASELINE.json "
+                         "configs[3], one --size frame as --bands row bands driven by a single process (run it "
+                         "without torchrun)")
+    ap.add_argument("--bands", type=int, default=4, help="row bands of the tiled workload")
     ap.add_argument("--cpu-sample", type=int, default=1536, help="edge of the CPU-baseline sample pair")
     args = ap.parse_args()
 
@@ -116,6 +162,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.workload == "tiled":
+        if world > 1:
+            raise SystemExit("--workload tiled is one process driving all devices: run it without torchrun")
+        return tiled(args, capi, synth, torch)
     if args.workload == "batch64":
         return batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev)
     n = args.size
@@ -192,6 +242,7 @@ def main():
         t1 = time.perf_counter()
         # OpenMP build of the oracle (bit-identical to the scalar one) under the reference's launch-geometry
         # dot-product schedule, on all the host cores this process may use
+        oo.set_threads(oo.host_cpu_share())
         cores = oo.num_threads("omp")
         _, _, cits = oo.flow(ca, cb, oo.FlowParams(kiters=ck, liters=args.liters, cgiters=args.cgiters),
                              flavour="omp", dot_threads=oo.REF_GRID_THREADS)

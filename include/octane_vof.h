@@ -15,6 +15,8 @@
  *                                (.cu:1268-1328 allocations, :1431 launch, :1441-1472 frees), split so that a
  *                                caller can keep device state across image pairs
  *   octane_vof_batch_run      <- (new) the reference is single-GPU: args.setdevice -> cudaSetDevice, .cu:1251-1265
+ *   octane_vof_tiled_*        <- (new) one frame over several GPUs as row bands of the fine pyramid levels, same
+ *                                arithmetic as the single-GPU solve: one global PCG per linearisation (.cu:1105-1195)
  *   octane_pix2uv_run         <- void oct_pix2uv_cuda(GOESVar&,double,float*,float*,short*,short*,short*,short*,OFFlags)
  *                                src/oct_pix2uv_cuda.cu:265 (declared at src/oct_optical_flow.cc:15)
  */
@@ -107,6 +109,35 @@ int octane_vof_plan_probe(octane_vof_plan *plan, int level, int iterations, doub
 int octane_vof_batch_run(int npairs, const float *const *img1, const float *const *img2,
                          int nx, int ny, int nchan, float *const *u_inout, float *const *v_inout,
                          const octane_vof_params *p, int ndevices, const int *devices);
+
+/* ---- one frame over several GPUs (BASELINE configs[3]: a full-disk pair as row bands) ----------------------------
+ * `nbands` (1..8) row bands, band b on devices[b] (NULL: b modulo the device count; ids may repeat -- several bands
+ * then share a device, which is how a one-GPU machine exercises this path).  Pyramid levels with fewer than
+ * min_band_pixels pixels (0 = default, 12 Mpixel) are solved redundantly by every band; on the larger ones a band
+ * owns a range of rows and the bands exchange, per PCG iteration, their reduction partials and one row of the
+ * residual per inner edge (stream-ordered peer copies over xGMI; no host synchronisation inside a pyramid).
+ * The iterates are those of the single-GPU solve up to the summation order of the dot products.
+ * Every band holds full-size planes: octane_vof_tiled_device_bytes() is per band.
+ *   _load   uploads (OCTANE_MEM_HOST) or copies (OCTANE_MEM_DEVICE, dense buffers on devices[0]) the pair and the
+ *           first guess to every band; blocking
+ *   _solve  issues one pyramid on the loaded inputs; asynchronous
+ *   _wait   blocks until the bands' streams are idle
+ *   _fetch  waits, then copies the flow out of band 0 (host buffers, or dense device buffers on devices[0])
+ *   _run    = load + solve + fetch (u/v in-out as for octane_vof_run) */
+typedef struct octane_vof_tiled octane_vof_tiled;
+int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, int nchan, const octane_vof_params *p,
+                            int nbands, const int *devices, long long min_band_pixels);
+int octane_vof_tiled_destroy(octane_vof_tiled *t);
+int octane_vof_tiled_load(octane_vof_tiled *t, const float *img1, const float *img2, const float *u, const float *v, int mem);
+int octane_vof_tiled_solve(octane_vof_tiled *t);
+int octane_vof_tiled_wait(octane_vof_tiled *t);
+int octane_vof_tiled_fetch(octane_vof_tiled *t, float *u, float *v, int mem);
+int octane_vof_tiled_run(octane_vof_tiled *t, const float *img1, const float *img2, float *u_inout, float *v_inout, int mem);
+int octane_vof_tiled_banded_levels(const octane_vof_tiled *t);                 /* how many levels are split into bands */
+int octane_vof_tiled_band_rows(const octane_vof_tiled *t, int level, int band, int *y0, int *y1);   /* 1 banded, 0 replicated */
+long long octane_vof_tiled_last_iterations(octane_vof_tiled *t);               /* PCG iterations of the last pyramid */
+long long octane_vof_tiled_last_copies(octane_vof_tiled *t);                   /* peer copies the last solve issued */
+size_t octane_vof_tiled_device_bytes(const octane_vof_tiled *t);
 
 /* ---- pix2uv: pixel displacement -> navigated wind (cm/s as short) ---- */
 typedef struct octane_nav {      /* the GOESNAVVar fields oct_pix2uv_cuda.cu reads (include/goesread.h) */

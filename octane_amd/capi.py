@@ -23,7 +23,12 @@ EXPORTS = (
     "octane_vof_default_params", "octane_vof_run", "octane_vof_plan_create", "octane_vof_plan_destroy",
     "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_last_iterations",
     "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_probe", "octane_vof_tune",
-    "octane_vof_batch_run", "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
+    "octane_vof_batch_run",
+    "octane_vof_tiled_create", "octane_vof_tiled_destroy", "octane_vof_tiled_load", "octane_vof_tiled_solve",
+    "octane_vof_tiled_wait", "octane_vof_tiled_fetch", "octane_vof_tiled_run", "octane_vof_tiled_banded_levels",
+    "octane_vof_tiled_band_rows", "octane_vof_tiled_last_iterations", "octane_vof_tiled_last_copies",
+    "octane_vof_tiled_device_bytes",
+    "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
     "octane_uv2pix_run", "octane_srsal_run",
     "octane_last_error", "octane_device_count",
 )
@@ -122,6 +127,22 @@ def lib() -> C.CDLL:
     L.octane_vof_batch_run.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int,
                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(VofParams), C.c_int,
                                        C.POINTER(C.c_int)]
+    L.octane_vof_tiled_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(VofParams), C.c_int,
+                                          C.POINTER(C.c_int), C.c_longlong]
+    L.octane_vof_tiled_destroy.argtypes = [vp]
+    L.octane_vof_tiled_load.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+    L.octane_vof_tiled_solve.argtypes = [vp]
+    L.octane_vof_tiled_wait.argtypes = [vp]
+    L.octane_vof_tiled_fetch.argtypes = [vp, vp, vp, C.c_int]
+    L.octane_vof_tiled_run.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+    L.octane_vof_tiled_banded_levels.argtypes = [vp]
+    L.octane_vof_tiled_band_rows.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.octane_vof_tiled_last_iterations.argtypes = [vp]
+    L.octane_vof_tiled_last_iterations.restype = C.c_longlong
+    L.octane_vof_tiled_last_copies.argtypes = [vp]
+    L.octane_vof_tiled_last_copies.restype = C.c_longlong
+    L.octane_vof_tiled_device_bytes.argtypes = [vp]
+    L.octane_vof_tiled_device_bytes.restype = C.c_size_t
     L.octane_pix2uv_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, C.c_int, C.c_int,
                                     vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     L.octane_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(NavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
@@ -247,6 +268,89 @@ class Plan:
         p = VofProfile()
         lib().octane_vof_plan_get_profile(self._h, C.byref(p))
         return p
+
+
+class TiledPlan:
+    """One frame solved by `nbands` row bands, band b on devices[b] (ids may repeat: virtual bands on one GPU).
+    Levels below `min_band_pixels` are solved redundantly by every band (include/octane_vof.h)."""
+
+    def __init__(self, nx: int, ny: int, nchan: int = 1, params: FlowParams | None = None, nbands: int = 2,
+                 devices=None, min_band_pixels: int = 0):
+        self.nx, self.ny, self.nchan, self.nbands = nx, ny, nchan, nbands
+        self.params = params or FlowParams()
+        self._h = C.c_void_p()
+        p = self.params.c()
+        dv = None
+        if devices is not None:
+            assert len(devices) == nbands
+            dv = (C.c_int * nbands)(*devices)
+        rc = lib().octane_vof_tiled_create(C.byref(self._h), nx, ny, nchan, C.byref(p), nbands, dv, min_band_pixels)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_tiled_create")
+
+    def close(self):
+        if self._h:
+            lib().octane_vof_tiled_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def banded_levels(self) -> int:
+        return int(lib().octane_vof_tiled_banded_levels(self._h))
+
+    @property
+    def device_bytes(self) -> int:
+        return lib().octane_vof_tiled_device_bytes(self._h)
+
+    def band_rows(self, level: int, band: int):
+        """(banded?, y0, y1) of `band` at pyramid level `level` (0 = coarsest)."""
+        y0, y1 = C.c_int(), C.c_int()
+        rc = lib().octane_vof_tiled_band_rows(self._h, level, band, C.byref(y0), C.byref(y1))
+        if rc < 0:
+            raise OctaneError(rc, "octane_vof_tiled_band_rows")
+        return bool(rc), y0.value, y1.value
+
+    def run_host(self, img1, img2, u0=None, v0=None):
+        a, b = _f32(img1), _f32(img2)
+        assert a.size == self.nchan * self.ny * self.nx and b.size == a.size
+        u = np.zeros((self.ny, self.nx), np.float32) if u0 is None else np.array(u0, np.float32, order="C", copy=True)
+        v = np.zeros((self.ny, self.nx), np.float32) if v0 is None else np.array(v0, np.float32, order="C", copy=True)
+        rc = lib().octane_vof_tiled_run(self._h, _ptr(a), _ptr(b), _ptr(u), _ptr(v), MEM_HOST)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_tiled_run")
+        return u, v
+
+    def load_device(self, img1_ptr: int, img2_ptr: int, u_ptr: int, v_ptr: int):
+        rc = lib().octane_vof_tiled_load(self._h, C.c_void_p(img1_ptr), C.c_void_p(img2_ptr), C.c_void_p(u_ptr),
+                                         C.c_void_p(v_ptr), MEM_DEVICE)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_tiled_load")
+
+    def solve(self):
+        rc = lib().octane_vof_tiled_solve(self._h)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_tiled_solve")
+
+    def wait(self):
+        rc = lib().octane_vof_tiled_wait(self._h)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_tiled_wait")
+
+    def fetch_device(self, u_ptr: int, v_ptr: int):
+        rc = lib().octane_vof_tiled_fetch(self._h, C.c_void_p(u_ptr), C.c_void_p(v_ptr), MEM_DEVICE)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_tiled_fetch")
+
+    def last_iterations(self) -> int:
+        return int(lib().octane_vof_tiled_last_iterations(self._h))
+
+    def last_copies(self) -> int:
+        return int(lib().octane_vof_tiled_last_copies(self._h))
 
 
 def flow(img1, img2, params: FlowParams | None = None, u0=None, v0=None):

@@ -37,6 +37,20 @@ __device__ __forceinline__ double fold_partials_256(const double *__restrict__ p
     return block_sum_256(v, scratch);
 }
 
+// The same over the partial blocks of `nbands` row bands (vof_kernels.hpp): band after band, so every workgroup of
+// every band obtains the same bits.  nbands == 1 is the fold above.  A block of another band may live in another
+// device's memory; it was written by a kernel that completed before this one started (event-ordered).
+__device__ __forceinline__ double fold_band_partials_256(const double *const *blocks, int kind_off, int n, int nbands,
+                                                         double *scratch)
+{
+    double v = 0.;
+    for (int b = 0; b < nbands; b++) {
+        const double *__restrict__ part = blocks[b] + kind_off;
+        for (int i = threadIdx.x; i < n; i += 256) v += part[i];
+    }
+    return block_sum_256(v, scratch);
+}
+
 // Work-item range of this workgroup in a persistent launch.  Plain: items b, b+G, b+2G, ...  Banded: the item
 // list is cut into 8 contiguous bands and workgroup b serves band b % 8 -- workgroups are dealt round-robin over
 // the 8 XCDs (observed, not guaranteed: MI355X_MICROARCH.md), so each XCD's L2 then sees one compact region of

@@ -26,7 +26,22 @@ void oct_variational_optical_flow(Image geo1i, Image geo2i, float *CTH, float *u
         std::cout << "Warning: setdevice set to non-existent GPU, setting to default GPU 1\n";
         p.device = 0;
     }
-    const int rc = octane_vof_run(geo1i.data, geo2i.data, nx, ny, geo1i.nchannels, uarr, varr, &p);
+    // OCTANE_VOF_BANDS=n (2..8): solve this one frame on n GPUs as row bands, band b on device (setdevice + b) mod
+    // the device count -- for frames like a 10848^2 full disk.  OFFlags has no field for it (the reference is
+    // single-GPU), hence an environment variable; the result is the single-GPU one up to reduction order.
+    int rc;
+    const char *eb = getenv("OCTANE_VOF_BANDS");
+    const int nbands = eb ? atoi(eb) : 1;
+    if (nbands > 1) {
+        int devs[8];
+        for (int b = 0; b < nbands && b < 8; b++) devs[b] = (p.device + b) % ndev;
+        octane_vof_tiled *t = nullptr;
+        rc = octane_vof_tiled_create(&t, nx, ny, geo1i.nchannels, &p, nbands, devs, 0);
+        if (rc == OCTANE_OK) rc = octane_vof_tiled_run(t, geo1i.data, geo2i.data, uarr, varr, OCTANE_MEM_HOST);
+        octane_vof_tiled_destroy(t);
+    } else {
+        rc = octane_vof_run(geo1i.data, geo2i.data, nx, ny, geo1i.nchannels, uarr, varr, &p);
+    }
     if (rc != OCTANE_OK)   // the reference ignores CUDA errors (.cu:1421,1431); a failed solve is reported here
         std::cerr << "oct_variational_optical_flow: " << octane_last_error() << " (code " << rc << ")\n";
 }

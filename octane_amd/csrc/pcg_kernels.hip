@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
     const int tid = threadIdx.x;
 
     const PcgState prev = L.st[k & 1];                               // requested together with the partials
-    const float rz_new = (float)fold_partials_256(L.part_rz, nparts_prev, s_red);
-    const float rr = (float)fold_partials_256(L.part_rr, nparts_prev, s_red);
+    const float rz_new = (float)fold_band_partials_256(L.band_parts, kPartRz, nparts_prev, L.nbands, s_red);
+    const float rr = (float)fold_band_partials_256(L.band_parts, kPartRr, nparts_prev, L.nbands, s_red);
     const bool active = (prev.stopped == 0) && (rr > tol);          // ref .cu:1131
     if (!active) {
         if (blockIdx.x == 0 && tid == 0) { PcgState n = prev; n.stopped = 1; L.st[(k + 1) & 1] = n; }
@@ -93,8 +93,15 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
         L.st[(k + 1) & 1] = n;
     }
 
+    // This launch covers rows [y0, y1) of the frame (the whole frame for a plain plan).  Rows y0-1 and y1 of a
+    // band's inner edges belong to the neighbouring bands: r there is read from the neighbour's own plane (its
+    // pass B finished before this launch started), the coefficients come from the band's own (overlapping)
+    // assembly, and p is kept up to date right here --
+    // the halo rows of p_new every tile recomputes anyway are stored when they lie outside the band, with the
+    // very arithmetic the owning band uses, so p needs no exchange.
     const int w = L.w, h = L.h, pitch = L.pitch;
-    const int tiles_x = (w + TX - 1) / TX, tiles_y = (h + TY - 1) / TY;
+    const int by0 = L.y0, by1 = L.y1;
+    const int tiles_x = (w + TX - 1) / TX, tiles_y = (by1 - by0 + TY - 1) / TY;
     const int ntiles = tiles_x * tiles_y;
     const int lx = tid & 31, ly = tid >> 5;
     double acc = 0.;
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
 
     const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
     for (int t = tr.first; t < tr.end; t += tr.step) {
-        const int tx0 = (t % tiles_x) * TX, ty0 = (t / tiles_x) * TY;
+        const int tx0 = (t % tiles_x) * TX, ty0 = by0 + (t / tiles_x) * TY;
         float a1[R][4], a4[R][4], a2[R][4], wxc[R][4], wyc[R][4], wys[R][4], npu[R][4], npv[R][4];
         float wxw[R];
 #pragma unroll
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
             const int x = tx0 + lx * 4 + (WIDE ? kTileX * q : 0);
             const int y = ty0 + ly + (WIDE ? 0 : kTileY * q);
             const int lrow1 = ly + (WIDE ? 0 : kTileY * q) + 1, lcol = kLInt + lx * 4 + (WIDE ? kTileX * q : 0);
-            const bool rowok = (y < h) && (x < w);
+            const bool rowok = (y < by1) && (x < w);
             const size_t o = (size_t)y * pitch + x;
             float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0};
             wxw[q] = 0.f;
@@ -150,7 +157,10 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
             if (hy >= 0 && hy < h && hx < w) {
                 const size_t ho = (size_t)hy * pitch + hx;
                 float r0[4], r1[4], d0[4], d1[4], q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
-                *(float4 *)r0 = ld4(L.ru + ho); *(float4 *)r1 = ld4(L.rv + ho);
+                // r of a neighbouring band's row comes straight from that band's plane
+                const float *hru = (hy < by0) ? L.ru_up : (hy >= by1) ? L.ru_dn : L.ru;
+                const float *hrv = (hy < by0) ? L.rv_up : (hy >= by1) ? L.rv_dn : L.rv;
+                *(float4 *)r0 = ld4(hru + ho); *(float4 *)r1 = ld4(hrv + ho);
                 *(float4 *)d0 = ld4(L.a1 + ho); *(float4 *)d1 = ld4(L.a4 + ho);
                 if (!first) { *(float4 *)q0 = ld4(pin_u + ho); *(float4 *)q1 = ld4(pin_v + ho); }
 #pragma unroll
@@ -158,6 +168,10 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
                     const bool ok = (hx + e) < w;
                     hu[e] = ok ? direction(r0[e], q0[e], d0[e], beta, first) : 0.f;
                     hv[e] = ok ? direction(r1[e], q1[e], d1[e], beta, first) : 0.f;
+                }
+                if (hy < by0 || hy >= by1) {                 // a neighbouring band's row: keep our copy of p current
+                    st4(pout_u + ho, *(float4 *)hu);
+                    st4(pout_v + ho, *(float4 *)hv);
                 }
             }
             st4(&s_pu[lrow * LROW + kLInt + (tid % HL) * 4], *(float4 *)hu);
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
             const int hy = ty0 + row;
             const int hx = side ? tx0 + TX : tx0 - 1;
             float hu = 0.f, hv = 0.f;
-            if (hy < h && hx >= 0 && hx < w) {
+            if (hy < by1 && hx >= 0 && hx < w) {
                 const size_t ho = (size_t)hy * pitch + hx;
                 const float q0 = first ? 0.f : pin_u[ho], q1 = first ? 0.f : pin_v[ho];
                 hu = direction(L.ru[ho], q0, L.a1[ho], beta, first);
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
             const int x = tx0 + lx * 4 + (WIDE ? kTileX * q : 0);
             const int y = ty0 + ly + (WIDE ? 0 : kTileY * q);
             const int lrow = ly + (WIDE ? 0 : kTileY * q), lc = kLInt + lx * 4 + (WIDE ? kTileX * q : 0);
-            if ((y < h) && (x < w)) {
+            if ((y < by1) && (x < w)) {
                 float su[4], sv[4], nu[4], nv[4];
                 *(float4 *)su = ld4(&s_pu[lrow * LROW + lc]);
                 *(float4 *)sv = ld4(&s_pv[lrow * LROW + lc]);
@@ -652,7 +666,7 @@ __device__ __forceinline__ void pass_b_issue(const LevelPtrs &L, int k, int xmod
     if (g >= ngroups) return;
     const int y = (int)(g / gw);
     b.x = (int)(g - (long)y * gw) * 4;
-    b.o = (size_t)y * pitch + b.x;
+    b.o = (size_t)(L.y0 + y) * pitch + b.x;
     b.valid = true;
     b.ru = ld4(L.ru + b.o); b.rv = ld4(L.rv + b.o);
     b.pu = ld4(L.pu[(k + 1) & 1] + b.o); b.pv = ld4(L.pv[(k + 1) & 1] + b.o);
@@ -668,9 +682,9 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
 {
     __shared__ double s_red[8];
     const int xmode = pass_b_xmode(L.defer_x, k);
-    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int w = L.w, pitch = L.pitch;
     const int gw = (w + 3) / 4;
-    const long ngroups = (long)gw * h;
+    const long ngroups = (long)gw * (L.y1 - L.y0);         // float4 groups of the rows this launch owns
     // Pass B walks the frame from the end to the start and pass A from the start to the end, so
     // each pass begins on the planes the previous one touched last (p, q, r and the diagonal are
     // still in the 256 MiB Infinity Cache there).
@@ -680,7 +694,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
     pass_b_issue(L, k, xmode, cr, cr.first, ngroups, gw, pitch, cur);
 
     const PcgState st = L.st[(k + 1) & 1];          // requested together with the partials: one round trip
-    const float pq = (float)fold_partials_256(L.part_pq, nparts_a, s_red);
+    const float pq = (float)fold_band_partials_256(L.band_parts, kPartPq, nparts_a, L.nbands, s_red);
     if (st.stopped) return;
     const float alpha = st.rz / pq;                        // ref .cu:1169
     const float nalpha = (float)(-1. * (double)alpha);     // ref .cu:1174
@@ -738,12 +752,12 @@ __global__ __launch_bounds__(256) void k_flow_update(LevelPtrs L, int nlaunched)
     const float apend = pending ? L.alpha[(n - 1) & 1] : 0.f;
     const float *__restrict__ ppu = L.pu[n & 1];
     const float *__restrict__ ppv = L.pv[n & 1];
-    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int w = L.w, pitch = L.pitch;
     const int gw = (w + 3) / 4;
-    const long ngroups = (long)gw * h;
+    const long ngroups = (long)gw * (L.y1 - L.y0);
     for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
         const int y = (int)(g / gw), x = (int)(g - (long)y * gw) * 4;
-        const size_t o = (size_t)y * pitch + x;
+        const size_t o = (size_t)(L.y0 + y) * pitch + x;
         float4 u = ld4(L.u + o), v = ld4(L.v + o), dx, dy;
         if (pending && n == 1) { dx = make_float4(0, 0, 0, 0); dy = dx; }
         else { dx = ld4(L.xu + o); dy = ld4(L.xv + o); }
@@ -811,8 +825,22 @@ int pcg_grid_size(int w, int h)
     return (int)((items + rounds - 1) / rounds);
 }
 
+// Grid of the 128 x 16 tiled form over `rows` rows: what a row band of a level launches (launch_pcg_pass_a below).
+int pcg_band_grid_size(int w, int rows)
+{
+    const long items = (long)((w + kTileX - 1) / kTileX) * ((rows + 2 * kTileY - 1) / (2 * kTileY));
+    const long cap = 768;
+    if (items <= cap) return (int)(items < 1 ? 1 : items);
+    const long rounds = (items + cap - 1) / cap;
+    return (int)((items + rounds - 1) / rounds);
+}
+
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
+    if (L.nbands > 1 || L.y0 != 0 || L.y1 != L.h) {   // a row band: only the tiled form knows about bands
+        hipLaunchKernelGGL((k_pcg_pass_a<2, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        return;
+    }
     switch (pass_a_choice(L.w, L.h)) {
     case 1: hipLaunchKernelGGL(k_pcg_pass_a_lat<1>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
     case 5: hipLaunchKernelGGL((k_pcg_pass_a<2, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
@@ -829,7 +857,7 @@ void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, i
 
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int nlaunched)
 {
-    hipLaunchKernelGGL(k_flow_update, dim3(stream_grid_size(L.w, L.h)), dim3(256), 0, s, L, nlaunched);
+    hipLaunchKernelGGL(k_flow_update, dim3(stream_grid_size(L.w, L.y1 - L.y0)), dim3(256), 0, s, L, nlaunched);
 }
 
 // ---------------------------------------------------------------------------------------------

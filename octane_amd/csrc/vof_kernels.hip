@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
 {
     __shared__ double s_red[8];
     const int w = L.w, h = L.h, pitch = L.pitch;
-    const int tiles_x = (w + kAsmTX - 1) / kAsmTX, tiles_y = (h + kAsmTY - 1) / kAsmTY;
+    // rows [ya0, ya1): the whole level for a plain plan; a band also fills the first row of each neighbouring band,
+    // so that pass A finds the coefficients and the initial residual of its halo rows without an exchange
+    const int tiles_x = (w + kAsmTX - 1) / kAsmTX, tiles_y = (L.ya1 - L.ya0 + kAsmTY - 1) / kAsmTY;
     const int ntiles = tiles_x * tiles_y;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const double al1 = P.al1, alpha = P.alpha, loa = P.loa;
@@ -220,8 +222,8 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
 
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int ii = (t % tiles_x) * kAsmTX + lx;
-        const int jj = (t / tiles_x) * kAsmTY + ly;
-        if (ii >= w || jj >= h) continue;
+        const int jj = L.ya0 + (t / tiles_x) * kAsmTY + ly;
+        if (ii >= w || jj >= L.ya1) continue;
         // mirrored neighbour coordinates (ref .cu:629-652)
         const int xe = (ii == w - 1) ? ii - 1 : ii + 1;
         const int xw = (ii == 0) ? ii + 1 : ii - 1;
@@ -340,8 +342,10 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
         // r.r and r.z of the initial residual (ref .cu:1115-1126, 1157): z = M r
         float zu = mu * bu;
         float zv = mv * bv;
-        acc_rr += (double)(bu * bu) + (double)(bv * bv);
-        acc_rz += (double)(bu * zu) + (double)(bv * zv);
+        if (jj >= L.y0 && jj < L.y1) {      // halo rows are the neighbouring band's to count
+            acc_rr += (double)(bu * bu) + (double)(bv * bv);
+            acc_rz += (double)(bu * zu) + (double)(bv * zv);
+        }
     }
     double tot_rr = block_sum_256(acc_rr, s_red);
     double tot_rz = block_sum_256(acc_rz, s_red);

@@ -17,6 +17,9 @@ struct Plane {
 constexpr int kMaxChan = 3;
 constexpr int kMaxParts = 2048;      // upper bound on persistent blocks == reduction partials
                                      // (256 CUs x 8 resident 256-thread workgroups)
+constexpr int kMaxBands = 8;         // row bands of one frame solved side by side (vof_tiled.hip)
+constexpr int kPartRz = 0, kPartRr = kMaxParts, kPartPq = 2 * kMaxParts;   // a band's partial block: [rz | rr | pq] x kMaxParts doubles
+constexpr int kBandAlign = 32;       // band boundaries are multiples of this many rows (a whole number of pass A tiles)
 
 // PCG tile geometry: 256 threads, each owning 4 consecutive pixels of one row.
 constexpr int kTileX = 128;
@@ -42,7 +45,16 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     float *ru, *rv, *qu, *qv, *xu, *xv;             // r (starts as rhs), q = A p, x
     float *pu[2], *pv[2];                           // search direction, ping-pong by iteration parity:
                                                     // pass A(k) reads p[k&1] (halo too) and writes p[(k+1)&1]
-    double *part_rz, *part_rr, *part_pq;
+    double *part_rz, *part_rr, *part_pq;            // where THIS launch writes its per-workgroup partials
+    // Row band of the level this launch works on (vof_tiled.hip); a plain plan has one band covering the frame.
+    // Planes are always addressed with frame coordinates: a band's neighbours' rows exist in its planes as halos.
+    int y0, y1;                     // rows this band owns: PCG passes, flow update and the dot products cover [y0, y1)
+    int ya0, ya1;                   // rows the assembly fills: the owned rows plus one halo row on inner edges
+    int nbands;                     // reductions fold the partial blocks of all bands, in band order
+    const double *band_parts[kMaxBands];            // every band's partial block ([rz|rr|pq]); other bands' blocks live
+                                                    // in their own memory (peer-mapped when on another device)
+    const float *ru_up, *rv_up, *ru_dn, *rv_dn;     // the r planes pass A reads rows y0-1 / y1 from: the neighbouring
+                                                    // bands' own planes (this band's for a plain plan)
     PcgState *st;
     float *alpha;                   // alpha of the last two iterations (pass B of iteration k writes alpha[k&1])
     int defer_x;                    // fold x += alpha p of two iterations into every second pass B
@@ -71,6 +83,8 @@ void set_max_blocks(int n);
 void set_grid_multiple(int m);           // tuning knob (<= kMaxParts)
 int  balanced_grid(long work_items);   // persistent grid: every block gets the same number of items (+-1)
 int  pcg_grid_size(int w, int h);
+int  pcg_band_grid_size(int w, int rows);   // pass A grid for a row band (always the 128 x 16 tiled form)
+int  pcg_b_grid_size(int w, int h);
 void set_pass_a_variant(int v);       // tuning knob: tile rows per thread 1 | 2 (default) | 4; 3 = LDS-ring marching experiment
 int  assemble_grid_size(int w, int h);
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid);

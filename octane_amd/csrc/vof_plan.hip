@@ -17,13 +17,12 @@
 
 #include "../../include/octane_vof.h"
 #include "vof_kernels.hpp"
+#include "vof_plan.hpp"
 
-namespace octane {
-int pcg_b_grid_size(int w, int h);
-}
 using namespace octane;
 
 static thread_local std::string g_last_error;
+void octane::set_last_error(const std::string &msg) { g_last_error = msg; }
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -33,55 +32,6 @@ static thread_local std::string g_last_error;
             return OCTANE_E_HIP;                                                               \
         }                                                                                      \
     } while (0)
-
-struct LevelInfo {
-    float factor;
-    int w, h, pitch;
-    int fs;            // blur half width (unused at the finest level)
-    int tap_off;       // offset of this level's taps in the device tap table
-    float lambdac;
-};
-
-struct EvPair { hipEvent_t a, b; int kind; };
-
-struct octane_vof_plan {
-    octane_vof_params prm;
-    int nx, ny, nc, device;
-    int pitch0;
-    size_t plane0;                 // floats per full-resolution plane
-    std::vector<LevelInfo> lev;
-    float *arena = nullptr;
-    size_t arena_bytes = 0;
-    // planes (all plane0 floats unless noted)
-    float *img1p, *img2p, *uh, *vh, *lev1, *lev2;
-    float *gx1, *gy1, *gx2, *gy2, *gxx, *gxy, *gyy;
-    float *U[2], *V[2], *ut, *vt;
-    float *a1, *a2, *a4, *wx, *wy, *mu, *mv, *ru, *rv, *pu[2], *pv[2], *qu, *qv, *xu, *xv, *tmp;
-    float *d_taps = nullptr;
-    double *d_parts = nullptr;     // 3 * kMaxParts
-    PcgState *d_state = nullptr;   // 2
-    float *d_alpha = nullptr;      // 2
-    long long *d_iters = nullptr;
-    long long *h_iters = nullptr;  // pinned
-    hipStream_t own_stream = nullptr;
-    octane_vof_trace_fn trace = nullptr;
-    void *trace_user = nullptr;
-    int profiling = 0;
-    std::vector<EvPair> evs;
-    size_t evs_used = 0;
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
-    octane_vof_profile prof;
-    float tol;
-    int reverse_b = 1;
-    int xcd_bands = 0;
-    int use_small = 1;
-    int defer_x = 1;
-    int use_graph = 0;   // OCTANE_TUNE_GRAPH=1: replay the pyramid as one hipGraph (measured: no throughput gain,
-                         // the host already runs ahead of the GPU; useful only when calls are latency-bound)
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_cur = 0;
-    int nt_hints = 15;   // x, q, mu/mv in pass B and a2 in pass A are single-use: streaming loads/stores
-};
 
 extern "C" const char *octane_last_error(void) { return g_last_error.c_str(); }
 
@@ -152,10 +102,18 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
     L.pu[0] = pl->pu[0]; L.pu[1] = pl->pu[1]; L.pv[0] = pl->pv[0]; L.pv[1] = pl->pv[1];
     L.qu = pl->qu; L.qv = pl->qv; L.xu = pl->xu; L.xv = pl->xv;
     L.part_rz = pl->d_parts; L.part_rr = pl->d_parts + kMaxParts; L.part_pq = pl->d_parts + 2 * kMaxParts;
+    for (int b = 0; b < kMaxBands; b++) L.band_parts[b] = pl->d_parts;
+    L.ru_up = L.ru_dn = pl->ru; L.rv_up = L.rv_dn = pl->rv;
+    L.y0 = 0; L.y1 = li.h; L.ya0 = 0; L.ya1 = li.h; L.nbands = 1;
     L.st = pl->d_state; L.iter_total = pl->d_iters; L.alpha = pl->d_alpha; L.defer_x = pl->defer_x;
     L.reverse_b = pl->reverse_b;
     L.xcd_bands = pl->xcd_bands;
     L.nt_hints = pl->nt_hints;
+}
+
+void octane::plan_fill_level_ptrs(octane_vof_plan *pl, int k, int cur, const LevelCtx &c, LevelPtrs &L)
+{
+    fill_level_ptrs(pl, pl->lev[k], cur, c.lev1, c.lev2, c.ut, c.vt, L);
 }
 
 // Times a few PCG iterations of the finest level on whatever the arena holds (the values do not matter, only
@@ -224,6 +182,11 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
 }
 
 extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int nchan, const octane_vof_params *p)
+{
+    return octane::plan_create_ex(out, nx, ny, nchan, p, 4);
+}
+
+int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, const octane_vof_params *p, int placement_trials)
 {
     if (!out || !p || nx < 2 || ny < 2 || nchan < 1 || nchan > kMaxChan || p->kiters < 1 || p->kiters > 24 ||
         p->liters < 0 || p->cgiters < 0 || !(p->alpha != 0.) || !(p->scaleF > 0. && p->scaleF <= 1.)) {
@@ -354,8 +317,8 @@ extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int
     // pass spread over the HBM channels: the same binary runs pass A at 245 or 264 us at 5000^2 depending on the
     // allocation alone.  For large frames a few candidate arenas are therefore allocated, a short
     // pass A / pass B sequence is timed on each, the fastest is kept and the others are freed.
-    int trials = 4;
-    if (const char *e = getenv("OCTANE_TUNE_PLACEMENT_TRIALS")) trials = atoi(e);
+    int trials = placement_trials;
+    if (const char *e = getenv("OCTANE_TUNE_PLACEMENT_TRIALS")) trials = atoi(e) < trials ? atoi(e) : trials;
     if (trials > 4) trials = 4;
     if (trials > 1 && (long)nx * ny >= (1L << 22) && pl->arena_bytes < ((size_t)24 << 30)) {
         float *cand[4] = {pl->arena, nullptr, nullptr, nullptr};
@@ -447,12 +410,109 @@ static EvPair *ev_begin(octane_vof_plan *pl, hipStream_t s, int kind, bool on)
 }
 static void ev_end(EvPair *p, hipStream_t s) { if (p) (void)hipEventRecord(p->b, s); }
 
-static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
+int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur, LevelCtx &c)
 {
     const octane_vof_params &prm = pl->prm;
     const int nc = pl->nc;
     const int nlev = (int)pl->lev.size();
     const bool hint = (prm.lambdac != 0.);
+    const LevelInfo &li = pl->lev[k];
+    const bool finest = (k == nlev - 1);
+    if (k > 0) {   // ref .cu:498-503: bicubic up-sample of the previous level's flow, divided by scaleF
+        const LevelInfo &lo = pl->lev[k - 1];
+        launch_upsample(s, pl->U[cur], lo.w, lo.h, lo.pitch, pl->U[cur ^ 1], li.w, li.h, li.pitch, (float)prm.scaleF);
+        launch_upsample(s, pl->V[cur], lo.w, lo.h, lo.pitch, pl->V[cur ^ 1], li.w, li.h, li.pitch, (float)prm.scaleF);
+        cur ^= 1;
+    }
+    if (finest) {  // ref .cu:504-517: the finest level uses the inputs themselves
+        c.lev1 = pl->img1p; c.lev2 = pl->img2p; c.ut = pl->uh; c.vt = pl->vh;
+    } else {       // ref .cu:519-563
+        const float *gk = pl->d_taps + li.tap_off;
+        // channel 0 only: the reference's zoom_out samples channel 0 for every channel (.cu:406)
+        launch_blur_rows_sampled(s, pl->img1p, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
+        launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->lev1, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
+        launch_blur_rows_sampled(s, pl->img2p, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
+        launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->lev2, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
+        for (int ch = 1; ch < nc; ch++) {
+            launch_copy2d(s, pl->lev1, li.pitch, pl->lev1 + ch * pl->plane0, li.pitch, li.w, li.h);
+            launch_copy2d(s, pl->lev2, li.pitch, pl->lev2 + ch * pl->plane0, li.pitch, li.w, li.h);
+        }
+        if (hint || k == 0) {   // decimated first guess, scaled to this level's pixel size
+            launch_blur_rows_sampled(s, pl->uh, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
+            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->ut, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
+            launch_blur_rows_sampled(s, pl->vh, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
+            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->vt, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
+        }
+        c.lev1 = pl->lev1; c.lev2 = pl->lev2; c.ut = pl->ut; c.vt = pl->vt;
+    }
+    if (k == 0) {  // ref .cu:576-585
+        launch_copy2d(s, c.ut, li.pitch, pl->U[cur], li.pitch, li.w, li.h);
+        launch_copy2d(s, c.vt, li.pitch, pl->V[cur], li.pitch, li.w, li.h);
+    }
+    // ref .cu:587-595; d/dy of gx2 is dead (overwritten by the fourth call), so it is not stored
+    launch_gradient(s, c.lev1, pl->gx1, pl->gy1, li.w, li.h, li.pitch, nc, pl->plane0);
+    launch_gradient(s, c.lev2, pl->gx2, pl->gy2, li.w, li.h, li.pitch, nc, pl->plane0);
+    launch_gradient(s, pl->gx2, pl->gxx, nullptr, li.w, li.h, li.pitch, nc, pl->plane0);
+    launch_gradient(s, pl->gy2, pl->gxy, pl->gyy, li.w, li.h, li.pitch, nc, pl->plane0);
+    return OCTANE_OK;
+}
+
+int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur, const LevelCtx &c, bool pf)
+{
+    const octane_vof_params &prm = pl->prm;
+    const LevelInfo &li = pl->lev[k];
+    LevelPtrs L;
+    fill_level_ptrs(pl, li, cur, c.lev1, c.lev2, c.ut, c.vt, L);
+
+    const int g_asm = assemble_grid_size(li.w, li.h);
+    const int g_a = pcg_grid_size(li.w, li.h);
+    const int g_b = pcg_b_grid_size(li.w, li.h);
+    const bool small = pl->use_small && pcg_small_applicable(li.w, li.h);
+
+    for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
+        AssembleParams ap;
+        ap.al1 = 1. - 0.5 * gnc;
+        ap.alpha = prm.alpha;
+        ap.loa = prm.lambda / prm.alpha;                // ref .cu:1230
+        ap.lambdac = li.lambdac;
+        ap.dozim = prm.dozim != 0;
+        for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
+            EvPair *e = ev_begin(pl, s, EV_ASM, pf);
+            launch_assemble(s, L, ap, g_asm);
+            ev_end(e, s);
+            if (pl->trace) {
+                int rc = emit(pl, s, "coef7", k, gnc, l, {pl->a1, pl->a2, pl->a4, pl->wx, pl->wy, pl->ru, pl->rv}, li.w, li.h, li.pitch);
+                if (rc) return rc;
+            }
+            if (small) {       // coarsest levels: the whole solve and the flow update in one workgroup
+                launch_pcg_solve_small(s, L, prm.cgiters, pl->tol);
+            } else {
+                for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182
+                    e = ev_begin(pl, s, EV_PASS_A, pf);
+                    launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
+                    ev_end(e, s);
+                    e = ev_begin(pl, s, EV_PASS_B, pf);
+                    launch_pcg_pass_b(s, L, it, g_a, g_b);
+                    ev_end(e, s);
+                }
+                e = ev_begin(pl, s, EV_UPD, pf);
+                launch_flow_update(s, L, prm.cgiters);      // ref .cu:1185-1195
+                ev_end(e, s);
+            }
+            if (pl->trace) {
+                int rc;
+                if ((rc = emit(pl, s, "dx2", k, gnc, l, {pl->xu, pl->xv}, li.w, li.h, li.pitch))) return rc;
+                if ((rc = emit(pl, s, "u", k, gnc, l, {pl->U[cur]}, li.w, li.h, li.pitch))) return rc;
+                if ((rc = emit(pl, s, "v", k, gnc, l, {pl->V[cur]}, li.w, li.h, li.pitch))) return rc;
+            }
+        }
+    }
+    return OCTANE_OK;
+}
+
+static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
+{
+    const int nlev = (int)pl->lev.size();
     int cur = 0;       // U[cur], V[cur] hold the flow of the level being solved
     pl->evs_used = 0;
     const bool prof = pl->profiling != 0;
@@ -466,44 +526,10 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
     for (int k = 0; k < nlev; k++) {
         const LevelInfo &li = pl->lev[k];
         const bool finest = (k == nlev - 1);
-        const float *lev1, *lev2, *ut, *vt;
+        LevelCtx c;
         if (prof) (void)hipEventRecord(pl->ev_s0, s);
-        if (k > 0) {   // ref .cu:498-503: bicubic up-sample of the previous level's flow, divided by scaleF
-            const LevelInfo &lo = pl->lev[k - 1];
-            launch_upsample(s, pl->U[cur], lo.w, lo.h, lo.pitch, pl->U[cur ^ 1], li.w, li.h, li.pitch, (float)prm.scaleF);
-            launch_upsample(s, pl->V[cur], lo.w, lo.h, lo.pitch, pl->V[cur ^ 1], li.w, li.h, li.pitch, (float)prm.scaleF);
-            cur ^= 1;
-        }
-        if (finest) {  // ref .cu:504-517: the finest level uses the inputs themselves
-            lev1 = pl->img1p; lev2 = pl->img2p; ut = pl->uh; vt = pl->vh;
-        } else {       // ref .cu:519-563
-            const float *gk = pl->d_taps + li.tap_off;
-            // channel 0 only: the reference's zoom_out samples channel 0 for every channel (.cu:406)
-            launch_blur_rows_sampled(s, pl->img1p, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
-            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->lev1, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
-            launch_blur_rows_sampled(s, pl->img2p, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
-            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->lev2, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
-            for (int c = 1; c < nc; c++) {
-                launch_copy2d(s, pl->lev1, li.pitch, pl->lev1 + c * pl->plane0, li.pitch, li.w, li.h);
-                launch_copy2d(s, pl->lev2, li.pitch, pl->lev2 + c * pl->plane0, li.pitch, li.w, li.h);
-            }
-            if (hint || k == 0) {   // decimated first guess, scaled to this level's pixel size
-                launch_blur_rows_sampled(s, pl->uh, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
-                launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->ut, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
-                launch_blur_rows_sampled(s, pl->vh, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
-                launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->vt, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
-            }
-            lev1 = pl->lev1; lev2 = pl->lev2; ut = pl->ut; vt = pl->vt;
-        }
-        if (k == 0) {  // ref .cu:576-585
-            launch_copy2d(s, ut, li.pitch, pl->U[cur], li.pitch, li.w, li.h);
-            launch_copy2d(s, vt, li.pitch, pl->V[cur], li.pitch, li.w, li.h);
-        }
-        // ref .cu:587-595; d/dy of gx2 is dead (overwritten by the fourth call), so it is not stored
-        launch_gradient(s, lev1, pl->gx1, pl->gy1, li.w, li.h, li.pitch, nc, pl->plane0);
-        launch_gradient(s, lev2, pl->gx2, pl->gy2, li.w, li.h, li.pitch, nc, pl->plane0);
-        launch_gradient(s, pl->gx2, pl->gxx, nullptr, li.w, li.h, li.pitch, nc, pl->plane0);
-        launch_gradient(s, pl->gy2, pl->gxy, pl->gyy, li.w, li.h, li.pitch, nc, pl->plane0);
+        int rc = plan_level_setup(pl, s, k, cur, c);
+        if (rc) return rc;
         if (prof) {
             (void)hipEventRecord(pl->ev_s1, s);
             (void)hipEventSynchronize(pl->ev_s1);
@@ -512,9 +538,8 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         }
 
         if (pl->trace) {
-            int rc;
-            if ((rc = emit_chan(pl, s, "img1", k, lev1, li.w, li.h, li.pitch))) return rc;
-            if ((rc = emit_chan(pl, s, "img2", k, lev2, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "img1", k, c.lev1, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "img2", k, c.lev2, li.w, li.h, li.pitch))) return rc;
             if ((rc = emit_chan(pl, s, "gx1", k, pl->gx1, li.w, li.h, li.pitch))) return rc;
             if ((rc = emit_chan(pl, s, "gy1", k, pl->gy1, li.w, li.h, li.pitch))) return rc;
             if ((rc = emit_chan(pl, s, "gx2", k, pl->gx2, li.w, li.h, li.pitch))) return rc;
@@ -526,55 +551,8 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
             if ((rc = emit(pl, s, "v0", k, -1, -1, {pl->V[cur]}, li.w, li.h, li.pitch))) return rc;
         }
 
-        LevelPtrs L;
-        fill_level_ptrs(pl, li, cur, lev1, lev2, ut, vt, L);
-
-        const int g_asm = assemble_grid_size(li.w, li.h);
-        const int g_a = pcg_grid_size(li.w, li.h);
-        const int g_b = pcg_b_grid_size(li.w, li.h);
-        const bool pf = prof && finest;
-        const bool small = pl->use_small && pcg_small_applicable(li.w, li.h);
-
-        for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
-            AssembleParams ap;
-            ap.al1 = 1. - 0.5 * gnc;
-            ap.alpha = prm.alpha;
-            ap.loa = prm.lambda / prm.alpha;                // ref .cu:1230
-            ap.lambdac = li.lambdac;
-            ap.dozim = prm.dozim != 0;
-            for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
-                EvPair *e = ev_begin(pl, s, EV_ASM, pf);
-                launch_assemble(s, L, ap, g_asm);
-                ev_end(e, s);
-                if (pl->trace) {
-                    int rc = emit(pl, s, "coef7", k, gnc, l, {pl->a1, pl->a2, pl->a4, pl->wx, pl->wy, pl->ru, pl->rv}, li.w, li.h, li.pitch);
-                    if (rc) return rc;
-                }
-                if (small) {       // coarsest levels: the whole solve and the flow update in one workgroup
-                    launch_pcg_solve_small(s, L, prm.cgiters, pl->tol);
-                } else {
-                for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182
-                    e = ev_begin(pl, s, EV_PASS_A, pf);
-                    launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
-                    ev_end(e, s);
-                    e = ev_begin(pl, s, EV_PASS_B, pf);
-                    launch_pcg_pass_b(s, L, it, g_a, g_b);
-                    ev_end(e, s);
-                }
-                e = ev_begin(pl, s, EV_UPD, pf);
-                launch_flow_update(s, L, prm.cgiters);      // ref .cu:1185-1195
-                ev_end(e, s);
-                }
-                if (pl->trace) {
-                    int rc;
-                    if ((rc = emit(pl, s, "dx2", k, gnc, l, {pl->xu, pl->xv}, li.w, li.h, li.pitch))) return rc;
-                    if ((rc = emit(pl, s, "u", k, gnc, l, {pl->U[cur]}, li.w, li.h, li.pitch))) return rc;
-                    if ((rc = emit(pl, s, "v", k, gnc, l, {pl->V[cur]}, li.w, li.h, li.pitch))) return rc;
-                }
-            }
-        }
+        if ((rc = plan_level_solve(pl, s, k, cur, c, prof && finest))) return rc;
         if (pl->trace) {
-            int rc;
             if ((rc = emit(pl, s, "ulev", k, -1, -1, {pl->U[cur]}, li.w, li.h, li.pitch))) return rc;
             if ((rc = emit(pl, s, "vlev", k, -1, -1, {pl->V[cur]}, li.w, li.h, li.pitch))) return rc;
         }
@@ -619,18 +597,9 @@ extern "C" long long octane_vof_plan_last_iterations(octane_vof_plan *pl)
     return *pl->h_iters;
 }
 
-extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const float *img2,
-                                   float *u, float *v, int mem, void *hip_stream)
+int octane::plan_load_inputs(octane_vof_plan *pl, const float *img1, const float *img2, const float *u, const float *v,
+                             int mem, hipStream_t s)
 {
-    if (!pl || !img1 || !img2 || !u || !v || (mem != OCTANE_MEM_HOST && mem != OCTANE_MEM_DEVICE)) {
-        g_last_error = "octane_vof_plan_run: invalid argument";
-        return OCTANE_E_INVALID;
-    }
-    HIP_TRY(hipSetDevice(pl->device));
-    // Device buffers: the work is ordered on exactly the stream the caller names (NULL is HIP's
-    // null stream, which is what PyTorch's default stream is).  Host buffers: the call blocks
-    // anyway, so NULL selects the plan's private stream.
-    hipStream_t s = (mem == OCTANE_MEM_DEVICE || hip_stream) ? (hipStream_t)hip_stream : pl->own_stream;
     const int nx = pl->nx, ny = pl->ny, nc = pl->nc, p0 = pl->pitch0;
     const size_t dense_row = (size_t)nx * sizeof(float), pitched_row = (size_t)p0 * sizeof(float);
     if (mem == OCTANE_MEM_HOST) {   // ref .cu:1330-1352 (element-wise fills of managed memory there)
@@ -647,6 +616,27 @@ extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const
         }
         launch_copy2d(s, u, nx, pl->uh, p0, nx, ny);
         launch_copy2d(s, v, nx, pl->vh, p0, nx, ny);
+    }
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const float *img2,
+                                   float *u, float *v, int mem, void *hip_stream)
+{
+    if (!pl || !img1 || !img2 || !u || !v || (mem != OCTANE_MEM_HOST && mem != OCTANE_MEM_DEVICE)) {
+        g_last_error = "octane_vof_plan_run: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(pl->device));
+    // Device buffers: the work is ordered on exactly the stream the caller names (NULL is HIP's
+    // null stream, which is what PyTorch's default stream is).  Host buffers: the call blocks
+    // anyway, so NULL selects the plan's private stream.
+    hipStream_t s = (mem == OCTANE_MEM_DEVICE || hip_stream) ? (hipStream_t)hip_stream : pl->own_stream;
+    const int nx = pl->nx, ny = pl->ny, p0 = pl->pitch0;
+    const size_t dense_row = (size_t)nx * sizeof(float), pitched_row = (size_t)p0 * sizeof(float);
+    {
+        const int rc = plan_load_inputs(pl, img1, img2, u, v, mem, s);
+        if (rc) return rc;
     }
     // The launch sequence of a pyramid is fixed for a plan (every pointer and size is the plan's own), so it is
     // captured once into a hipGraph and replayed: the ~4500 launches of a pyramid then cost a kernel boundary

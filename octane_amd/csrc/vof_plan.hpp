@@ -1,0 +1,78 @@
+// vof_plan.hpp -- the plan object behind include/octane_vof.h and the pieces of its level loop that the row-band
+// coordinator (vof_tiled.hip) drives band by band.  Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/octane_vof.h"
+#include "vof_kernels.hpp"
+
+struct LevelInfo {
+    float factor;
+    int w, h, pitch;
+    int fs;            // blur half width (unused at the finest level)
+    int tap_off;       // offset of this level's taps in the device tap table
+    float lambdac;
+};
+
+struct EvPair { hipEvent_t a, b; int kind; };
+
+struct octane_vof_plan {
+    octane_vof_params prm;
+    int nx, ny, nc, device;
+    int pitch0;
+    size_t plane0;                 // floats per full-resolution plane
+    std::vector<LevelInfo> lev;
+    float *arena = nullptr;
+    size_t arena_bytes = 0;
+    // planes (all plane0 floats unless noted)
+    float *img1p, *img2p, *uh, *vh, *lev1, *lev2;
+    float *gx1, *gy1, *gx2, *gy2, *gxx, *gxy, *gyy;
+    float *U[2], *V[2], *ut, *vt;
+    float *a1, *a2, *a4, *wx, *wy, *mu, *mv, *ru, *rv, *pu[2], *pv[2], *qu, *qv, *xu, *xv, *tmp;
+    float *d_taps = nullptr;
+    double *d_parts = nullptr;     // 3 * kMaxParts
+    octane::PcgState *d_state = nullptr;   // 2
+    float *d_alpha = nullptr;      // 2
+    long long *d_iters = nullptr;
+    long long *h_iters = nullptr;  // pinned
+    hipStream_t own_stream = nullptr;
+    octane_vof_trace_fn trace = nullptr;
+    void *trace_user = nullptr;
+    int profiling = 0;
+    std::vector<EvPair> evs;
+    size_t evs_used = 0;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
+    octane_vof_profile prof;
+    float tol;
+    int reverse_b = 1;
+    int xcd_bands = 0;
+    int use_small = 1;
+    int defer_x = 1;
+    int use_graph = 0;   // OCTANE_TUNE_GRAPH=1: replay the pyramid as one hipGraph (measured: no throughput gain,
+                         // the host already runs ahead of the GPU; useful only when calls are latency-bound)
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_cur = 0;
+    int nt_hints = 15;   // x, q, mu/mv in pass B and a2 in pass A are single-use: streaming loads/stores
+};
+
+
+namespace octane {
+
+struct LevelCtx { const float *lev1, *lev2, *ut, *vt; };   // where level k's images and first-guess hint live
+
+void set_last_error(const std::string &msg);
+// Plan without the placement trials (several bands may share one device, and the trials allocate 4 arenas).
+int  plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, const octane_vof_params *p, int placement_trials);
+// Level k up to the point where the solve starts: flow up-sampling (flips `cur`), pyramid images, gradients.
+// Everything is computed for the whole level -- bands replicate this work instead of exchanging halos for it.
+int  plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur, LevelCtx &c);
+// The three GNC steps x liters linearisations x cgiters PCG iterations of level k over the whole level.
+int  plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur, const LevelCtx &c, bool profile_kernels);
+void plan_fill_level_ptrs(octane_vof_plan *pl, int k, int cur, const LevelCtx &c, LevelPtrs &L);
+// Upload (host) or copy (device) the inputs into the plan's planes on stream s / copy the flow of U[cur],V[cur] out.
+int  plan_load_inputs(octane_vof_plan *pl, const float *img1, const float *img2, const float *u, const float *v, int mem, hipStream_t s);
+
+}  // namespace octane

@@ -121,6 +121,24 @@ def num_threads(flavour: str = "strict") -> int:
     return int(lib(flavour).oct_oracle_num_threads())
 
 
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: the scheduler affinity, cut down to the cgroup CPU quota if one is set
+    (a GPU box shows all 256 hardware threads but grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def set_threads(n: int, flavour: str = "omp") -> None:
+    lib(flavour).oct_oracle_set_threads(int(n))
+
+
 REF_GRID_THREADS = 20 * 16 * 128   # the reference's launch: 20 SMs (hard-coded, ref .cu:1422) x 16 blocks x 128 threads
 
 

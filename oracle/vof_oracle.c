@@ -53,6 +53,16 @@ int oct_oracle_num_threads(void)
 #endif
 }
 
+/* Limit the OpenMP build to n threads (a container's CPU quota is usually smaller than the machine). */
+void oct_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ---------------------------------------------------------------- helpers */
 
 /* ref .cu:26-41 oct_bc_cu: clamp (not reflect) to [0, n-1]; reports a hit. */

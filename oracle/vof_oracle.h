@@ -31,6 +31,7 @@ typedef struct oct_oracle_planes { float *a1, *a2, *a4, *a5, *a6, *a7, *a8, *bu,
 typedef struct oct_oracle_cgwork { float *z, *p, *rk, *tmp; int *ident; } oct_oracle_cgwork;
 
 int   oct_oracle_num_threads(void);
+void  oct_oracle_set_threads(int n);
 void  oct_oracle_level_dims(int nx, int ny, float factor, int *lx, int *ly);
 float oct_oracle_level_factor(float scale, int kiters, int k);
 int   oct_oracle_blur_halfwidth(float factor);

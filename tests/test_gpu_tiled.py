@@ -1,0 +1,175 @@
+"""One frame solved as row bands (BASELINE.json configs[3], SURVEY.md 8e "spatial tiles of one frame"), through the
+C-ABI (octane_vof_tiled_*).  A one-GPU box runs the bands as virtual ranks on the same device: the kernels, the band
+bookkeeping, the halo / partial exchanges and their ordering are exactly the ones several devices would run; only
+the copies are device-local instead of peer copies.
+
+The banded solve computes the same global PCG as the plain plan -- same operator, same recurrences, same stop test
+-- and differs only in the summation order of the dot products, so it must sit as close to the plain result as
+two valid reduction orders do (~1e-6) and meet the same oracle bar."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from octane_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ORDER_BAR = 2e-5     # two reduction orders of the same solve (measured ~1e-6; sensitive parameter sets excluded)
+
+
+def _plain(capi, a, b, prm, u0=None, v0=None):
+    nc, ny, nx = (1,) + a.shape if a.ndim == 2 else a.shape
+    pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm))
+    u, v = pl.run_host(a, b, u0, v0)
+    its = pl.last_iterations()
+    pl.close()
+    return u, v, its
+
+
+def _tiled(capi, a, b, prm, nbands, min_band_pixels=1, u0=None, v0=None, devices=None):
+    nc, ny, nx = (1,) + a.shape if a.ndim == 2 else a.shape
+    tp = capi.TiledPlan(nx, ny, nc, capi.FlowParams(**prm), nbands=nbands, devices=devices or [0] * nbands,
+                        min_band_pixels=min_band_pixels)
+    u, v = tp.run_host(a, b, u0, v0)
+    info = dict(its=tp.last_iterations(), banded=tp.banded_levels, copies=tp.last_copies(),
+                rows=[[tp.band_rows(k, bnd) for bnd in range(nbands)] for k in range(prm.get("kiters", 4))])
+    tp.close()
+    return u, v, info
+
+
+def test_one_band_is_the_plain_plan(capi):
+    a, b = synth.lattice_scene(200, 150, seed=4)
+    prm = dict(kiters=3)
+    up, vp, ip = _plain(capi, a, b, prm)
+    ut, vt, info = _tiled(capi, a, b, prm, 1)
+    assert info["banded"] == 0 and info["copies"] == 0 and info["its"] == ip
+    assert np.array_equal(up, ut) and np.array_equal(vp, vt)
+
+
+@pytest.mark.parametrize("nbands", [2, 3, 4])
+def test_bands_match_plain_plan_and_oracle(capi, oracle, nbands):
+    nx, ny = 300, 420
+    a, b = synth.lattice_scene(nx, ny, seed=31)
+    prm = dict(kiters=3, liters=2, cgiters=20)
+    up, vp, ip = _plain(capi, a, b, prm)
+    ut, vt, info = _tiled(capi, a, b, prm, nbands)
+    assert np.isfinite(ut).all() and np.isfinite(vt).all()
+    # levels are 75x105, 150x210, 300x420: a band needs 32 rows, so 4 bands leave the coarsest level replicated
+    assert info["banded"] == (2 if nbands == 4 else 3)
+    assert info["its"] == ip and info["copies"] > 0
+    for k, lev in enumerate(info["rows"]):
+        if lev[0][0]:                                    # banded: contiguous cover, aligned inner edges
+            assert lev[0][1] == 0
+            for lo, hi in zip(lev[:-1], lev[1:]):
+                assert lo[2] == hi[1] and lo[2] % 32 == 0
+    d = rel_l2(ut, vt, up, vp)
+    assert d < ORDER_BAR, f"banded vs plain: {d:.3e}"
+    uo, vo, io = oracle.flow(a, b, oracle.FlowParams(**prm), dot_threads=oracle.REF_GRID_THREADS)
+    assert io == info["its"]
+    assert rel_l2(ut, vt, uo, vo) < ORDER_BAR
+
+
+def test_bands_with_first_guess_hint_and_two_channels(capi, oracle):
+    """lambdac != 0 reads the decimated first guess in the assembly; two channels go through the channel-0
+    decimation quirk; the first guess also seeds the coarsest level."""
+    nx, ny = 260, 200
+    a, b = synth.lattice_scene(nx, ny, seed=8, nchan=2)
+    rng = np.random.RandomState(3)
+    u0 = (2.0 + 0.2 * rng.randn(ny, nx)).astype(np.float32)
+    v0 = (-1.0 + 0.2 * rng.randn(ny, nx)).astype(np.float32)
+    prm = dict(kiters=2, liters=2, cgiters=15, lambdac=0.4)
+    up, vp, ip = _plain(capi, a, b, prm, u0, v0)
+    ut, vt, info = _tiled(capi, a, b, prm, 3, u0=u0, v0=v0)
+    assert info["banded"] == 2 and info["its"] == ip
+    assert rel_l2(ut, vt, up, vp) < ORDER_BAR
+    uo, vo, _ = oracle.flow(a, b, oracle.FlowParams(**prm), u0=u0, v0=v0, dot_threads=oracle.REF_GRID_THREADS)
+    assert rel_l2(ut, vt, uo, vo) < ORDER_BAR
+
+
+def test_wide_frame_many_tiles_per_band(capi):
+    """Several 128-column tiles per band row and several tile rows per band: every workgroup of the persistent
+    kernels walks more than one tile, halo rows are stored by many workgroups."""
+    nx, ny = 1700, 1100
+    a, b = synth.lattice_scene(nx, ny, seed=12)
+    prm = dict(kiters=2, liters=1, cgiters=12)
+    up, vp, ip = _plain(capi, a, b, prm)
+    ut, vt, info = _tiled(capi, a, b, prm, 4)
+    assert info["banded"] == 2 and info["its"] == ip
+    assert rel_l2(ut, vt, up, vp) < ORDER_BAR
+
+
+def test_small_levels_stay_replicated_by_default_threshold(capi):
+    """With the default threshold (12 Mpixel) nothing at 2000 x 1500 is banded: every band solves every level and
+    band 0's result is the plain plan's, bit for bit."""
+    nx, ny = 2000, 1500
+    a, b = synth.lattice_scene(nx, ny, seed=5)
+    prm = dict(kiters=3, liters=1, cgiters=6)
+    up, vp, _ = _plain(capi, a, b, prm)
+    ut, vt, info = _tiled(capi, a, b, prm, 2, min_band_pixels=0)
+    assert info["banded"] == 0 and info["copies"] == 0
+    assert np.array_equal(up, ut) and np.array_equal(vp, vt)
+
+
+def test_mixed_replicated_and_banded_levels(capi):
+    """Threshold between the levels: the coarse ones replicated, the two finest banded -- the hand-over (every band
+    holds the whole coarse flow; the banded level all-gathers its bands at its end) in both directions."""
+    nx, ny = 1200, 900
+    a, b = synth.lattice_scene(nx, ny, seed=21)
+    prm = dict(kiters=4, liters=1, cgiters=10)
+    up, vp, ip = _plain(capi, a, b, prm)
+    ut, vt, info = _tiled(capi, a, b, prm, 3, min_band_pixels=200_000)   # 150x113, 300x225 replicated
+    assert info["banded"] == 2 and info["its"] == ip
+    assert rel_l2(ut, vt, up, vp) < ORDER_BAR
+
+
+def test_device_resident_inputs_and_repeated_solves(capi):
+    """load (dense device buffers) / solve / fetch, twice on the same plan: same bits as the host-buffer run."""
+    import torch
+    nx, ny = 640, 512
+    a, b = synth.lattice_scene(nx, ny, seed=2)
+    prm = dict(kiters=3, liters=1, cgiters=10)
+    uh, vh, info = _tiled(capi, a, b, prm, 2)
+    dev = torch.device("cuda:0")
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    tu, tv = torch.zeros(ny, nx, device=dev), torch.zeros(ny, nx, device=dev)
+    ou, ov = torch.empty(ny, nx, device=dev), torch.empty(ny, nx, device=dev)
+    torch.cuda.synchronize()
+    tp = capi.TiledPlan(nx, ny, 1, capi.FlowParams(**prm), nbands=2, devices=[0, 0], min_band_pixels=1)
+    tp.load_device(ta.data_ptr(), tb.data_ptr(), tu.data_ptr(), tv.data_ptr())
+    for _ in range(2):
+        tp.solve()
+        tp.fetch_device(ou.data_ptr(), ov.data_ptr())
+        assert tp.last_iterations() == info["its"]
+        assert np.array_equal(ou.cpu().numpy(), uh) and np.array_equal(ov.cpu().numpy(), vh)
+    tp.close()
+
+
+def test_full_disk_quarter_scale_four_bands(capi):
+    """5424 x 5424 (the second level of a 10848^2 full-disk pyramid; 29 Mpixel, above the default banding
+    threshold), four bands, default threshold: the finest level is banded, the 2712^2 one replicated.  Checked
+    against the plain plan on the same inputs."""
+    import torch
+    n = 5424
+    dev = torch.device("cuda:0")
+    a, b = synth.lattice_scene(n, n, seed=20240613 + 3, device=dev)
+    z = torch.zeros(n, n, device=dev)
+    ou, ov = torch.empty(n, n, device=dev), torch.empty(n, n, device=dev)
+    prm = capi.FlowParams(kiters=6, liters=1, cgiters=8)
+    torch.cuda.synchronize()
+    pl = capi.Plan(n, n, 1, prm)
+    pl.run_device(a.data_ptr(), b.data_ptr(), ou.data_ptr(), ov.data_ptr())
+    torch.cuda.synchronize()
+    up, vp, ip = ou.cpu().numpy(), ov.cpu().numpy(), pl.last_iterations()
+    pl.close()
+    tp = capi.TiledPlan(n, n, 1, prm, nbands=4, devices=[0, 0, 0, 0])
+    assert tp.banded_levels == 1
+    banded, y0, y1 = tp.band_rows(5, 2)
+    assert banded and (y0, y1) == (2720, 4064)
+    tp.load_device(a.data_ptr(), b.data_ptr(), z.data_ptr(), z.data_ptr())
+    tp.solve()
+    tp.fetch_device(ou.data_ptr(), ov.data_ptr())
+    ut, vt = ou.cpu().numpy(), ov.cpu().numpy()
+    assert tp.last_iterations() == ip
+    tp.close()
+    assert np.isfinite(ut).all() and np.isfinite(vt).all()
+    assert rel_l2(ut, vt, up, vp) < ORDER_BAR

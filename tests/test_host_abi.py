@@ -90,3 +90,27 @@ def test_cpp_host_path_equals_the_python_binding(host_demo, capi, tmp_path):
     want = capi.pix2uv(nav, 1000.0, 1300.0, ue, ve)
     for i in range(4):
         assert np.array_equal(shorts[i], want[i])
+
+
+@pytest.mark.gpu
+def test_cpp_host_path_with_row_bands(host_demo, capi, tmp_path):
+    """OCTANE_VOF_BANDS=2 sends oct_variational_optical_flow() through the row-band solve (two virtual bands on
+    device 0 here); the flow is the plain solve's up to reduction order, and the navigated shorts follow it."""
+    import os
+    from conftest import rel_l2
+    from octane_amd import synth
+    nx, ny = 320, 288
+    a, b = synth.lattice_scene(nx, ny, seed=7)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(a.tobytes()); f.write(b.tobytes())
+    env = dict(os.environ, OCTANE_VOF_BANDS="2", OCTANE_TUNE_MIN_BAND_PIXELS="1")
+    r = subprocess.run([host_demo, "--run", str(nx), str(ny), str(inp), str(outp), "-i1", "x", "-i2", "y", "-kiters", "3"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(outp, "rb").read()
+    n = nx * ny
+    u = np.frombuffer(raw, np.float32, n, 0).reshape(ny, nx)
+    v = np.frombuffer(raw, np.float32, n, 4 * n).reshape(ny, nx)
+    ue, ve = capi.flow(a, b, capi.FlowParams(kiters=3))
+    assert rel_l2(u, v, ue, ve) < 2e-5
