@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=5000)
+    ap.add_argument("--size", type=int, default=None, help="frame edge: 5000 (pair), 10848 (tiled) unless given")
     ap.add_argument("--kiters", type=int, default=8)
     ap.add_argument("--liters", type=int, default=3)
     ap.add_argument("--cgiters", type=int, default=30)
@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--bands", type=int, default=4, help="row bands of the tiled workload")
     ap.add_argument("--cpu-sample", type=int, default=1536, help="edge of the CPU-baseline sample pair")
     args = ap.parse_args()
+    if args.size is None:
+        args.size = 10848 if args.workload == "tiled" else 5000
 
     import torch
     import torch.distributed as dist

@@ -346,6 +346,14 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
             return OCTANE_E_HIP;
         }
     }
+    // hipMemset on device memory is enqueued on the null stream and may return before it has run; the plan's own
+    // stream does not synchronise with the null stream, so without this a first upload could be overtaken by the
+    // poison fill (seen with two plans created back to back).
+    if (hipDeviceSynchronize() != hipSuccess) {
+        g_last_error = "octane_vof_plan_create: device synchronisation failed";
+        octane_vof_plan_destroy(pl);
+        return OCTANE_E_HIP;
+    }
     *out = pl;
     return OCTANE_OK;
 }

@@ -142,6 +142,8 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
             rc = OCTANE_E_NOMEM;
         }
     }
+    for (int b = 0; b < nbands && rc == OCTANE_OK; b++)      // the fills above ran on the null stream
+        if (hipSetDevice(t->dev[b]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = OCTANE_E_HIP;
     if (rc != OCTANE_OK) { octane_vof_tiled_destroy(t); return rc; }
 
     // Row bands per level: boundaries at multiples of kBandAlign rows, every band at least kBandAlign rows.

@@ -153,7 +153,7 @@ def test_full_disk_quarter_scale_four_bands(capi):
     dev = torch.device("cuda:0")
     a, b = synth.lattice_scene(n, n, seed=20240613 + 3, device=dev)
     z = torch.zeros(n, n, device=dev)
-    ou, ov = torch.empty(n, n, device=dev), torch.empty(n, n, device=dev)
+    ou, ov = torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)     # in-out: zero first guess
     prm = capi.FlowParams(kiters=6, liters=1, cgiters=8)
     torch.cuda.synchronize()
     pl = capi.Plan(n, n, 1, prm)

@@ -48,6 +48,9 @@ def main():
         t = time.perf_counter() - t0
         tp.fetch_device(ou.data_ptr(), ov.data_ptr())
         ut, vt = ou.cpu().numpy(), ov.cpu().numpy()
+        bad = np.where((~np.isfinite(ut)).any(axis=1))[0]
+        if len(bad):
+            print(f"   non-finite rows: {bad.min()}..{bad.max()} ({len(bad)} rows), iterations {tp.last_iterations()}", flush=True)
         num = ((ut.astype(np.float64) - up) ** 2 + (vt.astype(np.float64) - vp) ** 2).sum()
         den = (up.astype(np.float64) ** 2 + vp.astype(np.float64) ** 2).sum()
         print(f"{nb} virtual band(s)    : {t * 1e3:8.2f} ms  {n * n / t / 1e6:7.2f} Mpix/s  host issue {t_issue * 1e3:7.2f} ms  "
