@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PASS_A_BYTES_PER_PIXEL = 36 + 16   # reads r(2) p(2) a1 a2 a4 wx wy, writes p(2) q(2)  -- DESIGN.md
+PASS_A_BYTES_PER_PIXEL_GNC0 = 28 + 16   # first GNC step (a third of the launches): wx == wy == -1, the planes are not read
 PASS_B_BYTES_PER_PIXEL = 40 + 16   # reads x(2) r(2) p(2) q(2) a1 a4, writes x(2) r(2)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -212,8 +213,12 @@ def main():
         plan.set_profiling(False)
         a_ms = pr.pass_a_ms / max(1, pr.pass_a_launches)
         b_ms = pr.pass_b_ms / max(1, pr.pass_b_launches)
+        # mean algorithmic bytes of a finest-level pass A launch: the three GNC steps run the same number of launches
+        bpp_a = PASS_A_BYTES_PER_PIXEL
+        if os.environ.get("OCTANE_TUNE_UNIT_W", "1") != "0":
+            bpp_a = (PASS_A_BYTES_PER_PIXEL_GNC0 + 2 * PASS_A_BYTES_PER_PIXEL) / 3.0
         if pr.pass_a_ms >= pr.pass_b_ms:
-            dom, dms, bpp = "k_pcg_pass_a", a_ms, PASS_A_BYTES_PER_PIXEL
+            dom, dms, bpp = "k_pcg_pass_a", a_ms, bpp_a
         else:
             dom, dms, bpp = "k_pcg_pass_b", b_ms, PASS_B_BYTES_PER_PIXEL
         # HBM-side traffic of that kernel from the PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be
@@ -229,7 +234,7 @@ def main():
         iter_gbs = (PASS_A_BYTES_PER_PIXEL + PASS_B_BYTES_PER_PIXEL + 8) * n * n / ((a_ms + b_ms) * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": round(dms, 4), "bytes_per_launch": bpp * n * n,
+                "avg_launch_ms": round(dms, 4), "bytes_per_launch": int(round(bpp * n * n)),
                 "pass_a_ms": round(a_ms, 4), "pass_b_ms": round(b_ms, 4),
                 "pcg_iteration_gbs_at_116B_per_pixel": round(iter_gbs, 1),
                 "assemble_ms": round(pr.assemble_ms / max(1, pr.assemble_launches), 4),

@@ -66,7 +66,10 @@ __device__ __forceinline__ float direction(float r, float pold, float diag, floa
 // r, p_old and the diagonal of the neighbouring pixels), then q = A p_new is formed from LDS + registers.  R = 2
 // (128 x 16) is the default: against R = 1 the two halo rows are amortised over 16 rows and there are half as many
 // barriers per pixel (-6 % time); R = 4 needs 236 VGPRs and loses more in occupancy than it saves.
-template <int R, bool WIDE>
+// UNITW: the first GNC step (al1 == 1) makes every neighbour weight exactly -1 (k_assemble: a7 = a8 =
+// (float)(-1 * (1 + 0 * psi)) ), so the wx / wy planes hold a constant and are not read: 44 instead of 52 B/pixel for
+// a third of all iterations, same bits.
+template <int R, bool WIDE, bool UNITW>
 __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int nparts_prev, float tol)
 {
     constexpr int TY = WIDE ? kTileY : kTileY * R;          // tile rows
@@ -132,10 +135,16 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
                 *(float4 *)a1[q] = ld4(L.a1 + o);
                 *(float4 *)a4[q] = ld4(L.a4 + o);
                 *(float4 *)a2[q] = ld4_if(L.a2 + o, L.nt_hints & 8);
-                *(float4 *)wxc[q] = ld4(L.wx + o);
-                *(float4 *)wyc[q] = ld4(L.wy + o);
-                if (y > 0) *(float4 *)wys[q] = ld4(L.wy + o - pitch);
-                if (x > 0) wxw[q] = L.wx[o - 1];
+                if (UNITW) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { wxc[q][e] = -1.f; wyc[q][e] = -1.f; wys[q][e] = -1.f; }
+                    wxw[q] = -1.f;
+                } else {
+                    *(float4 *)wxc[q] = ld4(L.wx + o);
+                    *(float4 *)wyc[q] = ld4(L.wy + o);
+                    if (y > 0) *(float4 *)wys[q] = ld4(L.wy + o - pitch);
+                    if (x > 0) wxw[q] = L.wx[o - 1];
+                }
                 float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
                 if (!first) { *(float4 *)pu = ld4(pin_u + o); *(float4 *)pv = ld4(pin_v + o); }
 #pragma unroll
@@ -462,6 +471,7 @@ constexpr int kRingRow = kMarchW + 8;     // [3 pad][west px][1024 interior][eas
 
 struct RawRow { float4 ru, rv, pu, pv, a1, a4; float s[6]; };   // s: the strip-end pixel's r,p,a (2 lanes only)
 
+template <bool UNITW>
 __global__ __launch_bounds__(256, 3) void k_pcg_pass_a_ring(LevelPtrs L, int k, int nparts_prev, float tol)
 {
     __shared__ double s_red[8];
@@ -549,18 +559,27 @@ __global__ __launch_bounds__(256, 3) void k_pcg_pass_a_ring(LevelPtrs L, int k, 
         float wym[4] = {0, 0, 0, 0};
         float4 a2n = make_float4(0, 0, 0, 0), wxn = a2n, wyn = a2n;
         float wx_side_c = 0.f, wx_side_n = 0.f;
+        if (UNITW) {        // first GNC step: every neighbour weight is exactly -1, the planes are not read
+#pragma unroll
+            for (int e = 0; e < 4; e++) { wxc[e] = -1.f; wyc[e] = -1.f; wym[e] = -1.f; }
+            wxn = make_float4(-1.f, -1.f, -1.f, -1.f); wyn = wxn;
+            wx_side_c = -1.f; wx_side_n = -1.f;
+        }
 
         __syncthreads();                             // a previous run may still be reading the ring
         if (y0 > 0) {
             issue(y0 - 1, raw);
-            if (colok) *(float4 *)wym = ld4(L.wy + (size_t)(y0 - 1) * pitch + x);
+            if (!UNITW && colok) *(float4 *)wym = ld4(L.wy + (size_t)(y0 - 1) * pitch + x);
             deposit(y0 - 1, raw);
         }
         {
             const size_t oc = (size_t)y0 * pitch + x;
             issue(y0, raw);
-            if (colok) { *(float4 *)a2c = ld4_if(L.a2 + oc, L.nt_hints & 8); *(float4 *)wxc = ld4(L.wx + oc); *(float4 *)wyc = ld4(L.wy + oc); }
-            if (west_side) wx_side_c = L.wx[oc - 1];
+            if (colok) {
+                *(float4 *)a2c = ld4_if(L.a2 + oc, L.nt_hints & 8);
+                if (!UNITW) { *(float4 *)wxc = ld4(L.wx + oc); *(float4 *)wyc = ld4(L.wy + oc); }
+            }
+            if (!UNITW && west_side) wx_side_c = L.wx[oc - 1];
             deposit(y0, raw);
             *(float4 *)a1c = raw.a1; *(float4 *)a4c = raw.a4;
             if (lane == 63) s_wxe[y0 & 1][wave] = wxc[3];
@@ -575,8 +594,11 @@ __global__ __launch_bounds__(256, 3) void k_pcg_pass_a_ring(LevelPtrs L, int k, 
             }
             if (have_next) {
                 const size_t on = (size_t)(y + 1) * pitch + x;
-                if (colok) { a2n = ld4_if(L.a2 + on, L.nt_hints & 8); wxn = ld4(L.wx + on); wyn = ld4(L.wy + on); }
-                if (west_side) wx_side_n = L.wx[on - 1];
+                if (colok) {
+                    a2n = ld4_if(L.a2 + on, L.nt_hints & 8);
+                    if (!UNITW) { wxn = ld4(L.wx + on); wyn = ld4(L.wy + on); }
+                }
+                if (!UNITW && west_side) wx_side_n = L.wx[on - 1];
                 if (y + 2 < h) issue(y + 2, raw);    // in flight while q(y) is evaluated
             }
             __syncthreads();
@@ -807,6 +829,22 @@ static int pass_a_choice(int w, int h)
     return 2;
 }
 
+static int g_unit_cap = 768;
+void set_unit_w_cap(int c) { g_unit_cap = (c >= 256 && c <= kMaxParts) ? c : 768; }
+
+// Grid of the unit-weight launches (first GNC step).  The tiled form needs 128 instead of 152 VGPRs there, so four
+// instead of three workgroups per CU are resident.
+int pcg_grid_size_unit_w(int w, int h)
+{
+    const int variant = pass_a_choice(w, h);
+    if (variant != 2) return pcg_grid_size(w, h);
+    const long items = (long)((w + kTileX - 1) / kTileX) * ((h + kTileY * 2 - 1) / (kTileY * 2));
+    const long cap = g_unit_cap;
+    if (items <= cap) return (int)items;
+    const long rounds = (items + cap - 1) / cap;
+    return (int)((items + rounds - 1) / rounds);
+}
+
 int pcg_grid_size(int w, int h)
 {
     const int variant = pass_a_choice(w, h);
@@ -838,15 +876,22 @@ int pcg_band_grid_size(int w, int rows)
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
     if (L.nbands > 1 || L.y0 != 0 || L.y1 != L.h) {   // a row band: only the tiled form knows about bands
-        hipLaunchKernelGGL((k_pcg_pass_a<2, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        if (L.unit_w) hipLaunchKernelGGL((k_pcg_pass_a<2, false, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        else hipLaunchKernelGGL((k_pcg_pass_a<2, false, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
         return;
     }
     switch (pass_a_choice(L.w, L.h)) {
     case 1: hipLaunchKernelGGL(k_pcg_pass_a_lat<1>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
-    case 5: hipLaunchKernelGGL((k_pcg_pass_a<2, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
-    case 4: hipLaunchKernelGGL((k_pcg_pass_a<4, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
-    case 3: hipLaunchKernelGGL(k_pcg_pass_a_ring, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
-    default: hipLaunchKernelGGL((k_pcg_pass_a<2, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    case 5: hipLaunchKernelGGL((k_pcg_pass_a<2, true, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    case 4: hipLaunchKernelGGL((k_pcg_pass_a<4, false, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol); break;
+    case 3:
+        if (L.unit_w) hipLaunchKernelGGL(k_pcg_pass_a_ring<true>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        else hipLaunchKernelGGL(k_pcg_pass_a_ring<false>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        break;
+    default:
+        if (L.unit_w) hipLaunchKernelGGL((k_pcg_pass_a<2, false, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        else hipLaunchKernelGGL((k_pcg_pass_a<2, false, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        break;
     }
 }
 

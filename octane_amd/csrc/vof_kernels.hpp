@@ -62,6 +62,7 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     int reverse_b;                  // pass B walks the frame backwards (Infinity-Cache reuse)
     int nt_hints;                   // bit mask of streaming-load/store hints (tuning)
     int xcd_bands;                  // give each XCD (blockIdx % 8) one contiguous band of the frame
+    int unit_w;                     // this linearisation has al1 == 1: wx == wy == -1 everywhere, pass A need not read them
 };
 
 struct AssembleParams {
@@ -83,6 +84,8 @@ void set_max_blocks(int n);
 void set_grid_multiple(int m);           // tuning knob (<= kMaxParts)
 int  balanced_grid(long work_items);   // persistent grid: every block gets the same number of items (+-1)
 int  pcg_grid_size(int w, int h);
+int  pcg_grid_size_unit_w(int w, int h);     // pass A grid of the unit-weight (first GNC step) launches
+void set_unit_w_cap(int c);
 int  pcg_band_grid_size(int w, int rows);   // pass A grid for a row band (always the 128 x 16 tiled form)
 int  pcg_b_grid_size(int w, int h);
 void set_pass_a_variant(int v);       // tuning knob: tile rows per thread 1 | 2 (default) | 4; 3 = LDS-ring marching experiment

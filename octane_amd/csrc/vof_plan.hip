@@ -109,6 +109,7 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
     L.reverse_b = pl->reverse_b;
     L.xcd_bands = pl->xcd_bands;
     L.nt_hints = pl->nt_hints;
+    L.unit_w = 0;
 }
 
 void octane::plan_fill_level_ptrs(octane_vof_plan *pl, int k, int cur, const LevelCtx &c, LevelPtrs &L)
@@ -213,6 +214,8 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_NT")) pl->nt_hints = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_DEFER_X")) pl->defer_x = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_GRAPH")) pl->use_graph = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_UNIT_W")) pl->use_unit_w = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_UNIT_W_CAP")) set_unit_w_cap(atoi(e));
     pcg_small_configure();
     set_grid_multiple(pl->xcd_bands ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
@@ -473,7 +476,8 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
     fill_level_ptrs(pl, li, cur, c.lev1, c.lev2, c.ut, c.vt, L);
 
     const int g_asm = assemble_grid_size(li.w, li.h);
-    const int g_a = pcg_grid_size(li.w, li.h);
+    const int g_a_plain = pcg_grid_size(li.w, li.h);
+    const int g_a_unit = pcg_grid_size_unit_w(li.w, li.h);
     const int g_b = pcg_b_grid_size(li.w, li.h);
     const bool small = pl->use_small && pcg_small_applicable(li.w, li.h);
 
@@ -484,6 +488,8 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
         ap.loa = prm.lambda / prm.alpha;                // ref .cu:1230
         ap.lambdac = li.lambdac;
         ap.dozim = prm.dozim != 0;
+        L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;   // al1 == 1: all neighbour weights are exactly -1
+        const int g_a = L.unit_w ? g_a_unit : g_a_plain;
         for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
             EvPair *e = ev_begin(pl, s, EV_ASM, pf);
             launch_assemble(s, L, ap, g_asm);
@@ -1005,6 +1011,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "nt") pl->nt_hints = value;
     else if (k == "defer_x") pl->defer_x = value != 0;
     else if (k == "small") pl->use_small = value != 0;
+    else if (k == "unit_w") pl->use_unit_w = value != 0;
     else return OCTANE_E_INVALID;
     return OCTANE_OK;
 }

@@ -51,6 +51,7 @@ struct octane_vof_plan {
     int xcd_bands = 0;
     int use_small = 1;
     int defer_x = 1;
+    int use_unit_w = 1;  // pass A skips the wx / wy planes while they hold the constant -1 (first GNC step)
     int use_graph = 0;   // OCTANE_TUNE_GRAPH=1: replay the pyramid as one hipGraph (measured: no throughput gain,
                          // the host already runs ahead of the GPU; useful only when calls are latency-bound)
     hipGraphExec_t graph_exec = nullptr;

@@ -305,6 +305,7 @@ static void solve_level_banded(BandRun &R, int b, int k, int cur, const LevelCtx
         ap.loa = prm.lambda / prm.alpha;                // ref .cu:1230
         ap.lambdac = li.lambdac;
         ap.dozim = prm.dozim != 0;
+        L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;
         for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
             if (!R.failed.load()) launch_assemble(s, L, ap, g_asm);
             sync_bands(R, b);

@@ -206,6 +206,27 @@ def test_deferred_x_update_is_bitwise_identical(capi, cgiters):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("variant", [2, 3])
+def test_unit_weight_pass_a_is_bitwise_identical(capi, variant):
+    """In the first GNC step every neighbour weight is exactly -1 and pass A does not read the wx / wy planes;
+    the result must equal the plane-reading form bit for bit (tiled and marching forms of pass A forced)."""
+    nx, ny = 1150, 700
+    a, b = synth.lattice_scene(nx, ny, seed=23)
+    prm = capi.FlowParams(kiters=2, liters=1, cgiters=9)
+    outs = []
+    for unit in (0, 1):
+        pl = capi.Plan(nx, ny, 1, prm)
+        try:
+            pl.tune("pass_a", variant)
+            pl.tune("unit_w", unit)
+            outs.append(pl.run_host(a, b))
+        finally:
+            pl.tune("pass_a", 0)
+            pl.close()
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_level_too_small_is_an_error(capi):
     a = np.zeros((1, 20, 20), np.float32)
     with pytest.raises(capi.OctaneError) as e:
