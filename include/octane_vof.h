@@ -133,6 +133,10 @@ int octane_vof_tiled_solve(octane_vof_tiled *t);
 int octane_vof_tiled_wait(octane_vof_tiled *t);
 int octane_vof_tiled_fetch(octane_vof_tiled *t, float *u, float *v, int mem);
 int octane_vof_tiled_run(octane_vof_tiled *t, const float *img1, const float *img2, float *u_inout, float *v_inout, int mem);
+/* How `rows` rows are cut into nbands bands: fills edges[0..nbands] (edges[0] = 0, edges[nbands] = rows, inner edges at
+ * multiples of 32 rows) and returns 1; returns 0 when such a level stays replicated (one band, or fewer than 32 rows
+ * for some band); negative on bad arguments.  Host arithmetic only (no GPU needed). */
+int octane_vof_band_partition(int rows, int nbands, int *edges);
 int octane_vof_tiled_banded_levels(const octane_vof_tiled *t);                 /* how many levels are split into bands */
 int octane_vof_tiled_band_rows(const octane_vof_tiled *t, int level, int band, int *y0, int *y1);   /* 1 banded, 0 replicated */
 long long octane_vof_tiled_last_iterations(octane_vof_tiled *t);               /* PCG iterations of the last pyramid */

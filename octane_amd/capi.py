@@ -27,7 +27,7 @@ EXPORTS = (
     "octane_vof_tiled_create", "octane_vof_tiled_destroy", "octane_vof_tiled_load", "octane_vof_tiled_solve",
     "octane_vof_tiled_wait", "octane_vof_tiled_fetch", "octane_vof_tiled_run", "octane_vof_tiled_banded_levels",
     "octane_vof_tiled_band_rows", "octane_vof_tiled_last_iterations", "octane_vof_tiled_last_copies",
-    "octane_vof_tiled_device_bytes",
+    "octane_vof_tiled_device_bytes", "octane_vof_band_partition",
     "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
     "octane_uv2pix_run", "octane_srsal_run",
     "octane_last_error", "octane_device_count",
@@ -143,6 +143,7 @@ def lib() -> C.CDLL:
     L.octane_vof_tiled_last_copies.restype = C.c_longlong
     L.octane_vof_tiled_device_bytes.argtypes = [vp]
     L.octane_vof_tiled_device_bytes.restype = C.c_size_t
+    L.octane_vof_band_partition.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.octane_pix2uv_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, C.c_int, C.c_int,
                                     vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     L.octane_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(NavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
@@ -268,6 +269,15 @@ class Plan:
         p = VofProfile()
         lib().octane_vof_plan_get_profile(self._h, C.byref(p))
         return p
+
+
+def band_partition(rows: int, nbands: int):
+    """Row-band edges [0, ..., rows] of a level with `rows` rows, or None when it stays replicated (no GPU needed)."""
+    e = (C.c_int * (nbands + 1))()
+    rc = lib().octane_vof_band_partition(rows, nbands, e)
+    if rc < 0:
+        raise OctaneError(rc, "octane_vof_band_partition")
+    return list(e) if rc == 1 else None
 
 
 class TiledPlan:

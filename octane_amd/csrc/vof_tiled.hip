@@ -73,6 +73,22 @@ struct octane_vof_tiled {
 
 static int round_to(int v, int m) { return (v + m / 2) / m * m; }
 
+// How `rows` rows of a level are cut into `nbands` bands: edges[0] = 0 <= edges[1] <= ... <= edges[nbands] = rows, inner
+// edges at multiples of 32 rows (whole pass A tiles) as close to equal shares as that allows.  Returns 1 and fills
+// edges[0..nbands], or 0 when the level cannot be banded (a single band, or a band would get fewer than 32 rows) --
+// such levels are solved redundantly by every band.  Pure host arithmetic: needs no GPU.
+extern "C" int octane_vof_band_partition(int rows, int nbands, int *edges)
+{
+    if (!edges || rows < 1 || nbands < 1 || nbands > kMaxBands) return OCTANE_E_INVALID;
+    if (nbands < 2 || rows < nbands * kBandAlign) return 0;
+    edges[0] = 0;
+    edges[nbands] = rows;
+    for (int b = 1; b < nbands; b++) edges[b] = round_to((int)((long)rows * b / nbands), kBandAlign);
+    for (int b = 0; b < nbands; b++)
+        if (edges[b + 1] - edges[b] < kBandAlign) return 0;
+    return 1;
+}
+
 extern "C" int octane_vof_tiled_destroy(octane_vof_tiled *t)
 {
     if (!t) return OCTANE_OK;
@@ -146,20 +162,17 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
         if (hipSetDevice(t->dev[b]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = OCTANE_E_HIP;
     if (rc != OCTANE_OK) { octane_vof_tiled_destroy(t); return rc; }
 
-    // Row bands per level: boundaries at multiples of kBandAlign rows, every band at least kBandAlign rows.
+    // Row bands per level (octane_vof_band_partition); levels it declines stay replicated.
     const std::vector<LevelInfo> &lev = t->pl[0]->lev;
     t->rows.resize(lev.size());
     for (size_t k = 0; k < lev.size(); k++) {
         const LevelInfo &li = lev[k];
-        if (nbands < 2 || (long)li.w * li.h < t->min_band_pixels || li.h < nbands * kBandAlign) continue;
+        if ((long)li.w * li.h < t->min_band_pixels) continue;
+        int edges[kMaxBands + 1];
+        if (octane_vof_band_partition(li.h, nbands, edges) != 1) continue;
         std::vector<BandRows> r(nbands);
-        bool ok = true;
-        for (int b = 0; b < nbands; b++) {
-            r[b].y0 = (b == 0) ? 0 : round_to((int)((long)li.h * b / nbands), kBandAlign);
-            r[b].y1 = (b == nbands - 1) ? li.h : round_to((int)((long)li.h * (b + 1) / nbands), kBandAlign);
-            ok = ok && (r[b].y1 - r[b].y0 >= kBandAlign);
-        }
-        if (ok) t->rows[k] = r;
+        for (int b = 0; b < nbands; b++) { r[b].y0 = edges[b]; r[b].y1 = edges[b + 1]; }
+        t->rows[k] = r;
     }
     *out = t;
     return OCTANE_OK;

@@ -89,3 +89,27 @@ def test_single_hip_runtime_whatever_the_import_order(capi):
     import torch  # noqa: F401
     mapped = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
     assert len(mapped) == 1, mapped
+
+
+def test_band_partition_covers_the_level_with_aligned_inner_edges(capi):
+    """Row bands of the multi-GPU solve (host arithmetic, no GPU): contiguous cover, inner edges on whole pass A tiles
+    (32 rows), no band thinner than 32 rows, near-equal shares; levels that cannot be cut stay replicated."""
+    for rows in (64, 105, 210, 1356, 2712, 5424, 10848, 4999):
+        for nb in range(1, 9):
+            e = capi.band_partition(rows, nb)
+            if nb == 1 or rows < 32 * nb:
+                assert e is None
+                continue
+            if e is None:          # rounding squeezed a band below 32 rows: only possible close to the limit
+                assert rows < 32 * (nb + 2)
+                continue
+            assert e[0] == 0 and e[-1] == rows and len(e) == nb + 1
+            for lo, hi in zip(e[:-1], e[1:]):
+                assert hi - lo >= 32
+            for inner in e[1:-1]:
+                assert inner % 32 == 0
+            share = rows / nb
+            assert max(abs((hi - lo) - share) for lo, hi in zip(e[:-1], e[1:])) <= 32
+    assert capi.band_partition(10848, 4) == [0, 2720, 5440, 8128, 10848]
+    with pytest.raises(capi.OctaneError):
+        capi.band_partition(100, 9)
