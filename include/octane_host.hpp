@@ -37,6 +37,16 @@ void oct_navcal_cuda(short *data2, short *data2s, short *x, short *y, short *xs,
                      OFFlags args);
 // ref src/oct_normalize_geo.cc:9: per-band radiance range; leaves the outputs untouched for an unknown band
 void oct_bandminmax(int gb, float &maxch, float &minch);
+// ref src/oct_polar_navcal_cuda.cu:64 / src/oct_merc_navcal_cuda.cu:52 (called by the polar / mercator readers,
+// src/oct_fileread.cc:567,728): navigation of re-mapped float images; lon0 / lat1 in degrees.  The polar form writes
+// channel `chan` (1-based) of data3, i.e. at offset (chan-1) * window size, as the reference does.
+void oct_polar_navcal_cuda(float *data2, short *data2s, short *x, short *y, short *xs, short *ys, int nx, int ny,
+                           int minx, int maxx, int miny, int maxy, float *data3, float *lat, float *lon, float xScale,
+                           float xOffset, float yScale, float yOffset, float lon0, float lat1, float R, int donav,
+                           int chan, OFFlags args);
+void oct_merc_navcal_cuda(float *data2, short *data2s, short *x, short *y, short *xs, short *ys, int nx, int ny,
+                          int minx, int maxx, int miny, int maxy, float *data3, float *lat, float *lon, float xScale,
+                          float xOffset, float yScale, float yOffset, float lon0, float R, int donav, OFFlags args);
 
 // The `octane` command line (ref src/main.cc:42-50 spellings, :53-108 defaults, :166-350 scan), including
 // its quirks: -scsig squares its argument, -set_device is 1-based, -corn clears docorn, -cgiters is not parsed.

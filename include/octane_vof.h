@@ -181,6 +181,20 @@ typedef struct octane_navcal_params {
 int octane_navcal_run(const short *data2, const short *x, const short *y, int nx, int ny,
                       const octane_navcal_params *p, float *data3, float *lat, float *lon,
                       short *data2s, short *xs, short *ys, int device);
+
+/* Navigation of re-mapped polar (mode OCTANE_NAV_POLAR) and mercator (OCTANE_NAV_MERC) inputs: the float pixel values
+ * pass through to data3 (window [minx,maxx) x [miny,maxy)), lat / lon (degrees) come from the inverse projection, data2s
+ * is zero-filled and xs / ys receive the window's coordinate shorts.  lon0 / lat1 in DEGREES as the reference's callers
+ * pass them (lat1 is unused for mercator).
+ * Replaces oct_polar_navcal_cuda (src/oct_polar_navcal_cuda.cu:64) and oct_merc_navcal_cuda (src/oct_merc_navcal_cuda.cu:52). */
+typedef struct octane_proj_navcal_params {
+    float xScale, xOffset, yScale, yOffset, lon0, lat1, R;
+    int donav, mode;
+    int minx, maxx, miny, maxy;
+} octane_proj_navcal_params;
+int octane_proj_navcal_run(const float *data2, const short *x, const short *y, int nx, int ny,
+                           const octane_proj_navcal_params *p, float *data3, float *lat, float *lon,
+                           short *data2s, short *xs, short *ys, int device);
 /* Per-band radiance range used for the normalisation when the user gives none (src/oct_normalize_geo.cc:9-88).
  * Returns 0, or OCTANE_E_INVALID for a band outside 1..16 (the reference leaves the outputs untouched then). */
 int octane_bandminmax(int band, float *maxch, float *minch);

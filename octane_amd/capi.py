@@ -29,7 +29,7 @@ EXPORTS = (
     "octane_vof_tiled_band_rows", "octane_vof_tiled_last_iterations", "octane_vof_tiled_last_copies",
     "octane_vof_tiled_device_bytes", "octane_vof_band_partition",
     "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
-    "octane_uv2pix_run", "octane_srsal_run",
+    "octane_proj_navcal_run", "octane_uv2pix_run", "octane_srsal_run",
     "octane_last_error", "octane_device_count",
 )
 
@@ -68,6 +68,12 @@ TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                        C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int)
 
 _lib = None
+
+
+class ProjNavcalParams(C.Structure):
+    _fields_ = [("xScale", C.c_float), ("xOffset", C.c_float), ("yScale", C.c_float), ("yOffset", C.c_float),
+                ("lon0", C.c_float), ("lat1", C.c_float), ("R", C.c_float), ("donav", C.c_int), ("mode", C.c_int),
+                ("minx", C.c_int), ("maxx", C.c_int), ("miny", C.c_int), ("maxy", C.c_int)]
 
 
 def _preload_hip_runtime() -> None:
@@ -147,6 +153,7 @@ def lib() -> C.CDLL:
     L.octane_pix2uv_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, C.c_int, C.c_int,
                                     vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     L.octane_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(NavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
+    L.octane_proj_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(ProjNavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
     L.octane_bandminmax.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.octane_uv2pix_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, C.c_int]
     L.octane_srsal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
@@ -439,6 +446,22 @@ def navcal(data2, x, y, prm: NavcalParams, device: int = 0):
                                  _ptr(d2s), _ptr(xs), _ptr(ys), device)
     if rc != OK:
         raise OctaneError(rc, "octane_navcal_run")
+    return data3, lat, lon, d2s, xs, ys
+
+
+def proj_navcal(data2, x, y, prm: ProjNavcalParams, device: int = 0):
+    """Polar / mercator navigation of a re-mapped float image [ny, nx] -> (data3, lat, lon, data2s, xs, ys) of prm's window."""
+    d2 = np.ascontiguousarray(data2, np.float32)
+    ny, nx = d2.shape
+    xx, yy = np.ascontiguousarray(x, np.int16), np.ascontiguousarray(y, np.int16)
+    ww, wh = prm.maxx - prm.minx, prm.maxy - prm.miny
+    data3, lat, lon = (np.zeros((max(wh, 0), max(ww, 0)), np.float32) for _ in range(3))
+    d2s = np.ones((max(wh, 0), max(ww, 0)), np.int16)
+    xs, ys = np.zeros(max(ww, 0), np.int16), np.zeros(max(wh, 0), np.int16)
+    rc = lib().octane_proj_navcal_run(_ptr(d2), _ptr(xx), _ptr(yy), nx, ny, C.byref(prm), _ptr(data3), _ptr(lat), _ptr(lon),
+                                      _ptr(d2s), _ptr(xs), _ptr(ys), device)
+    if rc != OK:
+        raise OctaneError(rc, "octane_proj_navcal_run")
     return data3, lat, lon, d2s, xs, ys
 
 

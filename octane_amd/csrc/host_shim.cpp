@@ -174,6 +174,47 @@ void oct_navcal_cuda(short *data2, short *data2s, short *x, short *y, short *xs,
     if (rc != OCTANE_OK) std::cerr << "oct_navcal_cuda: " << octane_last_error() << " (code " << rc << ")\n";
 }
 
+static void proj_navcal(const char *who, int mode, float *data2, short *data2s, short *x, short *y, short *xs, short *ys,
+                        int nx, int ny, int minx, int maxx, int miny, int maxy, float *data3, float *lat, float *lon,
+                        float xScale, float xOffset, float yScale, float yOffset, float lon0, float lat1, float R, int donav,
+                        const OFFlags &args)
+{
+    octane_proj_navcal_params p;
+    p.xScale = xScale; p.xOffset = xOffset; p.yScale = yScale; p.yOffset = yOffset; p.lon0 = lon0; p.lat1 = lat1; p.R = R;
+    p.donav = donav; p.mode = mode; p.minx = minx; p.maxx = maxx; p.miny = miny; p.maxy = maxy;
+    const int ndev = octane_device_count();
+    if (ndev == 0) {                              // ref pnav:84-88, mnav:69-73
+        std::cout << "No gpus available for use, exiting\n";
+        exit(0);
+    }
+    int dev = args.setdevice;
+    if (dev > ndev - 1) {
+        std::cout << "Warning: setdevice set to non-existent GPU, setting to default GPU 1\n";
+        dev = 0;
+    }
+    const int rc = octane_proj_navcal_run(data2, x, y, nx, ny, &p, data3, lat, lon, data2s, xs, ys, dev);
+    if (rc != OCTANE_OK) std::cerr << who << ": " << octane_last_error() << " (code " << rc << ")\n";
+}
+
+void oct_polar_navcal_cuda(float *data2, short *data2s, short *x, short *y, short *xs, short *ys, int nx, int ny,
+                           int minx, int maxx, int miny, int maxy, float *data3, float *lat, float *lon, float xScale,
+                           float xOffset, float yScale, float yOffset, float lon0, float lat1, float R, int donav,
+                           int chan, OFFlags args)
+{
+    const long n2 = (long)(maxx - minx) * (maxy - miny);
+    proj_navcal("oct_polar_navcal_cuda", OCTANE_NAV_POLAR, data2, data2s, x, y, xs, ys, nx, ny, minx, maxx, miny, maxy,
+                data3 + (long)(chan - 1) * n2 /* ref pnav:140-143 */, lat, lon, xScale, xOffset, yScale, yOffset, lon0, lat1, R,
+                donav, args);
+}
+
+void oct_merc_navcal_cuda(float *data2, short *data2s, short *x, short *y, short *xs, short *ys, int nx, int ny,
+                          int minx, int maxx, int miny, int maxy, float *data3, float *lat, float *lon, float xScale,
+                          float xOffset, float yScale, float yOffset, float lon0, float R, int donav, OFFlags args)
+{
+    proj_navcal("oct_merc_navcal_cuda", OCTANE_NAV_MERC, data2, data2s, x, y, xs, ys, nx, ny, minx, maxx, miny, maxy, data3,
+                lat, lon, xScale, xOffset, yScale, yOffset, lon0, 0.f, R, donav, args);
+}
+
 void oct_bandminmax(int gb, float &maxch, float &minch)
 {
     float mx, mn;

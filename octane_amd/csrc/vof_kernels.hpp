@@ -115,6 +115,13 @@ struct NavcalArgs {
 void launch_navcal(hipStream_t s, const NavcalArgs &A, const short *x, const short *y, const short *data2,
                    float *data3, float *lat, float *lon, short *data2s);
 
+struct ProjNavcalArgs {          // polar (mode 1) / mercator (mode 2) navigation; lon0, lat1 in radians
+    float xScale, xOffset, yScale, yOffset, R, lon0, lat1;
+    int donav, mode, nx, ny, minx, maxx, miny, maxy;
+};
+void launch_proj_navcal(hipStream_t s, const ProjNavcalArgs &A, const short *x, const short *y, const float *data2,
+                        float *data3, float *lat, float *lon);
+
 struct Uv2pixArgs {
     double secs, req, req2, rpol, rpol2, eval, lam0, pph;
     float xscale, xoffset, yscale, yoffset;

@@ -886,6 +886,58 @@ extern "C" int octane_navcal_run(const short *data2, const short *x, const short
     return rc;
 }
 
+extern "C" int octane_proj_navcal_run(const float *data2, const short *x, const short *y, int nx, int ny,
+                                      const octane_proj_navcal_params *p, float *data3, float *lat, float *lon,
+                                      short *data2s, short *xs, short *ys, int device)
+{
+    if (!data2 || !x || !y || !p || !data3 || !lat || !lon || !data2s || !xs || !ys || nx < 1 || ny < 1 ||
+        p->minx < 0 || p->miny < 0 || p->maxx > nx || p->maxy > ny || p->maxx <= p->minx || p->maxy <= p->miny ||
+        (p->mode != OCTANE_NAV_POLAR && p->mode != OCTANE_NAV_MERC)) {
+        g_last_error = "octane_proj_navcal_run: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    int ndev = octane_device_count();
+    if (ndev == 0) { g_last_error = "No gpus available for use"; return OCTANE_E_NODEVICE; }
+    if (device > ndev - 1 || device < 0) device = 0;
+    HIP_TRY(hipSetDevice(device));
+    const long n = (long)nx * ny, n2 = (long)(p->maxx - p->minx) * (p->maxy - p->miny);
+    for (int i = p->minx; i < p->maxx; i++) xs[i - p->minx] = x[i];       // ref pnav:122-129, mnav:104-111
+    for (int j = p->miny; j < p->maxy; j++) ys[j - p->miny] = y[j];
+    for (long k = 0; k < n2; k++) data2s[k] = 0;                          // ref pnav:119, mnav:101
+    const double PI = 3.14159265359, DTOR = PI / 180.;
+    ProjNavcalArgs A;
+    A.xScale = p->xScale; A.xOffset = p->xOffset; A.yScale = p->yScale; A.yOffset = p->yOffset; A.R = p->R;
+    A.lon0 = (float)(p->lon0 * DTOR);                                     // ref pnav:138, mnav:119: degrees -> radians, as float arguments
+    A.lat1 = (float)(p->lat1 * DTOR);
+    A.donav = p->donav; A.mode = p->mode; A.nx = nx; A.ny = ny;
+    A.minx = p->minx; A.maxx = p->maxx; A.miny = p->miny; A.maxy = p->maxy;
+    float *d_in = nullptr, *d_out = nullptr;
+    short *d_xy = nullptr;
+    hipStream_t s = nullptr;
+    int rc = OCTANE_OK;
+    do {
+        if (hipMalloc((void **)&d_in, n * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&d_xy, (size_t)(nx + ny) * sizeof(short)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&d_out, 3 * n2 * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipStreamCreate(&s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(d_in, data2, n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(d_xy, x, nx * sizeof(short), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(d_xy + nx, y, ny * sizeof(short), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        launch_proj_navcal(s, A, d_xy, d_xy + nx, d_in, d_out, d_out + n2, d_out + 2 * n2);
+        if (hipGetLastError() != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(data3, d_out, n2 * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(lat, d_out + n2, n2 * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(lon, d_out + 2 * n2, n2 * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+    } while (0);
+    if (rc != OCTANE_OK) g_last_error = "octane_proj_navcal_run: HIP failure";
+    if (s) (void)hipStreamDestroy(s);
+    if (d_in) (void)hipFree(d_in);
+    if (d_xy) (void)hipFree(d_xy);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // uv2pix (ref src/oct_pix2uv_cuda.cu:372-476) and srsal (ref src/oct_srsal_cuda.cu:73-147)
 // ---------------------------------------------------------------------------------------------

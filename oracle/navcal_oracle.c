@@ -57,3 +57,48 @@ void oct_oracle_navcal(const short *data2, const short *x, const short *y, int n
         }
     }
 }
+
+/* Polar (mode 1, ref src/oct_polar_navcal_cuda.cu:11-62 kernel, :64-163 wrapper) and mercator (mode 2, ref
+ * src/oct_merc_navcal_cuda.cu:11-50, :52-143) navigation of re-mapped inputs: pixel values pass through, lat / lon
+ * from the inverse projection.  lon0 / lat1 arrive in degrees and are converted to float radians as the wrappers'
+ * kernel arguments are.  The reference's `cos(lat1)` / `sin(lat1)` take a float and resolve to the float overloads
+ * in C++; C has no overloads, hence cosf / sinf here.  `lat1 > 89.99999` compares radians: never true (kept). */
+void oct_oracle_proj_navcal(const float *data2, const short *x, const short *y, int nx, int ny,
+                            const oct_oracle_proj_navcal_params *p, float *data3, float *lat, float *lon,
+                            short *data2s, short *xs, short *ys)
+{
+    const double PI = 3.14159265359;
+    const double DTOR = PI / 180.;
+    const int ww = p->maxx - p->minx;
+    const float lon0 = (float)(p->lon0 * DTOR), lat1 = (float)(p->lat1 * DTOR);
+    const float R = p->R;
+    for (int j = p->miny; j < p->maxy; j++) {
+        ys[j - p->miny] = y[j];
+        for (int i = p->minx; i < p->maxx; i++) {
+            long lxyz = (long)i + (long)nx * j;
+            long lxyz2 = (long)(i - p->minx) + (long)ww * (j - p->miny);
+            xs[i - p->minx] = x[i];
+            data2s[lxyz2] = 0;
+            double xVal = x[i] * p->xScale + p->xOffset;                   /* float arithmetic first */
+            double yVal = y[j] * p->yScale + p->yOffset;
+            float la = 0.f, lo = 0.f;
+            if (p->donav == 1) {
+                if (p->mode == 1) {
+                    double rho = sqrt(xVal * xVal + yVal * yVal);
+                    double c = asin(rho / R);
+                    if (lat1 > 89.99999) lo = (float)(lon0 + atan2(xVal, -yVal));
+                    else lo = (float)(lon0 + atan2(xVal * sin(c), (rho * cosf(lat1) * cos(c) - yVal * sinf(lat1) * sin(c))));
+                    if (rho > 0.0000001) la = (float)asin(cos(c) * sinf(lat1) + (yVal * sin(c) * cosf(lat1) / rho));
+                    else la = lat1;
+                } else {
+                    lo = (float)(xVal / R + lon0);
+                    la = (float)(PI / 2. - 2. * atan(exp(-yVal / R)));
+                }
+                la = (float)(la / DTOR);
+                lo = (float)(lo / DTOR);
+            }
+            lat[lxyz2] = la; lon[lxyz2] = lo;
+            data3[lxyz2] = data2[lxyz];
+        }
+    }
+}

@@ -215,6 +215,28 @@ def navcal(data2: np.ndarray, x: np.ndarray, y: np.ndarray, prm: NavcalParams):
     return data3, lat, lon, d2s, xs, ys
 
 
+class ProjNavcalParams(C.Structure):
+    _fields_ = [("xScale", C.c_float), ("xOffset", C.c_float), ("yScale", C.c_float), ("yOffset", C.c_float),
+                ("lon0", C.c_float), ("lat1", C.c_float), ("R", C.c_float), ("donav", C.c_int), ("mode", C.c_int),
+                ("minx", C.c_int), ("maxx", C.c_int), ("miny", C.c_int), ("maxy", C.c_int)]
+
+
+def proj_navcal(data2: np.ndarray, x: np.ndarray, y: np.ndarray, prm: ProjNavcalParams):
+    """Polar (mode 1) / mercator (mode 2) navigation.  Returns (data3, lat, lon, data2s, xs, ys) for prm's window."""
+    d2 = np.ascontiguousarray(data2, np.float32)
+    ny, nx = d2.shape
+    ww, wh = prm.maxx - prm.minx, prm.maxy - prm.miny
+    data3, lat, lon = (np.zeros((wh, ww), np.float32) for _ in range(3))
+    d2s = np.ones((wh, ww), np.int16)
+    xs, ys = np.zeros(ww, np.int16), np.zeros(wh, np.int16)
+    L = lib()
+    L.oct_oracle_proj_navcal.argtypes = [_F, _S, _S, C.c_int, C.c_int, C.POINTER(ProjNavcalParams), _F, _F, _F, _S, _S, _S]
+    L.oct_oracle_proj_navcal.restype = None
+    L.oct_oracle_proj_navcal(d2.ravel(), np.ascontiguousarray(x, np.int16), np.ascontiguousarray(y, np.int16), nx, ny,
+                             C.byref(prm), data3.ravel(), lat.ravel(), lon.ravel(), d2s.ravel(), xs, ys)
+    return data3, lat, lon, d2s, xs, ys
+
+
 def uv2pix(nav: Nav, t1: float, t2: float, u, v, lat, lon, gx, gy):
     uu = np.array(u, np.float32, order="C", copy=True); vv = np.array(v, np.float32, order="C", copy=True)
     L = lib()

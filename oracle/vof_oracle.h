@@ -85,6 +85,15 @@ void oct_oracle_navcal(const short *data2, const short *x, const short *y, int n
                        const oct_oracle_navcal_params *p, float *data3, float *lat, float *lon,
                        short *data2s, short *xs, short *ys);
 
+typedef struct oct_oracle_proj_navcal_params {
+    float xScale, xOffset, yScale, yOffset, lon0, lat1, R;   /* lon0, lat1 in degrees */
+    int donav, mode;                                          /* mode 1 polar, 2 mercator */
+    int minx, maxx, miny, maxy;
+} oct_oracle_proj_navcal_params;
+void oct_oracle_proj_navcal(const float *data2, const short *x, const short *y, int nx, int ny,
+                            const oct_oracle_proj_navcal_params *p, float *data3, float *lat, float *lon,
+                            short *data2s, short *xs, short *ys);
+
 /* ---- uv2pix / srsal (post_oracle.c) ---- */
 void oct_oracle_uv2pix(const oct_oracle_nav *nav, double t1, double t2, float *u_inout, float *v_inout,
                        const float *lat, const float *lon, const short *gx, const short *gy);

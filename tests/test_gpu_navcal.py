@@ -82,3 +82,43 @@ def test_counts_to_winds_chain(capi, oracle):
     u, v = capi.flow(g1, g2, capi.FlowParams(kiters=3))
     uo, vo, _ = oracle.flow(o1, o2, oracle.FlowParams(kiters=3), dot_threads=oracle.REF_GRID_THREADS)
     assert rel_l2(u, v, uo, vo) < 2e-5
+
+
+def _proj_case(nx, ny, mode):
+    rng = np.random.RandomState(9)
+    data2 = (255.0 * rng.rand(ny, nx)).astype(np.float32)
+    x = (np.arange(nx) - nx // 2).astype(np.int16)
+    y = (ny // 2 - np.arange(ny)).astype(np.int16)
+    if mode == 1:      # polar grid of 4 km pixels in metres around the pole; corners fall outside the sphere's disc
+        kw = dict(xScale=16000.0, xOffset=2000.0, yScale=16000.0, yOffset=-2000.0, lon0=-45.0, lat1=90.0, R=6371228.0)
+    else:              # mercator, metres
+        kw = dict(xScale=8000.0, xOffset=0.0, yScale=8000.0, yOffset=1000.0, lon0=-100.0, lat1=0.0, R=6378137.0)
+    return data2, x, y, kw
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_polar_and_mercator_navigation_match_oracle(capi, oracle, mode):
+    nx, ny = 640, 520
+    data2, x, y, kw = _proj_case(nx, ny, mode)
+    win = dict(minx=13, maxx=nx - 20, miny=7, maxy=ny - 11)
+    got = capi.proj_navcal(data2, x, y, capi.ProjNavcalParams(donav=1, mode=mode, **kw, **win))
+    want = oracle.proj_navcal(data2, x, y, oracle.ProjNavcalParams(donav=1, mode=mode, **kw, **win))
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[0], data2[7:ny - 11, 13:nx - 20])   # values pass through
+    for g, w, nm in zip(got[1:3], want[1:3], ("lat", "lon")):
+        assert np.array_equal(np.isnan(g), np.isnan(w)), nm       # polar: rho > R has no inverse
+        ok = ~np.isnan(w)
+        assert ok.mean() > 0.5
+        ulp = np.abs(g[ok].view(np.int32).astype(np.int64) - w[ok].view(np.int32))
+        # OCML vs glibc differ by an ulp in sin / cos / asin now and then; next to the pole asin is evaluated near 1,
+        # where one ulp of its argument is tens of ulps of the angle (still < 1e-3 degree)
+        assert ulp.max() <= (64 if mode == 1 else 1), f"{nm}: up to {ulp.max()} ulp"
+        assert (ulp <= 1).mean() > 0.999 and (ulp == 0).mean() > 0.99, (nm, (ulp <= 1).mean(), (ulp == 0).mean())
+        assert np.abs(g[ok].astype(np.float64) - w[ok]).max() < 1e-3
+    assert not got[3].any()                                       # data2s is zero-filled
+    assert np.array_equal(got[4], x[13:nx - 20]) and np.array_equal(got[5], y[7:ny - 11])
+    if mode == 2:      # closed form: lon = x/R + lon0, Gudermannian latitude
+        xv = (x[13:nx - 20].astype(np.float32) * np.float32(kw["xScale"]) + np.float32(kw["xOffset"])).astype(np.float64)
+        assert np.allclose(got[2][0], np.degrees(xv / kw["R"]) + kw["lon0"], atol=1e-4)
+    # donav = 0: no navigation, zeros
+    got0 = capi.proj_navcal(data2, x, y, capi.ProjNavcalParams(donav=0, mode=mode, **kw, **win))
+    assert not got0[1].any() and not got0[2].any() and np.array_equal(got0[0], got[0])

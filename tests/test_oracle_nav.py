@@ -86,3 +86,29 @@ def test_srsal_known_answers(oracle):
     # without the edge in the guide it is a plain Gaussian blur across the step
     uo2, _ = oracle.srsal(u, v, np.zeros_like(c))
     assert 3.0 < uo2[20, 24] < uo2[20, 25] < 7.0
+
+
+def test_projected_navigation_known_answers(oracle):
+    """Mercator: lon = x/R + lon0 and the Gudermannian latitude; polar (orthographic about lat1 = 90 deg): the pole
+    itself, the great-circle distance c = asin(rho/R) => lat = 90 - c, and no inverse outside the disc."""
+    R = 6371228.0
+    x = np.array([-300, 0, 300], np.int16)
+    y = np.array([0, 250, -250], np.int16)
+    d = np.zeros((3, 3), np.float32)
+    m = oracle.proj_navcal(d, x, y, oracle.ProjNavcalParams(xScale=10000.0, xOffset=0.0, yScale=10000.0, yOffset=0.0, lon0=-100.0,
+                                                             lat1=0.0, R=R, donav=1, mode=2, minx=0, maxx=3, miny=0, maxy=3))
+    xv, yv = x.astype(np.float64) * 1e4, y.astype(np.float64) * 1e4
+    assert np.allclose(m[2][0], np.degrees(xv / R) - 100.0, atol=2e-5)
+    assert np.allclose(m[1][:, 0], np.degrees(np.pi / 2 - 2 * np.arctan(np.exp(-yv / R))), atol=2e-5)
+    p = oracle.proj_navcal(d, x, y, oracle.ProjNavcalParams(xScale=10000.0, xOffset=0.0, yScale=10000.0, yOffset=0.0, lon0=-45.0,
+                                                             lat1=90.0, R=R, donav=1, mode=1, minx=0, maxx=3, miny=0, maxy=3))
+    lat, lon = p[1], p[2]
+    assert abs(lat[0, 1] - 90.0) < 1e-4                                    # x = y = 0: the pole (rho == 0 branch)
+    rho = np.hypot(xv[None, :], yv[:, None])
+    want = 90.0 - np.degrees(np.arcsin(rho / R))
+    off = rho > 0
+    assert np.allclose(lat[off], want[off], atol=2e-3)                     # float lat1 = pi/2 costs ~1e-3 deg
+    far = oracle.proj_navcal(d, np.array([700, 0, 0], np.int16), y, oracle.ProjNavcalParams(
+        xScale=10000.0, xOffset=0.0, yScale=10000.0, yOffset=0.0, lon0=-45.0, lat1=90.0, R=R, donav=1, mode=1, minx=0, maxx=3, miny=0, maxy=3))
+    assert np.isnan(far[1][0, 0])                                          # 7000 km from the pole on the plane: off the disc
+    assert not p[3].any() and np.array_equal(p[4], x) and np.array_equal(p[5], y)
