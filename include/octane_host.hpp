@@ -14,12 +14,17 @@
 void oct_variational_optical_flow(Image geo1i, Image geo2i, float *CTH, float *uarr, float *varr,
                                   int nx, int ny, int nc, OFFlags args);
 
+// ref src/oct_patch_match_optical_flow.cc:56 (declared at src/oct_optical_flow.cc:11): the -sosm method, a CPU loop in
+// the reference, a HIP kernel here.  uarr/varr: first guess in (centres the search), displacement out.  Reads
+// args.rad / args.srad.
+void oct_patch_match_optical_flow(float *geo1i, float *geo2i, float *uarr, float *varr, int nx, int ny, OFFlags args);
+
 // ref src/oct_pix2uv_cuda.cu:265 (declared at src/oct_optical_flow.cc:15).  Writes goesData.dT.
 void oct_pix2uv_cuda(GOESVar &goesData, double t2, float *uarr, float *varr, short *ur, short *vr,
                      short *ur2, short *vr2, OFFlags args);
 
 // ref src/oct_optical_flow.cc:21-111: zero / first-guess initialisation (oct_uv2pix), solver dispatch, CTP scaling,
-// pix2uv, optional -srsal.  -sosm (patch matching) is outside this library's scope and is reported.
+// pix2uv, optional -srsal.  -sosm dispatches to oct_patch_match_optical_flow (one channel only, as in the reference).
 int oct_optical_flow(GOESVar &goesData, GOESVar &goesData2, OFFlags &args);
 
 // ref src/oct_pix2uv_cuda.cu:372: first-guess winds in u/v (m/s) -> pixel displacements, using goesData.latVal/lonVal/x/y

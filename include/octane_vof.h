@@ -143,6 +143,15 @@ long long octane_vof_tiled_last_iterations(octane_vof_tiled *t);               /
 long long octane_vof_tiled_last_copies(octane_vof_tiled *t);                   /* peer copies the last solve issued */
 size_t octane_vof_tiled_device_bytes(const octane_vof_tiled *t);
 
+/* ---- patch matching (-sosm): the second flow method behind the reference's dispatch wrapper -------------------------
+ * Per pixel: centre the search at the truncated, clamped first guess (u/v in), visit the (2 srad + 1)^2 displacements
+ * in the reference's spiral order, keep the first strict minimum of the (2 rad + 1)^2 sum of squared differences (fp64),
+ * refine each axis with a three-point parabola.  u/v out: displacement relative to the pixel (the first guess is not
+ * added back -- as in the reference).  One channel, host buffers [ny][nx], blocking.  0 <= rad, srad <= 16.
+ * Replaces oct_patch_match_optical_flow (src/oct_patch_match_optical_flow.cc:56), a CPU loop in the reference. */
+int octane_sosm_run(const float *img1, const float *img2, int nx, int ny, float *u_inout, float *v_inout,
+                    int rad, int srad, int device);
+
 /* ---- pix2uv: pixel displacement -> navigated wind (cm/s as short) ---- */
 typedef struct octane_nav {      /* the GOESNAVVar fields oct_pix2uv_cuda.cu reads (include/goesread.h) */
     double pph, req, rpol, lam0;

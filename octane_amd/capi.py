@@ -29,7 +29,7 @@ EXPORTS = (
     "octane_vof_tiled_band_rows", "octane_vof_tiled_last_iterations", "octane_vof_tiled_last_copies",
     "octane_vof_tiled_device_bytes", "octane_vof_band_partition",
     "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
-    "octane_proj_navcal_run", "octane_uv2pix_run", "octane_srsal_run",
+    "octane_proj_navcal_run", "octane_uv2pix_run", "octane_srsal_run", "octane_sosm_run",
     "octane_last_error", "octane_device_count",
 )
 
@@ -154,6 +154,7 @@ def lib() -> C.CDLL:
                                     vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     L.octane_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(NavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
     L.octane_proj_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(ProjNavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
+    L.octane_sosm_run.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int]
     L.octane_bandminmax.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.octane_uv2pix_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, C.c_int]
     L.octane_srsal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
@@ -447,6 +448,18 @@ def navcal(data2, x, y, prm: NavcalParams, device: int = 0):
     if rc != OK:
         raise OctaneError(rc, "octane_navcal_run")
     return data3, lat, lon, d2s, xs, ys
+
+
+def sosm(img1, img2, rad: int = 2, srad: int = 2, u0=None, v0=None, device: int = 0):
+    """Patch-matching flow (-sosm) of one-channel images [ny, nx]; returns (u, v)."""
+    a, b = _f32(img1), _f32(img2)
+    ny, nx = a.shape
+    u = np.zeros((ny, nx), np.float32) if u0 is None else np.array(u0, np.float32, order="C", copy=True)
+    v = np.zeros((ny, nx), np.float32) if v0 is None else np.array(v0, np.float32, order="C", copy=True)
+    rc = lib().octane_sosm_run(_ptr(a), _ptr(b), nx, ny, _ptr(u), _ptr(v), rad, srad, device)
+    if rc != OK:
+        raise OctaneError(rc, "octane_sosm_run")
+    return u, v
 
 
 def proj_navcal(data2, x, y, prm: ProjNavcalParams, device: int = 0):

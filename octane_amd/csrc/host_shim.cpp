@@ -46,6 +46,18 @@ void oct_variational_optical_flow(Image geo1i, Image geo2i, float *CTH, float *u
         std::cerr << "oct_variational_optical_flow: " << octane_last_error() << " (code " << rc << ")\n";
 }
 
+void oct_patch_match_optical_flow(float *geo1i, float *geo2i, float *uarr, float *varr, int nx, int ny, OFFlags args)
+{
+    const int ndev = octane_device_count();
+    if (ndev == 0) {          // the reference runs this method on the CPU; here it needs the GPU like everything else
+        std::cout << "No gpus available for use, exiting\n";
+        exit(0);
+    }
+    const int dev = args.setdevice > ndev - 1 ? 0 : args.setdevice;
+    const int rc = octane_sosm_run(geo1i, geo2i, nx, ny, uarr, varr, args.rad, args.srad, dev);
+    if (rc != OCTANE_OK) std::cerr << "oct_patch_match_optical_flow: " << octane_last_error() << " (code " << rc << ")\n";
+}
+
 void oct_pix2uv_cuda(GOESVar &g, double t2, float *uarr, float *varr, short *ur, short *vr, short *ur2, short *vr2, OFFlags args)
 {
     octane_nav nav;
@@ -90,11 +102,15 @@ int oct_optical_flow(GOESVar &goesData, GOESVar &goesData2, OFFlags &args)
         oct_uv2pix(goesData, goesData.uPix, goesData.vPix, goesData2.t, args);
     }
     const int nc = 1 + args.doc2 + args.doc3;
-    if (args.dososm == 1) {
-        printf("Patch matching (-sosm) is not part of this library, exiting\n");
-        exit(0);
+    if (args.dososm == 1) {                   // ref oct_optical_flow.cc:57-64
+        if (args.doc2 == 1 || args.doc3 == 1) {
+            printf("Multichannel not yet supported on Patch Matching/Sum-of-Squared-error minimization, exiting\n");
+            exit(0);
+        }
+        oct_patch_match_optical_flow(goesData.data.data, goesData2.data.data, goesData.uPix, goesData.vPix, nx, ny, args);
+    } else {
+        oct_variational_optical_flow(goesData.data, goesData2.data, goesData.CTHVal, goesData.uPix, goesData.vPix, nx, ny, nc, args);
     }
-    oct_variational_optical_flow(goesData.data, goesData2.data, goesData.CTHVal, goesData.uPix, goesData.vPix, nx, ny, nc, args);
     short *CTP = nullptr;
     if (args.doCTH == 1) {                   // ref oct_optical_flow.cc:71-88
         CTP = new short[n];

@@ -130,6 +130,11 @@ struct Uv2pixArgs {
 void launch_uv2pix(hipStream_t s, const Uv2pixArgs &A, const float *u, const float *v, const float *lat, const float *lon,
                    const short *gx, const short *gy, float *upix, float *vpix);
 
+// patch matching (-sosm): `spiral` holds 2*count ints (n, m in visiting order) followed by (2 srad + 1)^2 visiting
+// indices laid out [n + srad][m + srad] (-1 = never visited)
+void launch_sosm(hipStream_t s, const float *g1, const float *g2, float *u, float *v, int nx, int ny, int rad, int srad,
+                 const int *spiral, int count);
+
 struct SrsalArgs { double gk[37]; double sigpix2; };
 void launch_srsal(hipStream_t s, const float *u, const float *v, const float *cth, int nx, int ny, const SrsalArgs &A,
                   float *uo, float *vo);

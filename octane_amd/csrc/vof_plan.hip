@@ -939,6 +939,68 @@ extern "C" int octane_proj_navcal_run(const float *data2, const short *x, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// patch matching, -sosm (ref src/oct_patch_match_optical_flow.cc:56-156)
+// ---------------------------------------------------------------------------------------------
+extern "C" int octane_sosm_run(const float *img1, const float *img2, int nx, int ny, float *u, float *v, int rad, int srad, int device)
+{
+    if (!img1 || !img2 || !u || !v || nx < 1 || ny < 1 || rad < 0 || srad < 0 || rad > 16 || srad > 16) {
+        g_last_error = "octane_sosm_run: invalid argument";
+        return OCTANE_E_INVALID;
+    }
+    int ndev = octane_device_count();
+    if (ndev == 0) { g_last_error = "No gpus available for use"; return OCTANE_E_NODEVICE; }
+    if (device > ndev - 1 || device < 0) device = 0;
+    HIP_TRY(hipSetDevice(device));
+    // The spiral of ref pm:107-137 as a table.  The window test `(-SXD2 < n <= SXD2)` is a chained comparison
+    // (bool <= int) in the reference and is evaluated as written.
+    const int SX = 2 * srad + 1, SY = 2 * srad + 1, SXD2 = SX / 2, SYD2 = SY / 2;
+    std::vector<int> tab(2 * (size_t)SX * SY + (size_t)SX * SY, -1);
+    int count = 0;
+    {
+        int n = 0, m = 0, dn = 0, dm = -1;
+        for (int ic = 0; ic < SX * SY; ic++) {
+            if (((-SXD2 < n) <= SXD2) && ((-SYD2 < m) <= SYD2)) { tab[2 * count] = n; tab[2 * count + 1] = m; count++; }
+            if ((n == m) || ((n < 0) && (n == -m)) || ((n > 0) && (n == 1 - m))) { const int odn = dn; dn = -dm; dm = odn; }
+            n += dn; m += dm;
+        }
+    }
+    std::vector<int> dev_tab(2 * (size_t)count + (size_t)SX * SY, -1);
+    for (int c = 0; c < count; c++) {
+        dev_tab[2 * c] = tab[2 * c]; dev_tab[2 * c + 1] = tab[2 * c + 1];
+        const int n = tab[2 * c], m = tab[2 * c + 1];
+        if (n >= -srad && n <= srad && m >= -srad && m <= srad) {
+            int &slot = dev_tab[2 * count + (n + srad) * SY + (m + srad)];
+            if (slot < 0) slot = c;                                         // first visit decides ties
+        }
+    }
+    const size_t n = (size_t)nx * ny;
+    float *d = nullptr;
+    int *d_tab = nullptr;
+    hipStream_t s = nullptr;
+    int rc = OCTANE_OK;
+    do {
+        if (hipMalloc((void **)&d, 4 * n * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&d_tab, dev_tab.size() * sizeof(int)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipStreamCreate(&s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        const float *src[4] = {img1, img2, u, v};
+        bool ok = true;
+        for (int i = 0; i < 4 && ok; i++) ok = hipMemcpyAsync(d + i * n, src[i], n * sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d_tab, dev_tab.data(), dev_tab.size() * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
+        if (!ok) { rc = OCTANE_E_HIP; break; }
+        launch_sosm(s, d, d + n, d + 2 * n, d + 3 * n, nx, ny, rad, srad, d_tab, count);
+        if (hipGetLastError() != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(u, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemcpyAsync(v, d + 3 * n, n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipStreamSynchronize(s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+    } while (0);
+    if (rc != OCTANE_OK) g_last_error = "octane_sosm_run: HIP failure";
+    if (s) (void)hipStreamDestroy(s);
+    if (d) (void)hipFree(d);
+    if (d_tab) (void)hipFree(d_tab);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // uv2pix (ref src/oct_pix2uv_cuda.cu:372-476) and srsal (ref src/oct_srsal_cuda.cu:73-147)
 // ---------------------------------------------------------------------------------------------
 extern "C" int octane_uv2pix_run(const octane_nav *nav, double t1, double t2, float *u, float *v,

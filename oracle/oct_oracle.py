@@ -237,6 +237,32 @@ def proj_navcal(data2: np.ndarray, x: np.ndarray, y: np.ndarray, prm: ProjNavcal
     return data3, lat, lon, d2s, xs, ys
 
 
+def sosm(img1, img2, rad: int = 2, srad: int = 2, u0=None, v0=None, flavour: str = "strict"):
+    """Patch-matching flow (restatement).  Returns (u, v)."""
+    a = np.ascontiguousarray(img1, np.float32); b = np.ascontiguousarray(img2, np.float32)
+    ny, nx = a.shape
+    u = np.zeros((ny, nx), np.float32) if u0 is None else np.array(u0, np.float32, order="C", copy=True)
+    v = np.zeros((ny, nx), np.float32) if v0 is None else np.array(v0, np.float32, order="C", copy=True)
+    L = lib(flavour)
+    L.oct_oracle_sosm.argtypes = [_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.oct_oracle_sosm.restype = None
+    L.oct_oracle_sosm(a.ravel(), b.ravel(), u.ravel(), v.ravel(), nx, ny, rad, srad)
+    return u, v
+
+
+def ref_sosm(img1, img2, rad: int = 2, srad: int = 2, u0=None, v0=None):
+    """The REFERENCE's own oct_patch_match_optical_flow, from oracle/_ref (only where /root/reference exists)."""
+    a = np.ascontiguousarray(img1, np.float32); b = np.ascontiguousarray(img2, np.float32)
+    ny, nx = a.shape
+    u = np.zeros((ny, nx), np.float32) if u0 is None else np.array(u0, np.float32, order="C", copy=True)
+    v = np.zeros((ny, nx), np.float32) if v0 is None else np.array(v0, np.float32, order="C", copy=True)
+    R = C.CDLL(ref_helpers_path())
+    R.oct_ref_patch_match.argtypes = [_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
+    R.oct_ref_patch_match.restype = None
+    R.oct_ref_patch_match(a.ravel(), b.ravel(), u.ravel(), v.ravel(), nx, ny, rad, srad)
+    return u, v
+
+
 def uv2pix(nav: Nav, t1: float, t2: float, u, v, lat, lon, gx, gy):
     uu = np.array(u, np.float32, order="C", copy=True); vv = np.array(v, np.float32, order="C", copy=True)
     L = lib()

@@ -99,6 +99,10 @@ void oct_oracle_uv2pix(const oct_oracle_nav *nav, double t1, double t2, float *u
                        const float *lat, const float *lon, const short *gx, const short *gy);
 void oct_oracle_srsal(float *u, float *v, const float *cth, int nx, int ny, float *uo, float *vo);
 
+/* ---- patch matching, -sosm (sosm_oracle.c) ---- */
+int  oct_oracle_sosm_spiral(int srad, int *nm);
+void oct_oracle_sosm(const float *img1, const float *img2, float *u_inout, float *v_inout, int nx, int ny, int rad, int srad);
+
 #ifdef __cplusplus
 }
 #endif
