@@ -59,6 +59,10 @@ void octane_vof_default_params(octane_vof_params *p);
  * Caller keeps ownership of every pointer; inputs are not modified. */
 int octane_vof_run(const float *img1, const float *img2, int nx, int ny, int nchan,
                    float *u_inout, float *v_inout, const octane_vof_params *p);
+/* octane_vof_run keeps the plan of its last call and reuses it when the next call has the same shape and parameters
+ * (creating and freeing a multi-GB arena per pair costs up to 0.5 s at 10848^2).  This frees the kept plan;
+ * OCTANE_VOF_CACHE=0 in the environment restores allocate-per-call, as the reference does (.cu:1268-1472). */
+void octane_vof_release_cache(void);
 
 /* Plan API: device state sized for (nx, ny, nchan, params) and reused across pairs. */
 typedef struct octane_vof_plan octane_vof_plan;

@@ -20,7 +20,7 @@ NAV_GEOS, NAV_POLAR, NAV_MERC = 0, 1, 2
 
 # every symbol include/octane_vof.h declares
 EXPORTS = (
-    "octane_vof_default_params", "octane_vof_run", "octane_vof_plan_create", "octane_vof_plan_destroy",
+    "octane_vof_default_params", "octane_vof_run", "octane_vof_release_cache", "octane_vof_plan_create", "octane_vof_plan_destroy",
     "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_last_iterations",
     "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_probe", "octane_vof_tune",
     "octane_vof_batch_run",
@@ -118,6 +118,7 @@ def lib() -> C.CDLL:
     L.octane_vof_default_params.argtypes = [C.POINTER(VofParams)]
     L.octane_vof_default_params.restype = None
     L.octane_vof_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(VofParams)]
+    L.octane_vof_release_cache.restype = None
     L.octane_vof_plan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(VofParams)]
     L.octane_vof_plan_destroy.argtypes = [vp]
     L.octane_vof_plan_device_bytes.argtypes = [vp]
@@ -384,6 +385,11 @@ def flow(img1, img2, params: FlowParams | None = None, u0=None, v0=None):
     if rc != OK:
         raise OctaneError(rc, "octane_vof_run")
     return u, v
+
+
+def release_cache() -> None:
+    """Free the plan octane_vof_run keeps between calls."""
+    lib().octane_vof_release_cache()
 
 
 def batch_flow(pairs, params: FlowParams | None = None, devices=None):

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -698,11 +699,53 @@ extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const
     return OCTANE_OK;
 }
 
+// One-shot entry.  The reference allocates and frees all device state per call (.cu:1268-1472); here the plan of the
+// last call is kept and reused when the next call has the same shape and parameters (a time series through the same
+// host program), because creating and destroying a multi-GB arena costs as much as 0.5 s at 10848^2.
+// OCTANE_VOF_CACHE=0 restores allocate-per-call; octane_vof_release_cache() frees the kept plan.
+static std::mutex g_cache_mu;
+static octane_vof_plan *g_cache_plan = nullptr;
+static octane_vof_params g_cache_prm;
+static int g_cache_nx = 0, g_cache_ny = 0, g_cache_nc = 0;
+
+static bool same_params(const octane_vof_params &a, const octane_vof_params &b)
+{
+    return a.alpha == b.alpha && a.lambda == b.lambda && a.lambdac == b.lambdac && a.scaleF == b.scaleF && a.scsig == b.scsig &&
+           a.kiters == b.kiters && a.liters == b.liters && a.cgiters == b.cgiters && a.dozim == b.dozim && a.device == b.device;
+}
+
+extern "C" void octane_vof_release_cache(void)
+{
+    std::lock_guard<std::mutex> g(g_cache_mu);
+    if (g_cache_plan) { octane_vof_plan_destroy(g_cache_plan); g_cache_plan = nullptr; }
+}
+
 extern "C" int octane_vof_run(const float *img1, const float *img2, int nx, int ny, int nchan,
                               float *u, float *v, const octane_vof_params *p)
 {
+    if (!p) { g_last_error = "octane_vof_run: invalid argument"; return OCTANE_E_INVALID; }
+    const char *e = getenv("OCTANE_VOF_CACHE");
+    const bool use_cache = !(e && atoi(e) == 0);
+    // one pair, one plan: the placement trials (four arenas allocated and timed, ~0.2 s at 5000^2) only pay off for a
+    // plan that lives for many pairs, so these plans take the first arena they get
+    if (use_cache && g_cache_mu.try_lock()) {
+        std::lock_guard<std::mutex> g(g_cache_mu, std::adopt_lock);
+        if (g_cache_plan && !(g_cache_nx == nx && g_cache_ny == ny && g_cache_nc == nchan && same_params(g_cache_prm, *p))) {
+            octane_vof_plan_destroy(g_cache_plan);
+            g_cache_plan = nullptr;
+        }
+        if (!g_cache_plan) {
+            const int rc = plan_create_ex(&g_cache_plan, nx, ny, nchan, p, 1);
+            if (rc != OCTANE_OK) { g_cache_plan = nullptr; return rc; }
+            g_cache_prm = *p; g_cache_nx = nx; g_cache_ny = ny; g_cache_nc = nchan;
+        }
+        const int rc = octane_vof_plan_run(g_cache_plan, img1, img2, u, v, OCTANE_MEM_HOST, nullptr);
+        if (rc != OCTANE_OK) { octane_vof_plan_destroy(g_cache_plan); g_cache_plan = nullptr; }   // do not keep a plan that failed
+        return rc;
+    }
+    // cache disabled, or another thread is inside the cached plan: a private plan for this call
     octane_vof_plan *pl = nullptr;
-    int rc = octane_vof_plan_create(&pl, nx, ny, nchan, p);
+    int rc = plan_create_ex(&pl, nx, ny, nchan, p, 1);
     if (rc != OCTANE_OK) return rc;
     rc = octane_vof_plan_run(pl, img1, img2, u, v, OCTANE_MEM_HOST, nullptr);
     octane_vof_plan_destroy(pl);
