@@ -1,0 +1,100 @@
+// Test tool for the NetCDF-4 layer (octane_amd/csrc/io).
+//   io_demo --make-goes out.nc nx ny rad.bin t band xoff yoff   writes a GOES-R L1b look-alike: Rad (int16 counts from rad.bin,
+//                                                            deflate-compressed), x, y, t, band_id, goes_imager_projection,
+//                                                            planck_* and kappa0, with the attributes oct_goesread needs
+//   io_demo --make-fg out.nc nx ny uv.bin                     a first-guess file: UFG, VFG (float32 from uv.bin)
+//   io_demo --dump file.nc                                    one line per variable: name|shape|att=value;...
+//   io_demo --read file.nc var type out.bin                   whole variable as short|int|float|double
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nc4lite.hpp"
+
+using nc4lite::Type;
+
+int main(int argc, char **argv)
+{
+    try {
+        if (argc == 10 && !strcmp(argv[1], "--make-goes")) {
+            const int nx = atoi(argv[3]), ny = atoi(argv[4]);
+            std::vector<short> rad((size_t)nx * ny), x(nx), y(ny);
+            FILE *f = fopen(argv[5], "rb");
+            if (!f || fread(rad.data(), 2, rad.size(), f) != rad.size()) { printf("bad input\n"); return 2; }
+            fclose(f);
+            for (int i = 0; i < nx; i++) x[i] = (short)i;
+            for (int j = 0; j < ny; j++) y[j] = (short)j;
+            const double t = atof(argv[6]);
+            const int band = atoi(argv[7]);
+            nc4lite::Writer w(argv[2]);
+            w.def_dim("y", ny); w.def_dim("x", nx); w.def_dim("band", 1);
+            w.def_var("Rad", Type::Short, {"y", "x"}, 4);
+            w.put_att("Rad", "scale_factor", 0.04572892f); w.put_att("Rad", "add_offset", -1.6443f);
+            w.put_att("Rad", "long_name", std::string("ABI L1b Radiances"));
+            w.def_var("x", Type::Short, {"x"});
+            w.put_att("x", "scale_factor", 5.6e-05f); w.put_att("x", "add_offset", (float)atof(argv[8]));
+            w.def_var("y", Type::Short, {"y"});
+            w.put_att("y", "scale_factor", -5.6e-05f); w.put_att("y", "add_offset", (float)atof(argv[9]));
+            w.def_var("t", Type::Double);
+            w.put_att("t", "units", std::string("seconds since 2000-01-01 12:00:00"));
+            w.def_var("band_id", Type::Byte, {"band"});
+            w.def_var("goes_imager_projection", Type::Int);
+            const char *gp = "goes_imager_projection";
+            w.put_att(gp, "grid_mapping_name", std::string("geostationary"));
+            w.put_att(gp, "perspective_point_height", 35786023.0);
+            w.put_att(gp, "semi_major_axis", 6378137.0);
+            w.put_att(gp, "semi_minor_axis", 6356752.31414);
+            w.put_att(gp, "inverse_flattening", 298.2572221);
+            w.put_att(gp, "latitude_of_projection_origin", 0.0);
+            w.put_att(gp, "longitude_of_projection_origin", -75.0);
+            w.put_att(gp, "sweep_angle_axis", std::string("x"));
+            const float pl[5] = {10803.3f, 1392.74f, 0.07550f, 0.99975f, 0.0015839f};
+            const char *pn[5] = {"planck_fk1", "planck_fk2", "planck_bc1", "planck_bc2", "kappa0"};
+            for (int i = 0; i < 5; i++) { w.def_var(pn[i], Type::Float); w.put_var(pn[i], &pl[i]); }
+            w.put_var("Rad", rad.data()); w.put_var("x", x.data()); w.put_var("y", y.data()); w.put_var("t", &t);
+            w.put_var("band_id", &band);
+            const int gip = -2147483647;
+            w.put_var(gp, &gip);
+            w.close();
+            return 0;
+        }
+        if (argc == 6 && !strcmp(argv[1], "--make-fg")) {
+            const int nx = atoi(argv[3]), ny = atoi(argv[4]);
+            std::vector<float> uv((size_t)2 * nx * ny);
+            FILE *f = fopen(argv[5], "rb");
+            if (!f || fread(uv.data(), 4, uv.size(), f) != uv.size()) { printf("bad input\n"); return 2; }
+            fclose(f);
+            nc4lite::Writer w(argv[2]);
+            w.def_dim("ny", ny); w.def_dim("nx", nx);
+            w.def_var("UFG", Type::Float, {"ny", "nx"});
+            w.def_var("VFG", Type::Float, {"ny", "nx"});
+            w.put_var("UFG", uv.data()); w.put_var("VFG", uv.data() + (size_t)nx * ny);
+            w.close();
+            return 0;
+        }
+        if (argc == 3 && !strcmp(argv[1], "--dump")) {
+            fputs(nc4lite::describe(argv[2]).c_str(), stdout);
+            return 0;
+        }
+        if (argc == 6 && !strcmp(argv[1], "--read")) {
+            nc4lite::Reader r(argv[2]);
+            size_t n = 1;
+            for (size_t d : r.shape(argv[3])) n *= d;
+            FILE *f = fopen(argv[5], "wb");
+            const std::string ty = argv[4];
+            if (ty == "short") { std::vector<short> v(n); r.read(argv[3], v.data()); fwrite(v.data(), 2, n, f); }
+            else if (ty == "int") { std::vector<int> v(n); r.read(argv[3], v.data()); fwrite(v.data(), 4, n, f); }
+            else if (ty == "float") { std::vector<float> v(n); r.read(argv[3], v.data()); fwrite(v.data(), 4, n, f); }
+            else { std::vector<double> v(n); r.read(argv[3], v.data()); fwrite(v.data(), 8, n, f); }
+            fclose(f);
+            return 0;
+        }
+    } catch (const nc4lite::Error &e) {
+        printf("error: %s\n", e.what());
+        return 3;
+    }
+    printf("usage: see the header of tests/cpp/io_demo.cpp\n");
+    return 1;
+}
