@@ -138,7 +138,7 @@ def main():
                          "configs[3], one --size frame as --bands row bands driven by a single process (run it "
                          "without torchrun)")
     ap.add_argument("--bands", type=int, default=4, help="row bands of the tiled workload")
-    ap.add_argument("--cpu-sample", type=int, default=1536, help="edge of the CPU-baseline sample pair")
+    ap.add_argument("--cpu-sample", type=int, default=3072, help="edge of the CPU-baseline sample pair")
     args = ap.parse_args()
     if args.size is None:
         args.size = 10848 if args.workload == "tiled" else 5000

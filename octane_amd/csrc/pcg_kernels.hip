@@ -21,8 +21,11 @@
 // (+ x(2) every second iteration).  Single-use planes (x, q, mu/mv, a2) move with streaming hints so that the
 // planes both passes share (r, p) keep the Infinity Cache; pass B walks the frame backwards for the same reason.
 //
-// Also here: k_pcg_solve_small (a whole solve in one workgroup for the coarsest levels), k_flow_update, and
-// k_pcg_pass_a_ring, a marching form of pass A with 8 % instead of 30 % re-fetch that is not faster.
+// Pass A comes in three forms chosen per level (pass_a_choice): a latency-oriented tiled form below 1 Mpixel, 128 x 16
+// tiles, and k_pcg_pass_a_ring, a marching form with 8 % instead of 30 % re-fetch that wins at 4-12 Mpixel only
+// (DESIGN.md 8).  The tiled and marching forms skip the wx / wy planes in the first GNC step, where every weight is -1,
+// and the tiled form can work on a row band of the level (vof_tiled.hip).
+// Also here: k_pcg_solve_small (a whole solve in one workgroup for the coarsest levels) and k_flow_update.
 #include "vof_kernels.hpp"
 #include "device_util.hpp"
 

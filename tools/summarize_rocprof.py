@@ -49,7 +49,8 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
                 sel += v[p * per_pyr + (nl - 1) * n:(p + 1) * per_pyr]
             vals[(k, cname)] = sum(sel) / len(sel)
     px = size * size
-    alg = {"k_pcg_pass_a": (36, 16), "k_pcg_pass_b": (40, 16), "k_assemble": (52, 36), "k_flow_update": (16, 8)}
+    # pass A reads 36 B/px, 28 in the first of the three GNC steps (wx / wy are the constant -1 there): mean 33.33
+    alg = {"k_pcg_pass_a": (100.0 / 3.0, 16), "k_pcg_pass_b": (40, 16), "k_assemble": (52, 36), "k_flow_update": (16, 8)}
     out += ["", "## HBM traffic per launch at the finest level (rocprofv3 --pmc, separate passes)", "",
             "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE x1, both KiB -> bytes. Infinity-Cache hits are",
             "counted by these counters (they sit on the L2's fabric side), so this is L2<->fabric traffic, an upper",
@@ -146,8 +147,9 @@ def main():
     if all(fin.values()):
         px = size * size
         lines += ["", "## Finest level against the HBM roofline (algorithmic bytes, DESIGN.md)", "",
-                  f"* pass A: 52 B/px x {px} px = {52 * px / 1e9:.3f} GB per launch / {fin['k_pcg_pass_a'] / 1e3:.1f} us = "
-                  f"**{52 * px / fin['k_pcg_pass_a']:.0f} GB/s** ({52 * px / fin['k_pcg_pass_a'] / 80:.1f} % of 8 TB/s)",
+                  f"* pass A: 49.33 B/px (52; 44 in the first GNC step, a third of the launches) x {px} px = {148 / 3 * px / 1e9:.3f} GB "
+                  f"per launch / {fin['k_pcg_pass_a'] / 1e3:.1f} us = **{148 / 3 * px / fin['k_pcg_pass_a']:.0f} GB/s** "
+                  f"({148 / 3 * px / fin['k_pcg_pass_a'] / 80:.1f} % of 8 TB/s)",
                   f"* pass B: 56 B/px x {px} px = {56 * px / 1e9:.3f} GB per launch / {fin['k_pcg_pass_b'] / 1e3:.1f} us = "
                   f"**{56 * px / fin['k_pcg_pass_b']:.0f} GB/s** ({56 * px / fin['k_pcg_pass_b'] / 80:.1f} % of 8 TB/s)",
                   f"* one PCG iteration at SURVEY 8(d)'s 116 B/px: {116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']):.0f} GB/s "
