@@ -73,14 +73,25 @@ size_t octane_vof_plan_device_bytes(const octane_vof_plan *plan);
 
 #define OCTANE_MEM_HOST   0
 #define OCTANE_MEM_DEVICE 1
+#define OCTANE_STREAM_OWN ((void *)(long)-1)   /* hip_stream value: the stream private to the plan */
 /* Solve one pair.  mem says where img1/img2/u/v live.  hip_stream is a hipStream_t.
  * OCTANE_MEM_DEVICE: the call only enqueues work on hip_stream (NULL = HIP's null stream) and
  * returns.  OCTANE_MEM_HOST: the call uploads, solves, downloads and synchronises before
- * returning (NULL = a stream private to the plan). */
+ * returning (NULL = a stream private to the plan).
+ * OCTANE_STREAM_OWN selects the plan's private stream for device buffers too: the inputs must be complete when the call is
+ * made, and octane_vof_plan_wait() (or the next blocking call on the plan) tells when the outputs are.  Two plans
+ * working side by side on one GPU (the lanes of a batch) should use it: their private streams sit on different
+ * hardware queues, whereas two streams of a framework's pool may share one (ROCm maps streams onto GPU_MAX_HW_QUEUES = 4
+ * queues) and then never overlap. */
 int octane_vof_plan_run(octane_vof_plan *plan, const float *img1, const float *img2,
                         float *u_inout, float *v_inout, int mem, void *hip_stream);
+/* The same with the first guess and the result in separate buffers; u0 = v0 = NULL means a zero first guess (what
+ * oct_optical_flow uses without -firstguess, src/oct_optical_flow.cc:38-48). */
+int octane_vof_plan_solve(octane_vof_plan *plan, const float *img1, const float *img2, const float *u0, const float *v0,
+                          float *u_out, float *v_out, int mem, void *hip_stream);
 
 /* Number of PCG iterations the last completed run executed (sum over all solves); blocks on the stream. */
+int octane_vof_plan_wait(octane_vof_plan *plan);          /* blocks until the plan's private stream is idle */
 long long octane_vof_plan_last_iterations(octane_vof_plan *plan);
 
 /* Debug tap (NULL = off, zero cost): called on the host after each stage with a copy of the stage's

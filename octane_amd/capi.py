@@ -21,7 +21,7 @@ NAV_GEOS, NAV_POLAR, NAV_MERC = 0, 1, 2
 # every symbol include/octane_vof.h declares
 EXPORTS = (
     "octane_vof_default_params", "octane_vof_run", "octane_vof_release_cache", "octane_vof_plan_create", "octane_vof_plan_destroy",
-    "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_last_iterations",
+    "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_solve", "octane_vof_plan_wait", "octane_vof_plan_last_iterations",
     "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_probe", "octane_vof_tune",
     "octane_vof_batch_run",
     "octane_vof_tiled_create", "octane_vof_tiled_destroy", "octane_vof_tiled_load", "octane_vof_tiled_solve",
@@ -93,6 +93,9 @@ def _preload_hip_runtime() -> None:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
+STREAM_OWN = (1 << 64) - 1     # OCTANE_STREAM_OWN, (void *)-1
+
+
 class OctaneError(RuntimeError):
     def __init__(self, code: int, where: str):
         self.code = code
@@ -124,6 +127,8 @@ def lib() -> C.CDLL:
     L.octane_vof_plan_device_bytes.argtypes = [vp]
     L.octane_vof_plan_device_bytes.restype = C.c_size_t
     L.octane_vof_plan_run.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+    L.octane_vof_plan_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
+    L.octane_vof_plan_wait.argtypes = [vp]
     L.octane_vof_plan_last_iterations.argtypes = [vp]
     L.octane_vof_plan_last_iterations.restype = C.c_longlong
     L.octane_vof_plan_set_trace.argtypes = [vp, TRACE_FN, vp]
@@ -238,11 +243,27 @@ class Plan:
         return u, v
 
     def run_device(self, img1_ptr: int, img2_ptr: int, u_ptr: int, v_ptr: int, stream: int = 0):
-        """Device pointers (dense [nchan, ny, nx] / [ny, nx] float32); enqueues on `stream`."""
+        """Device pointers (dense [nchan, ny, nx] / [ny, nx] float32); enqueues on `stream` (a hipStream_t, 0 = the null
+        stream, STREAM_OWN = the plan's private stream: inputs must be complete, wait() tells when the outputs are)."""
         rc = lib().octane_vof_plan_run(self._h, C.c_void_p(img1_ptr), C.c_void_p(img2_ptr), C.c_void_p(u_ptr),
                                        C.c_void_p(v_ptr), MEM_DEVICE, C.c_void_p(stream) if stream else None)
         if rc != OK:
             raise OctaneError(rc, "octane_vof_plan_run")
+
+    def solve_device(self, img1_ptr: int, img2_ptr: int, u_out_ptr: int, v_out_ptr: int, u0_ptr: int = 0, v0_ptr: int = 0,
+                     stream: int = 0):
+        """Like run_device with the first guess (0 = none: zero flow) and the result in separate device buffers."""
+        rc = lib().octane_vof_plan_solve(self._h, C.c_void_p(img1_ptr), C.c_void_p(img2_ptr),
+                                         C.c_void_p(u0_ptr) if u0_ptr else None, C.c_void_p(v0_ptr) if v0_ptr else None,
+                                         C.c_void_p(u_out_ptr), C.c_void_p(v_out_ptr), MEM_DEVICE,
+                                         C.c_void_p(stream) if stream else None)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_plan_solve")
+
+    def wait(self):
+        rc = lib().octane_vof_plan_wait(self._h)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_plan_wait")
 
     def last_iterations(self) -> int:
         return int(lib().octane_vof_plan_last_iterations(self._h))

@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
                 const size_t o = (size_t)y * pitch + x;
                 st4(pout_u + o, *(float4 *)npu[q]);
                 st4(pout_v + o, *(float4 *)npv[q]);
-                st4(L.qu + o, *(float4 *)qu);
-                st4(L.qv + o, *(float4 *)qv);
+                st4_if(L.qu + o, *(float4 *)qu, L.nt_hints & 16);
+                st4_if(L.qv + o, *(float4 *)qv, L.nt_hints & 16);
                 acc += (double)rowdot;
             }
         }
@@ -448,8 +448,8 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a_lat(LevelPtrs L, int k, int 
                 const size_t o = (size_t)y * pitch + x;
                 st4(pout_u + o, *(float4 *)npu[q]);
                 st4(pout_v + o, *(float4 *)npv[q]);
-                st4(L.qu + o, *(float4 *)qu);
-                st4(L.qv + o, *(float4 *)qv);
+                st4_if(L.qu + o, *(float4 *)qu, L.nt_hints & 16);
+                st4_if(L.qv + o, *(float4 *)qv, L.nt_hints & 16);
                 acc += (double)rowdot;
             }
         }
@@ -640,8 +640,8 @@ __global__ __launch_bounds__(256, 3) void k_pcg_pass_a_ring(LevelPtrs L, int k, 
                 const size_t o = (size_t)y * pitch + x;
                 st4(pout_u + o, *(float4 *)pcu);
                 st4(pout_v + o, *(float4 *)pcv);
-                st4(L.qu + o, *(float4 *)qu);
-                st4(L.qv + o, *(float4 *)qv);
+                st4_if(L.qu + o, *(float4 *)qu, L.nt_hints & 16);
+                st4_if(L.qv + o, *(float4 *)qv, L.nt_hints & 16);
                 acc += (double)rowdot;
             }
             // roll to the next row
@@ -806,11 +806,22 @@ static int stream_grid_size(int w, int h)
 
 // Pass B keeps two chunks of operands in registers (~124 VGPRs): 4 workgroups per CU are resident, so its
 // persistent grid is capped at 256 x 4.
+// Residency caps of the two passes' persistent grids.  Defaults fill the chip (3 x 256 and 4 x 256 workgroups); a
+// caller that runs two plans side by side (octane_vof_batch_run's lanes) lowers them so that the other lane's
+// latency-bound kernels find free wave slots instead of queueing behind a whole bandwidth-bound launch.
+static int g_cap_a = 768, g_cap_b = 1024;
+void set_pass_caps(int cap_a, int cap_b)
+{
+    g_cap_a = (cap_a >= 64 && cap_a <= 768) ? cap_a : 768;
+    g_cap_b = (cap_b >= 64 && cap_b <= 1024) ? cap_b : 1024;
+}
+
 static int pass_b_grid_size(int w, int h)
 {
     long chunks = ((long)((w + 3) / 4) * h + 255) / 256;
     int g = balanced_grid(chunks);
-    if (g > 1024) { long rounds = (chunks + 1023) / 1024; g = (int)((chunks + rounds - 1) / rounds); }
+    const long cap = g_cap_b;
+    if (g > cap) { long rounds = (chunks + cap - 1) / cap; g = (int)((chunks + rounds - 1) / rounds); }
     return g;
 }
 
@@ -855,12 +866,12 @@ int pcg_grid_size(int w, int h)
         long rows = (long)((w + kMarchW - 1) / kMarchW) * h;
         long g = rows / 8;
         if (g < 1) g = 1;
-        return (int)(g > 768 ? 768 : g);
+        return (int)(g > g_cap_a ? g_cap_a : g);
     }
     const int R = (variant == 5) ? 2 : variant;          // 5 = two sub-tiles side by side (256 x 8)
     const long items = (variant == 5) ? (long)((w + 2 * kTileX - 1) / (2 * kTileX)) * ((h + kTileY - 1) / kTileY)
                                       : (long)((w + kTileX - 1) / kTileX) * ((h + kTileY * R - 1) / (kTileY * R));
-    const long cap = (R == 2) ? 768 : 512;               // 185 / 148 / 236 VGPRs: 2 / 3 / 2 workgroups per CU resident
+    const long cap = (R == 2) ? g_cap_a : (g_cap_a < 512 ? g_cap_a : 512);   // 185 / 148 / 236 VGPRs: 2 / 3 / 2 workgroups per CU resident
     if (items <= cap) return (int)items;
     const long rounds = (items + cap - 1) / cap;
     return (int)((items + rounds - 1) / rounds);

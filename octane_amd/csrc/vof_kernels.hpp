@@ -86,6 +86,7 @@ int  balanced_grid(long work_items);   // persistent grid: every block gets the 
 int  pcg_grid_size(int w, int h);
 int  pcg_grid_size_unit_w(int w, int h);     // pass A grid of the unit-weight (first GNC step) launches
 void set_unit_w_cap(int c);
+void set_pass_caps(int cap_a, int cap_b);   // residency caps of the pass A / pass B persistent grids (defaults 768 / 1024)
 int  pcg_band_grid_size(int w, int rows);   // pass A grid for a row band (always the 128 x 16 tiled form)
 int  pcg_b_grid_size(int w, int h);
 void set_pass_a_variant(int v);       // tuning knob: tile rows per thread 1 | 2 (default) | 4; 3 = LDS-ring marching experiment

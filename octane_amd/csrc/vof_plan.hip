@@ -217,6 +217,10 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_GRAPH")) pl->use_graph = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_UNIT_W")) pl->use_unit_w = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_UNIT_W_CAP")) set_unit_w_cap(atoi(e));
+    {
+        const char *ea = getenv("OCTANE_TUNE_CAP_A"), *eb = getenv("OCTANE_TUNE_CAP_B");
+        if (ea || eb) set_pass_caps(ea ? atoi(ea) : 768, eb ? atoi(eb) : 1024);
+    }
     pcg_small_configure();
     set_grid_multiple(pl->xcd_bands ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
@@ -606,6 +610,14 @@ extern "C" int octane_vof_plan_get_profile(octane_vof_plan *pl, octane_vof_profi
     return OCTANE_OK;
 }
 
+extern "C" int octane_vof_plan_wait(octane_vof_plan *pl)
+{
+    if (!pl) return OCTANE_E_INVALID;
+    HIP_TRY(hipSetDevice(pl->device));
+    HIP_TRY(hipStreamSynchronize(pl->own_stream));
+    return OCTANE_OK;
+}
+
 extern "C" long long octane_vof_plan_last_iterations(octane_vof_plan *pl)
 {
     if (!pl) return -1;
@@ -622,15 +634,23 @@ int octane::plan_load_inputs(octane_vof_plan *pl, const float *img1, const float
             HIP_TRY(hipMemcpy2DAsync(pl->img1p + c * pl->plane0, pitched_row, img1 + (size_t)c * nx * ny, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpy2DAsync(pl->img2p + c * pl->plane0, pitched_row, img2 + (size_t)c * nx * ny, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
         }
-        HIP_TRY(hipMemcpy2DAsync(pl->uh, pitched_row, u, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpy2DAsync(pl->vh, pitched_row, v, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
+        if (u) {
+            HIP_TRY(hipMemcpy2DAsync(pl->uh, pitched_row, u, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpy2DAsync(pl->vh, pitched_row, v, dense_row, dense_row, ny, hipMemcpyHostToDevice, s));
+        }
     } else {
         for (int c = 0; c < nc; c++) {
             launch_copy2d(s, img1 + (size_t)c * nx * ny, nx, pl->img1p + c * pl->plane0, p0, nx, ny);
             launch_copy2d(s, img2 + (size_t)c * nx * ny, nx, pl->img2p + c * pl->plane0, p0, nx, ny);
         }
-        launch_copy2d(s, u, nx, pl->uh, p0, nx, ny);
-        launch_copy2d(s, v, nx, pl->vh, p0, nx, ny);
+        if (u) {
+            launch_copy2d(s, u, nx, pl->uh, p0, nx, ny);
+            launch_copy2d(s, v, nx, pl->vh, p0, nx, ny);
+        }
+    }
+    if (!u) {       // no first guess: zero flow, as oct_optical_flow does without -firstguess (ref oct_optical_flow.cc:38-48)
+        HIP_TRY(hipMemsetAsync(pl->uh, 0, pl->plane0 * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(pl->vh, 0, pl->plane0 * sizeof(float), s));
     }
     return OCTANE_OK;
 }
@@ -638,8 +658,15 @@ int octane::plan_load_inputs(octane_vof_plan *pl, const float *img1, const float
 extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const float *img2,
                                    float *u, float *v, int mem, void *hip_stream)
 {
-    if (!pl || !img1 || !img2 || !u || !v || (mem != OCTANE_MEM_HOST && mem != OCTANE_MEM_DEVICE)) {
-        g_last_error = "octane_vof_plan_run: invalid argument";
+    if (!u || !v) { g_last_error = "octane_vof_plan_run: invalid argument"; return OCTANE_E_INVALID; }
+    return octane_vof_plan_solve(pl, img1, img2, u, v, u, v, mem, hip_stream);
+}
+
+extern "C" int octane_vof_plan_solve(octane_vof_plan *pl, const float *img1, const float *img2, const float *u0, const float *v0,
+                                     float *u, float *v, int mem, void *hip_stream)
+{
+    if (!pl || !img1 || !img2 || !u || !v || ((u0 == nullptr) != (v0 == nullptr)) || (mem != OCTANE_MEM_HOST && mem != OCTANE_MEM_DEVICE)) {
+        g_last_error = "octane_vof_plan_solve: invalid argument";
         return OCTANE_E_INVALID;
     }
     HIP_TRY(hipSetDevice(pl->device));
@@ -647,10 +674,11 @@ extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const
     // null stream, which is what PyTorch's default stream is).  Host buffers: the call blocks
     // anyway, so NULL selects the plan's private stream.
     hipStream_t s = (mem == OCTANE_MEM_DEVICE || hip_stream) ? (hipStream_t)hip_stream : pl->own_stream;
+    if (hip_stream == OCTANE_STREAM_OWN) s = pl->own_stream;
     const int nx = pl->nx, ny = pl->ny, p0 = pl->pitch0;
     const size_t dense_row = (size_t)nx * sizeof(float), pitched_row = (size_t)p0 * sizeof(float);
     {
-        const int rc = plan_load_inputs(pl, img1, img2, u, v, mem, s);
+        const int rc = plan_load_inputs(pl, img1, img2, u0, v0, mem, s);
         if (rc) return rc;
     }
     // The launch sequence of a pyramid is fixed for a plan (every pointer and size is the plan's own), so it is
@@ -760,9 +788,11 @@ extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const 
         g_last_error = "octane_vof_batch_run: invalid argument";
         return OCTANE_E_INVALID;
     }
-    // Frames up to ~8 Mpixel leave the GPU latency-bound on their coarse levels, so each device gets two lanes (two
-    // plans, two streams, two host threads) whose kernels interleave; larger frames are bandwidth-bound and get one.
-    int lanes = ((long)nx * ny <= (8L << 20)) ? 2 : 1;
+    // Frames up to ~8 Mpixel leave the GPU latency-bound on their coarse levels, so each device gets three lanes (three
+    // plans on their private streams -- distinct hardware queues --, three host threads) whose kernels interleave:
+    // 91 / 120 / 135 / 121 Mpix/s with 1 / 2 / 3 / 4 lanes at 2000^2 (a fourth lane shares one of the 4 hardware
+    // queues).  Larger frames are bandwidth-bound and get one.
+    int lanes = ((long)nx * ny <= (8L << 20)) ? 3 : 1;
     if (const char *e = getenv("OCTANE_TUNE_BATCH_LANES")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
     const int nworkers = ndevices * lanes;
     std::vector<int> rcs(nworkers, OCTANE_OK);

@@ -58,3 +58,41 @@ def test_concurrent_one_shot_calls(capi):
     for o in out:
         assert o is not None and np.array_equal(o[0], want[0]) and np.array_equal(o[1], want[1])
     capi.release_cache()
+
+
+def test_two_lanes_on_their_own_streams(capi):
+    """octane_vof_plan_solve on OCTANE_STREAM_OWN: two plans side by side on one GPU (the lanes of the batch workload),
+    zero first guess by passing none, results where the caller wants them."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 384
+    pairs = [synth.lattice_scene(n, n, seed=s, device=dev) for s in (1, 2)]
+    prm = capi.FlowParams(kiters=4, liters=2)
+    want = []
+    for a, b in pairs:
+        pl = capi.Plan(n, n, 1, prm)
+        want.append(pl.run_host(a.cpu().numpy(), b.cpu().numpy()))
+        pl.close()
+    plans = [capi.Plan(n, n, 1, prm) for _ in range(2)]
+    outs = [(torch.full((n, n), 7.0, device=dev), torch.full((n, n), -7.0, device=dev)) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i, (a, b) in enumerate(pairs):
+            plans[i].solve_device(a.data_ptr(), b.data_ptr(), outs[i][0].data_ptr(), outs[i][1].data_ptr(), stream=capi.STREAM_OWN)
+    for p in plans:
+        p.wait()
+    for i in range(2):
+        assert np.array_equal(outs[i][0].cpu().numpy(), want[i][0]) and np.array_equal(outs[i][1].cpu().numpy(), want[i][1])
+    # a first guess in separate buffers
+    u0 = torch.full((n, n), 1.5, device=dev); v0 = torch.full((n, n), -0.5, device=dev)
+    torch.cuda.synchronize()
+    plans[0].solve_device(pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), outs[0][0].data_ptr(), outs[0][1].data_ptr(),
+                          u0.data_ptr(), v0.data_ptr(), stream=capi.STREAM_OWN)
+    plans[0].wait()
+    ref = capi.Plan(n, n, 1, prm)
+    wu, wv = ref.run_host(pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy(), u0.cpu().numpy(), v0.cpu().numpy())
+    ref.close()
+    assert np.array_equal(outs[0][0].cpu().numpy(), wu) and np.array_equal(outs[0][1].cpu().numpy(), wv)
+    assert float(u0[0, 0]) == 1.5                       # the first guess is not written
+    for p in plans:
+        p.close()
