@@ -138,6 +138,55 @@ def tiled(args, capi, synth, torch):
     print(json.dumps(out), flush=True)
 
 
+def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
+    """BASELINE.json configs[3] under the one-process-per-GPU launch (torchrun): rank r owns row band r of the ONE frame
+    (octane_vof_mp_*: HIP IPC mappings of the other ranks' arenas, phase barrier in shared memory; torch.distributed only
+    for rendezvous, the handle all-gather and the timing).  Every rank holds the whole pair on its own device."""
+    n = args.size
+    a, b = synth.lattice_scene(n, n, seed=20240613 + 3, device=dev)          # same seed on every rank: the same frame
+    u = torch.zeros(n, n, device=dev)
+    v = torch.zeros(n, n, device=dev)
+    prm = capi.FlowParams(kiters=args.kiters, liters=args.liters, cgiters=args.cgiters, device=local)
+
+    def all_gather(blob):
+        out = [None] * world
+        dist.all_gather_object(out, blob)
+        return out
+
+    torch.cuda.synchronize()
+    mp = capi.MpPlan(n, n, 1, prm, rank, world, "/octane_bench_%s" % os.environ.get("MASTER_PORT", "0"), all_gather)
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mp.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mp.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr())     # blocking and collective
+    barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev if os.environ.get("OCTANE_BENCH_BACKEND", "nccl") == "nccl" else None)
+    if rank == 0:
+        iters, expect = mp.last_iterations(), args.kiters * 3 * args.liters * args.cgiters
+        out = {"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n),
+               "value": round(n * n * args.steps / elapsed / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan=1 alpha=5 "
+                                      f"lambda=1 (BASELINE.json configs[3]), {iters} PCG iterations per pyramid (expected {expect}); "
+                                      f"one row band per rank, {world} ranks",
+                          "sharding": f"row bands of the {mp.banded_levels} finest level(s), coarser levels replicated; HIP IPC peer reads "
+                                      "of partial sums and edge rows, phase barrier in shared memory; no collective on the data path"},
+               "roofline": None, "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    mp.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,8 +200,8 @@ def main():
     ap.add_argument("--workload", default="pair", choices=["pair", "batch64", "tiled"],
                     help="pair (default): one --size pair per GPU; batch64: BASELINE.json configs[4], 64 pairs of "
                          "2000x2000 (kiters=6) shared by all ranks, two concurrent lanes per GPU; tiled: BASELINE.json "
-                         "configs[3], one --size frame as --bands row bands driven by a single process (run it "
-                         "without torchrun)")
+                         "configs[3], one --size frame as row bands: --bands bands driven by a single process, or -- "
+                         "under torchrun -- one band per rank")
     ap.add_argument("--bands", type=int, default=4, help="row bands of the tiled workload")
     ap.add_argument("--cpu-sample", type=int, default=3072, help="edge of the CPU-baseline sample pair")
     args = ap.parse_args()
@@ -182,8 +231,8 @@ def main():
     dev = torch.device("cuda", local)
 
     if args.workload == "tiled":
-        if world > 1:
-            raise SystemExit("--workload tiled is one process driving all devices: run it without torchrun")
+        if world > 1:      # torchrun: one band per rank
+            return tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev)
         return tiled(args, capi, synth, torch)
     if args.workload == "batch64":
         return batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev)

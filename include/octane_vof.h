@@ -158,6 +158,29 @@ long long octane_vof_tiled_last_iterations(octane_vof_tiled *t);               /
 long long octane_vof_tiled_last_copies(octane_vof_tiled *t);                   /* peer copies the last solve issued */
 size_t octane_vof_tiled_device_bytes(const octane_vof_tiled *t);
 
+/* ---- the same row-band solve with one band per PROCESS (the one-process-per-GPU launch) -----------------------------
+ * Rank r of `world` (<= 8) owns band r on the device params->device selects.  Protocol, every step collective:
+ *   octane_vof_mp_create   builds the band and opens the POSIX shared-memory object `shm_name` ("/something", the same on
+ *                          every rank, unique per job; rank 0 creates it) that holds the ranks' phase barrier
+ *   octane_vof_mp_handles  writes OCTANE_MP_HANDLE_BYTES bytes: the HIP IPC handles of this rank's two allocations; the
+ *                          host program all-gathers them in rank order (torch.distributed, MPI, ...)
+ *   octane_vof_mp_connect  maps the other ranks' allocations from the gathered world * OCTANE_MP_HANDLE_BYTES bytes
+ *   octane_vof_mp_run      every rank passes the whole pair (host buffers, or dense device buffers on its own device)
+ *                          and the first guess (NULL, NULL = zero); the flow arrives in u / v on rank 0 only
+ * Same kernels and halo / partial protocol as octane_vof_tiled_*; a phase boundary is a stream drain plus a barrier in
+ * shared memory.  No collective library is involved on the data path. */
+#define OCTANE_MP_HANDLE_BYTES 128
+typedef struct octane_vof_mp octane_vof_mp;
+int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nchan, const octane_vof_params *p, int rank, int world,
+                         long long min_band_pixels, const char *shm_name);
+int octane_vof_mp_handles(octane_vof_mp *m, void *buf);
+int octane_vof_mp_connect(octane_vof_mp *m, const void *all_handles);
+int octane_vof_mp_run(octane_vof_mp *m, const float *img1, const float *img2, const float *u0, const float *v0,
+                      float *u_out, float *v_out, int mem);
+int octane_vof_mp_banded_levels(const octane_vof_mp *m);
+long long octane_vof_mp_last_iterations(octane_vof_mp *m);
+int octane_vof_mp_destroy(octane_vof_mp *m);
+
 /* ---- patch matching (-sosm): the second flow method behind the reference's dispatch wrapper -------------------------
  * Per pixel: centre the search at the truncated, clamped first guess (u/v in), visit the (2 srad + 1)^2 displacements
  * in the reference's spiral order, keep the first strict minimum of the (2 rad + 1)^2 sum of squared differences (fp64),

@@ -28,6 +28,8 @@ EXPORTS = (
     "octane_vof_tiled_wait", "octane_vof_tiled_fetch", "octane_vof_tiled_run", "octane_vof_tiled_banded_levels",
     "octane_vof_tiled_band_rows", "octane_vof_tiled_last_iterations", "octane_vof_tiled_last_copies",
     "octane_vof_tiled_device_bytes", "octane_vof_band_partition",
+    "octane_vof_mp_create", "octane_vof_mp_handles", "octane_vof_mp_connect", "octane_vof_mp_run", "octane_vof_mp_banded_levels",
+    "octane_vof_mp_last_iterations", "octane_vof_mp_destroy",
     "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
     "octane_proj_navcal_run", "octane_uv2pix_run", "octane_srsal_run", "octane_sosm_run",
     "octane_last_error", "octane_device_count",
@@ -156,6 +158,14 @@ def lib() -> C.CDLL:
     L.octane_vof_tiled_device_bytes.argtypes = [vp]
     L.octane_vof_tiled_device_bytes.restype = C.c_size_t
     L.octane_vof_band_partition.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.octane_vof_mp_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(VofParams), C.c_int, C.c_int, C.c_longlong, C.c_char_p]
+    L.octane_vof_mp_handles.argtypes = [vp, vp]
+    L.octane_vof_mp_connect.argtypes = [vp, vp]
+    L.octane_vof_mp_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.octane_vof_mp_banded_levels.argtypes = [vp]
+    L.octane_vof_mp_last_iterations.argtypes = [vp]
+    L.octane_vof_mp_last_iterations.restype = C.c_longlong
+    L.octane_vof_mp_destroy.argtypes = [vp]
     L.octane_pix2uv_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, C.c_int, C.c_int,
                                     vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     L.octane_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(NavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
@@ -391,6 +401,65 @@ class TiledPlan:
 
     def last_copies(self) -> int:
         return int(lib().octane_vof_tiled_last_copies(self._h))
+
+
+MP_HANDLE_BYTES = 128
+
+
+class MpPlan:
+    """One band of a row-band solve with one band per process (octane_vof_mp_*).  Every method is collective over the
+    `world` ranks.  `all_gather` is a callable taking this rank's bytes and returning the list of every rank's bytes in
+    rank order (e.g. a wrapper of torch.distributed.all_gather_object)."""
+
+    def __init__(self, nx: int, ny: int, nchan: int, params: FlowParams, rank: int, world: int, shm_name: str, all_gather,
+                 min_band_pixels: int = 0):
+        self.nx, self.ny, self.nchan, self.rank, self.world = nx, ny, nchan, rank, world
+        self._h = C.c_void_p()
+        p = params.c()
+        rc = lib().octane_vof_mp_create(C.byref(self._h), nx, ny, nchan, C.byref(p), rank, world, min_band_pixels, shm_name.encode())
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_mp_create")
+        buf = C.create_string_buffer(MP_HANDLE_BYTES)
+        rc = lib().octane_vof_mp_handles(self._h, buf)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_mp_handles")
+        blobs = all_gather(buf.raw)
+        assert len(blobs) == world and all(len(b) == MP_HANDLE_BYTES for b in blobs)
+        rc = lib().octane_vof_mp_connect(self._h, C.create_string_buffer(b"".join(blobs), MP_HANDLE_BYTES * world))
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_mp_connect")
+
+    def close(self):
+        if self._h:
+            lib().octane_vof_mp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    @property
+    def banded_levels(self) -> int:
+        return int(lib().octane_vof_mp_banded_levels(self._h))
+
+    def last_iterations(self) -> int:
+        return int(lib().octane_vof_mp_last_iterations(self._h))
+
+    def run_host(self, img1, img2, u0=None, v0=None):
+        """Whole pair on every rank (numpy); returns (u, v) on rank 0, (None, None) elsewhere."""
+        a, b = _f32(img1), _f32(img2)
+        u = np.zeros((self.ny, self.nx), np.float32)
+        v = np.zeros((self.ny, self.nx), np.float32)
+        g0 = _f32(u0) if u0 is not None else None
+        g1 = _f32(v0) if v0 is not None else None
+        rc = lib().octane_vof_mp_run(self._h, _ptr(a), _ptr(b), _ptr(g0) if g0 is not None else None,
+                                     _ptr(g1) if g1 is not None else None, _ptr(u), _ptr(v), MEM_HOST)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_mp_run")
+        return (u, v) if self.rank == 0 else (None, None)
+
+    def run_device(self, img1_ptr: int, img2_ptr: int, u_out_ptr: int, v_out_ptr: int, u0_ptr: int = 0, v0_ptr: int = 0):
+        """Dense device buffers on this rank's device (complete when the call is made); blocking."""
+        rc = lib().octane_vof_mp_run(self._h, C.c_void_p(img1_ptr), C.c_void_p(img2_ptr), C.c_void_p(u0_ptr) if u0_ptr else None,
+                                     C.c_void_p(v0_ptr) if v0_ptr else None, C.c_void_p(u_out_ptr), C.c_void_p(v_out_ptr), MEM_DEVICE)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_mp_run")
 
 
 def flow(img1, img2, params: FlowParams | None = None, u0=None, v0=None):

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -207,105 +208,104 @@ extern "C" size_t octane_vof_tiled_device_bytes(const octane_vof_tiled *t)
     return t ? t->pl[0]->arena_bytes + (size_t)3 * kMaxParts * sizeof(double) : 0;
 }
 
-// ---- transport -----------------------------------------------------------------------------------------------
-// One host thread per band issues that band's launches, copies and event operations.  The threads never wait for
-// the GPU; they meet at a spin barrier once per phase only so that "record my event" is issued before "make your
-// stream wait for my event" (waiting on an event that has not been recorded yet is a no-op in HIP).
+// ---- how a band reaches the others ---------------------------------------------------------------------------------
+// The level loop below is written once against this interface and runs in two settings:
+//   * ThreadNet -- all bands in one process, one host thread per band (octane_vof_tiled_*): phase boundaries are events
+//     recorded and waited on across the bands' streams, the threads only meet at a spin barrier so that "record" is
+//     issued before "wait"; the host never waits for the GPU inside a pyramid;
+//   * ProcNet   -- one band per process (octane_vof_mp_*, the torchrun launch): the other bands' arenas and partial
+//     blocks are HIP IPC mappings, a phase boundary is "drain my stream, then meet the other processes at a barrier in
+//     POSIX shared memory".
+// Every band's arena is carved identically, so a plane of band c is band b's plane pointer moved by the distance
+// between the two arena bases as mapped in this process.
 struct SpinBarrier {
     std::atomic<int> arrived{0};
     std::atomic<int> generation{0};
-    int n = 1;
-    void wait()
+    // returns false when `timeout_s` (0 = none) passed without everybody arriving
+    bool wait(int n, double timeout_s = 0.)
     {
         const int gen = generation.load(std::memory_order_acquire);
         if (arrived.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
             arrived.store(0, std::memory_order_relaxed);
             generation.store(gen + 1, std::memory_order_release);
-        } else {
-            int spins = 0;
-            while (generation.load(std::memory_order_acquire) == gen)
-                if (++spins > 4096) std::this_thread::yield();
+            return true;
         }
+        long spins = 0;
+        std::chrono::steady_clock::time_point t0;
+        while (generation.load(std::memory_order_acquire) == gen) {
+            if (++spins > 4096) {
+                std::this_thread::yield();
+                if (timeout_s > 0. && (spins & 1023) == 0) {
+                    if (spins == 5120) t0 = std::chrono::steady_clock::now();
+                    else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+                }
+            }
+        }
+        return true;
     }
 };
 
-struct BandRun {                     // per-solve state shared by the band threads
-    octane_vof_tiled *t;
-    SpinBarrier bar;
-    std::atomic<int> failed{0};      // first failing band + 1
-    std::mutex mu;
-    std::string error;
-    int rc = OCTANE_OK;
-    std::vector<long long> copies;
-    std::vector<int> cur;
+struct BandNet {
+    int nb = 1;
+    octane_vof_params prm;
+    const std::vector<std::vector<BandRows>> *rows = nullptr;     // [level][band]; empty = replicated level
+    char *arena[kMaxBands] = {nullptr};                            // every band's arena base as mapped in this process
+    double *parts[kMaxBands] = {nullptr};                          // every band's partial block
+    std::vector<long long> copies = std::vector<long long>(kMaxBands, 0);
+    std::vector<int> cur = std::vector<int>(kMaxBands, 0);
+    virtual ~BandNet() {}
+    virtual octane_vof_plan *plan(int b) = 0;                      // band b's plan (bands of this process only)
+    virtual bool failed() = 0;
+    virtual void fail(int b, int rc, const std::string &msg) = 0;
+    virtual void sync(int b) = 0;                                  // phase boundary, called by every band
+    virtual hipError_t copy(int b, void *dst, int dband, const void *src, size_t bytes) = 0;   // on band b's stream
+    float *peer(int c, int b, float *plane_of_b) const
+    {
+        return reinterpret_cast<float *>(arena[c] + (reinterpret_cast<char *>(plane_of_b) - arena[b]));
+    }
 };
 
-// HIP calls of a band thread: after the first failure anywhere every thread keeps walking the same control flow
-// (so the barriers still match up) but issues nothing more.
+// HIP calls of a band: after the first failure anywhere every band keeps walking the same control flow (so the phase
+// boundaries still match up) but issues nothing more.
 #define BAND_HIP(expr)                                                                         \
     do {                                                                                       \
-        if (!R.failed.load(std::memory_order_relaxed)) {                                       \
+        if (!N.failed()) {                                                                     \
             hipError_t e_ = (expr);                                                            \
-            if (e_ != hipSuccess) band_fail(R, b, OCTANE_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+            if (e_ != hipSuccess) N.fail(b, OCTANE_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
         }                                                                                      \
     } while (0)
 
-static void band_fail(BandRun &R, int b, int rc, const std::string &msg)
+// Rows [ya, yb) of one of band b's planes to the same plane of band dst.
+static void send_rows(BandNet &N, int b, float *plane, int pitch, int ya, int yb, int dst)
 {
-    std::lock_guard<std::mutex> g(R.mu);
-    if (!R.failed.load()) { R.rc = rc; R.error = msg; R.failed.store(b + 1); }
+    N.copies[b]++;
+    BAND_HIP(N.copy(b, N.peer(dst, b, plane) + (size_t)ya * pitch, dst, plane + (size_t)ya * pitch, (size_t)(yb - ya) * pitch * sizeof(float)));
 }
 
-static void copy_band(BandRun &R, int b, void *dst, int dband, const void *src, size_t bytes)
+// ---- one banded level, as band b issues it ----------------------------------------------------------------------------
+static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx &ctx, bool finest)
 {
-    octane_vof_tiled *t = R.t;
-    R.copies[b]++;
-    hipStream_t s = t->pl[b]->own_stream;
-    if (t->dev[dband] == t->dev[b]) BAND_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
-    else BAND_HIP(hipMemcpyPeerAsync(dst, t->dev[dband], src, t->dev[b], bytes, s));
-}
-
-// Everything band b has issued so far becomes a dependency of whatever the other bands issue next, and vice versa.
-static void sync_bands(BandRun &R, int b)
-{
-    octane_vof_tiled *t = R.t;
-    BAND_HIP(hipEventRecord(t->ev[b], t->pl[b]->own_stream));
-    R.bar.wait();
-    for (int c = 0; c < t->nbands; c++)
-        if (c != b) BAND_HIP(hipStreamWaitEvent(t->pl[b]->own_stream, t->ev[c], 0));
-    R.bar.wait();        // nobody re-records its event before everybody has queued the waits on it
-}
-
-// Rows [ya, yb) of a plane (same layout in every band's arena) from band b to band dst.
-static void send_rows(BandRun &R, int b, float *from_base, float *to_base, int pitch, int ya, int yb, int dst)
-{
-    copy_band(R, b, to_base + (size_t)ya * pitch, dst, from_base + (size_t)ya * pitch, (size_t)(yb - ya) * pitch * sizeof(float));
-}
-
-// ---- one banded level, as band b's thread issues it ---------------------------------------------------------------
-static void solve_level_banded(BandRun &R, int b, int k, int cur, const LevelCtx &ctx, bool finest)
-{
-    octane_vof_tiled *t = R.t;
-    const int nb = t->nbands;
-    const octane_vof_params &prm = t->prm;
-    octane_vof_plan *pl = t->pl[b];
+    const int nb = N.nb;
+    const octane_vof_params &prm = N.prm;
+    octane_vof_plan *pl = N.plan(b);
     hipStream_t s = pl->own_stream;
     const LevelInfo &li = pl->lev[k];
-    const std::vector<BandRows> &rows = t->rows[k];
+    const std::vector<BandRows> &rows = (*N.rows)[k];
     LevelPtrs L;
     plan_fill_level_ptrs(pl, k, cur, ctx, L);
     L.y0 = rows[b].y0; L.y1 = rows[b].y1;
     L.ya0 = (b == 0) ? 0 : L.y0 - 1;
     L.ya1 = (b == nb - 1) ? li.h : L.y1 + 1;
     L.nbands = nb;
-    double *own = t->parts[b];
+    double *own = N.parts[b];
     L.part_rz = own + kPartRz; L.part_rr = own + kPartRr; L.part_pq = own + kPartPq;
-    for (int c = 0; c < kMaxBands; c++) L.band_parts[c] = t->parts[c < nb ? c : b];
-    L.ru_up = t->pl[b > 0 ? b - 1 : b]->ru; L.rv_up = t->pl[b > 0 ? b - 1 : b]->rv;
-    L.ru_dn = t->pl[b < nb - 1 ? b + 1 : b]->ru; L.rv_dn = t->pl[b < nb - 1 ? b + 1 : b]->rv;
+    for (int c = 0; c < kMaxBands; c++) L.band_parts[c] = N.parts[c < nb ? c : b];
+    const int up = b > 0 ? b - 1 : b, dn = b < nb - 1 ? b + 1 : b;
+    L.ru_up = N.peer(up, b, pl->ru); L.rv_up = N.peer(up, b, pl->rv);
+    L.ru_dn = N.peer(dn, b, pl->ru); L.rv_dn = N.peer(dn, b, pl->rv);
     int maxrows = 0;
     for (int c = 0; c < nb; c++) maxrows = rows[c].y1 - rows[c].y0 > maxrows ? rows[c].y1 - rows[c].y0 : maxrows;
-    // every band launches the same grids, so that the slots hold the same number of partials (idle workgroups
+    // every band launches the same grids, so that the blocks hold the same number of partials (idle workgroups
     // contribute zeros)
     const int g_asm = assemble_grid_size(li.w, maxrows + 2);
     const int g_a = pcg_band_grid_size(li.w, maxrows);
@@ -320,70 +320,107 @@ static void solve_level_banded(BandRun &R, int b, int k, int cur, const LevelCtx
         ap.dozim = prm.dozim != 0;
         L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;
         for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
-            if (!R.failed.load()) launch_assemble(s, L, ap, g_asm);
-            sync_bands(R, b);
+            if (!N.failed()) launch_assemble(s, L, ap, g_asm);
+            N.sync(b);
             for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182
-                if (!R.failed.load()) launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
-                sync_bands(R, b);
-                if (!R.failed.load()) launch_pcg_pass_b(s, L, it, g_a, g_b);
-                sync_bands(R, b);
+                if (!N.failed()) launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
+                N.sync(b);
+                if (!N.failed()) launch_pcg_pass_b(s, L, it, g_a, g_b);
+                N.sync(b);
             }
-            if (!R.failed.load()) launch_flow_update(s, L, prm.cgiters);          // ref .cu:1185-1195
+            if (!N.failed()) launch_flow_update(s, L, prm.cgiters);          // ref .cu:1185-1195
             // the next assembly reads u, v two rows beyond the band (one for the halo row it fills, one for that
             // row's own 3 x 3 neighbourhood)
             if (b > 0) {
-                send_rows(R, b, pl->U[cur], t->pl[b - 1]->U[cur], li.pitch, L.y0, L.y0 + 2, b - 1);
-                send_rows(R, b, pl->V[cur], t->pl[b - 1]->V[cur], li.pitch, L.y0, L.y0 + 2, b - 1);
+                send_rows(N, b, pl->U[cur], li.pitch, L.y0, L.y0 + 2, b - 1);
+                send_rows(N, b, pl->V[cur], li.pitch, L.y0, L.y0 + 2, b - 1);
             }
             if (b < nb - 1) {
-                send_rows(R, b, pl->U[cur], t->pl[b + 1]->U[cur], li.pitch, L.y1 - 2, L.y1, b + 1);
-                send_rows(R, b, pl->V[cur], t->pl[b + 1]->V[cur], li.pitch, L.y1 - 2, L.y1, b + 1);
+                send_rows(N, b, pl->U[cur], li.pitch, L.y1 - 2, L.y1, b + 1);
+                send_rows(N, b, pl->V[cur], li.pitch, L.y1 - 2, L.y1, b + 1);
             }
-            sync_bands(R, b);
+            N.sync(b);
         }
     }
     // Level done: the next level's up-sampling (replicated) needs the whole flow on every band; after the finest
     // level only band 0, which hands the result out, does.
     for (int c = 0; c < nb; c++) {
         if (c == b || (finest && c != 0)) continue;
-        send_rows(R, b, pl->U[cur], t->pl[c]->U[cur], li.pitch, L.y0, L.y1, c);
-        send_rows(R, b, pl->V[cur], t->pl[c]->V[cur], li.pitch, L.y0, L.y1, c);
+        send_rows(N, b, pl->U[cur], li.pitch, L.y0, L.y1, c);
+        send_rows(N, b, pl->V[cur], li.pitch, L.y0, L.y1, c);
     }
-    sync_bands(R, b);
+    N.sync(b);
 }
 
 // The whole pyramid of band b.
-static void band_worker(BandRun &R, int b)
+static void band_worker(BandNet &N, int b)
 {
-    octane_vof_tiled *t = R.t;
-    octane_vof_plan *pl = t->pl[b];
+    octane_vof_plan *pl = N.plan(b);
     const int nlev = (int)pl->lev.size();
-    BAND_HIP(hipSetDevice(t->dev[b]));
+    BAND_HIP(hipSetDevice(pl->device));
     BAND_HIP(hipMemsetAsync(pl->d_iters, 0, sizeof(long long), pl->own_stream));
     pl->evs_used = 0;
     int cur = 0;
     LevelCtx ctx;
     for (int k = 0; k < nlev; k++) {
-        if (!R.failed.load()) {
+        if (!N.failed()) {
             const int rc = plan_level_setup(pl, pl->own_stream, k, cur, ctx);
-            if (rc) band_fail(R, b, rc, "plan_level_setup failed");
+            if (rc) N.fail(b, rc, "plan_level_setup failed");
         } else if (k > 0) {
             cur ^= 1;      // keep the bookkeeping in step with the healthy bands
         }
-        if (t->rows[k].empty()) {
-            if (!R.failed.load()) {
+        if ((*N.rows)[k].empty()) {
+            if (!N.failed()) {
                 const int rc = plan_level_solve(pl, pl->own_stream, k, cur, ctx, false);
-                if (rc) band_fail(R, b, rc, "plan_level_solve failed");
+                if (rc) N.fail(b, rc, "plan_level_solve failed");
             }
         } else {
-            sync_bands(R, b);          // a band's halo rows must not be written while it still sets the level up
-            solve_level_banded(R, b, k, cur, ctx, k == nlev - 1);
+            N.sync(b);                 // a band's halo rows must not be written while it still sets the level up
+            solve_level_banded(N, b, k, cur, ctx, k == nlev - 1);
         }
     }
     if (b == 0) BAND_HIP(hipMemcpyAsync(pl->h_iters, pl->d_iters, sizeof(long long), hipMemcpyDeviceToHost, pl->own_stream));
     BAND_HIP(hipGetLastError());
-    R.cur[b] = cur;
+    N.cur[b] = cur;
 }
+
+// ---- all bands in this process: one host thread per band --------------------------------------------------------
+struct ThreadNet : BandNet {
+    octane_vof_tiled *t;
+    SpinBarrier bar;
+    std::atomic<int> failed_{0};     // first failing band + 1
+    std::mutex mu;
+    std::string error;
+    int rc = OCTANE_OK;
+    explicit ThreadNet(octane_vof_tiled *t_) : t(t_)
+    {
+        nb = t->nbands; prm = t->prm; rows = &t->rows;
+        for (int b = 0; b < nb; b++) { arena[b] = reinterpret_cast<char *>(t->pl[b]->arena); parts[b] = t->parts[b]; }
+    }
+    octane_vof_plan *plan(int b) override { return t->pl[b]; }
+    bool failed() override { return failed_.load(std::memory_order_relaxed) != 0; }
+    void fail(int b, int code, const std::string &msg) override
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!failed_.load()) { rc = code; error = msg; failed_.store(b + 1); }
+    }
+    // Everything band b has issued so far becomes a dependency of whatever the other bands issue next, and vice versa.
+    void sync(int b) override
+    {
+        BandNet &N = *this;
+        BAND_HIP(hipEventRecord(t->ev[b], t->pl[b]->own_stream));
+        bar.wait(nb);
+        for (int c = 0; c < nb; c++)
+            if (c != b) BAND_HIP(hipStreamWaitEvent(t->pl[b]->own_stream, t->ev[c], 0));
+        bar.wait(nb);       // nobody re-records its event before everybody has queued the waits on it
+    }
+    hipError_t copy(int b, void *dst, int dband, const void *src, size_t bytes) override
+    {
+        hipStream_t s = t->pl[b]->own_stream;
+        if (t->dev[dband] == t->dev[b]) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+        return hipMemcpyPeerAsync(dst, t->dev[dband], src, t->dev[b], bytes, s);
+    }
+};
 
 static hipError_t copy_from_band0(octane_vof_tiled *t, void *dst, int dband, const void *src, size_t bytes, hipStream_t s)
 {
@@ -430,27 +467,23 @@ extern "C" int octane_vof_tiled_solve(octane_vof_tiled *t)
 {
     if (!t || !t->loaded) { set_last_error("octane_vof_tiled_solve: no inputs loaded"); return OCTANE_E_INVALID; }
     const int nb = t->nbands;
-    BandRun R;
-    R.t = t;
-    R.bar.n = nb;
-    R.copies.assign(nb, 0);
-    R.cur.assign(nb, 0);
+    ThreadNet N(t);
     if (nb == 1) {
-        band_worker(R, 0);
+        band_worker(N, 0);
     } else {
         std::vector<std::thread> th;
-        for (int b = 0; b < nb; b++) th.emplace_back([&R, b]() { band_worker(R, b); });
+        for (int b = 0; b < nb; b++) th.emplace_back([&N, b]() { band_worker(N, b); });
         for (auto &x : th) x.join();
     }
     t->copies = 0;
-    for (int b = 0; b < nb; b++) t->copies += R.copies[b];
-    if (R.failed.load()) {
-        set_last_error("octane_vof_tiled_solve (band " + std::to_string(R.failed.load() - 1) + "): " + R.error);
+    for (int b = 0; b < nb; b++) t->copies += N.copies[b];
+    if (N.failed()) {
+        set_last_error("octane_vof_tiled_solve (band " + std::to_string(N.failed_.load() - 1) + "): " + N.error);
         (void)octane_vof_tiled_wait(t);
-        return R.rc;
+        return N.rc;
     }
     (void)hipSetDevice(t->dev[0]);
-    t->last_cur = R.cur[0];
+    t->last_cur = N.cur[0];
     return OCTANE_OK;
 }
 
@@ -491,4 +524,252 @@ extern "C" int octane_vof_tiled_run(octane_vof_tiled *t, const float *img1, cons
     if (rc == OCTANE_OK) rc = octane_vof_tiled_solve(t);
     if (rc == OCTANE_OK) rc = octane_vof_tiled_fetch(t, u, v, mem);
     return rc;
+}
+
+// =====================================================================================================================
+// One band per PROCESS (the one-process-per-GPU launch): octane_vof_mp_*.
+//
+// Same level loop, same kernels, same halo / partial protocol as above; what differs is how a band reaches the others.
+// Every rank creates its band (a full-size plan + a partial block), exports the two allocations as HIP IPC handles, the
+// host program all-gathers the handles (torch.distributed, MPI, a file -- 128 bytes per rank) and every rank maps the
+// other ranks' allocations.  A phase boundary is: drain my stream (hipStreamSynchronize), then meet the other ranks at a
+// barrier that lives in a POSIX shared-memory object.  That costs a host round trip per boundary (two per PCG iteration)
+// where the in-process form costs an event wait, and in exchange needs nothing but shared memory between the ranks: no
+// collective library on the data path (RCCL stays what the launcher uses for rendezvous and timing).
+// The barrier gives up after 120 s so that a rank that died cannot leave the others spinning.
+// =====================================================================================================================
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+struct MpShared {                 // lives in the shared-memory object; zero-filled at creation by rank 0
+    SpinBarrier bar;
+    std::atomic<int> failed;      // first failing rank + 1
+    std::atomic<int> ready;       // rank 0 sets it once the object is initialised
+};
+
+struct octane_vof_mp {
+    int rank = 0, world = 1, device = 0;
+    int nx = 0, ny = 0, nc = 0;
+    octane_vof_params prm;
+    octane_vof_plan *pl = nullptr;
+    double *parts = nullptr;
+    char *arena[kMaxBands] = {nullptr};
+    double *parts_all[kMaxBands] = {nullptr};
+    bool connected = false;
+    std::vector<std::vector<BandRows>> rows;
+    std::string shm_name;
+    MpShared *shm = nullptr;
+    int last_cur = 0;
+    long long copies = 0;
+};
+
+struct MpHandles { hipIpcMemHandle_t arena, parts; };
+static_assert(sizeof(MpHandles) == OCTANE_MP_HANDLE_BYTES, "OCTANE_MP_HANDLE_BYTES must match two hipIpcMemHandle_t");
+
+struct ProcNet : BandNet {
+    octane_vof_mp *m;
+    std::string error;
+    int rc = OCTANE_OK;
+    explicit ProcNet(octane_vof_mp *m_) : m(m_)
+    {
+        nb = m->world; prm = m->prm; rows = &m->rows;
+        for (int b = 0; b < nb; b++) { arena[b] = m->arena[b]; parts[b] = m->parts_all[b]; }
+    }
+    octane_vof_plan *plan(int) override { return m->pl; }
+    bool failed() override { return m->shm->failed.load(std::memory_order_relaxed) != 0; }
+    void fail(int b, int code, const std::string &msg) override
+    {
+        if (rc == OCTANE_OK) { rc = code; error = msg; }
+        int expect = 0;
+        m->shm->failed.compare_exchange_strong(expect, b + 1);
+    }
+    void sync(int b) override
+    {
+        BandNet &N = *this;
+        BAND_HIP(hipStreamSynchronize(m->pl->own_stream));
+        if (!m->shm->bar.wait(nb, 120.)) fail(b, OCTANE_E_HIP, "timed out waiting for the other ranks at a phase boundary");
+    }
+    hipError_t copy(int, void *dst, int, const void *src, size_t bytes) override
+    {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, m->pl->own_stream);     // dst is an IPC mapping
+    }
+};
+
+extern "C" int octane_vof_mp_destroy(octane_vof_mp *m)
+{
+    if (!m) return OCTANE_OK;
+    (void)hipSetDevice(m->device);
+    if (m->pl && m->pl->own_stream) (void)hipStreamSynchronize(m->pl->own_stream);
+    for (int b = 0; b < m->world && b < kMaxBands; b++) {
+        if (b == m->rank) continue;
+        if (m->arena[b]) (void)hipIpcCloseMemHandle(m->arena[b]);
+        if (m->parts_all[b]) (void)hipIpcCloseMemHandle(m->parts_all[b]);
+    }
+    if (m->shm) {
+        if (m->connected) (void)m->shm->bar.wait(m->world, 20.);      // nobody unmaps what another rank may still read
+        munmap(m->shm, sizeof(MpShared));
+        if (m->rank == 0) shm_unlink(m->shm_name.c_str());
+    }
+    if (m->parts) (void)hipFree(m->parts);
+    if (m->pl) octane_vof_plan_destroy(m->pl);
+    delete m;
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nchan, const octane_vof_params *p, int rank, int world,
+                                    long long min_band_pixels, const char *shm_name)
+{
+    if (!out || !p || world < 1 || world > kMaxBands || rank < 0 || rank >= world || !shm_name || shm_name[0] != '/') {
+        set_last_error("octane_vof_mp_create: invalid argument (1 <= world <= 8, shm_name like /octane_1234)");
+        return OCTANE_E_INVALID;
+    }
+    *out = nullptr;
+    octane_vof_mp *m = new octane_vof_mp();
+    m->rank = rank; m->world = world; m->nx = nx; m->ny = ny; m->nc = nchan; m->prm = *p; m->shm_name = shm_name;
+    int rc = plan_create_ex(&m->pl, nx, ny, nchan, p, 1);
+    if (rc != OCTANE_OK) { delete m; return rc; }
+    m->device = m->pl->device;
+    if (hipMalloc((void **)&m->parts, (size_t)3 * kMaxParts * sizeof(double)) != hipSuccess ||
+        hipMemset(m->parts, 0, (size_t)3 * kMaxParts * sizeof(double)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        set_last_error("octane_vof_mp_create: device allocation failed");
+        octane_vof_mp_destroy(m);
+        return OCTANE_E_NOMEM;
+    }
+    m->arena[rank] = reinterpret_cast<char *>(m->pl->arena);
+    m->parts_all[rank] = m->parts;
+    const long minpix = min_band_pixels > 0 ? (long)min_band_pixels : (12L << 20);
+    m->rows.resize(m->pl->lev.size());
+    for (size_t k = 0; k < m->pl->lev.size(); k++) {
+        const LevelInfo &li = m->pl->lev[k];
+        if ((long)li.w * li.h < minpix) continue;
+        int edges[kMaxBands + 1];
+        if (octane_vof_band_partition(li.h, world, edges) != 1) continue;
+        std::vector<BandRows> r(world);
+        for (int b = 0; b < world; b++) { r[b].y0 = edges[b]; r[b].y1 = edges[b + 1]; }
+        m->rows[k] = r;
+    }
+    // the shared-memory object: rank 0 creates and initialises it, the others wait for it to appear
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(shm_name);
+        fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, sizeof(MpShared)) != 0) { close(fd); fd = -1; }
+    } else {
+        for (int tries = 0; tries < 6000 && fd < 0; tries++) {     // up to 60 s
+            fd = shm_open(shm_name, O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat st;
+                if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(MpShared)) { close(fd); fd = -1; }
+            }
+            if (fd < 0) usleep(10000);
+        }
+    }
+    if (fd < 0) {
+        set_last_error(std::string("octane_vof_mp_create: cannot open shared memory object ") + shm_name);
+        octane_vof_mp_destroy(m);
+        return OCTANE_E_INVALID;
+    }
+    void *mem = mmap(nullptr, sizeof(MpShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) {
+        set_last_error("octane_vof_mp_create: mmap of the shared memory object failed");
+        octane_vof_mp_destroy(m);
+        return OCTANE_E_INVALID;
+    }
+    m->shm = static_cast<MpShared *>(mem);
+    if (rank == 0) {
+        new (m->shm) MpShared();
+        m->shm->failed.store(0);
+        m->shm->ready.store(1, std::memory_order_release);
+    } else {
+        for (int tries = 0; tries < 6000 && m->shm->ready.load(std::memory_order_acquire) != 1; tries++) usleep(10000);
+        if (m->shm->ready.load(std::memory_order_acquire) != 1) {
+            set_last_error("octane_vof_mp_create: rank 0 never initialised the shared memory object");
+            octane_vof_mp_destroy(m);
+            return OCTANE_E_INVALID;
+        }
+    }
+    *out = m;
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_mp_handles(octane_vof_mp *m, void *buf)
+{
+    if (!m || !buf) return OCTANE_E_INVALID;
+    TILED_TRY(hipSetDevice(m->device));
+    MpHandles h;
+    TILED_TRY(hipIpcGetMemHandle(&h.arena, m->pl->arena));
+    TILED_TRY(hipIpcGetMemHandle(&h.parts, m->parts));
+    std::memcpy(buf, &h, sizeof h);
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_mp_connect(octane_vof_mp *m, const void *all_handles)
+{
+    if (!m || !all_handles || m->connected) { set_last_error("octane_vof_mp_connect: invalid argument"); return OCTANE_E_INVALID; }
+    TILED_TRY(hipSetDevice(m->device));
+    const MpHandles *h = static_cast<const MpHandles *>(all_handles);
+    for (int b = 0; b < m->world; b++) {
+        if (b == m->rank) continue;
+        void *pa = nullptr, *pp = nullptr;
+        TILED_TRY(hipIpcOpenMemHandle(&pa, h[b].arena, hipIpcMemLazyEnablePeerAccess));
+        TILED_TRY(hipIpcOpenMemHandle(&pp, h[b].parts, hipIpcMemLazyEnablePeerAccess));
+        m->arena[b] = static_cast<char *>(pa);
+        m->parts_all[b] = static_cast<double *>(pp);
+    }
+    m->connected = true;
+    if (!m->shm->bar.wait(m->world, 120.)) { set_last_error("octane_vof_mp_connect: the other ranks did not arrive"); return OCTANE_E_HIP; }
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_mp_banded_levels(const octane_vof_mp *m)
+{
+    if (!m) return -1;
+    int n = 0;
+    for (auto &r : m->rows) n += !r.empty();
+    return n;
+}
+
+extern "C" long long octane_vof_mp_last_iterations(octane_vof_mp *m) { return m ? *m->pl->h_iters : -1; }
+
+// Every rank passes the whole pair (host buffers, or dense device buffers on its own device) and the first guess; the
+// flow arrives in u / v on rank 0 only (other ranks' u / v are left alone).  Collective: every rank must call it.
+extern "C" int octane_vof_mp_run(octane_vof_mp *m, const float *img1, const float *img2, const float *u0, const float *v0,
+                                 float *u, float *v, int mem)
+{
+    if (!m || !m->connected || !img1 || !img2 || ((u0 == nullptr) != (v0 == nullptr)) || (m->rank == 0 && (!u || !v)) ||
+        (mem != OCTANE_MEM_HOST && mem != OCTANE_MEM_DEVICE)) {
+        set_last_error("octane_vof_mp_run: invalid argument (or octane_vof_mp_connect not called)");
+        return OCTANE_E_INVALID;
+    }
+    TILED_TRY(hipSetDevice(m->device));
+    octane_vof_plan *pl = m->pl;
+    int rc = plan_load_inputs(pl, img1, img2, u0, v0, mem, pl->own_stream);
+    if (rc) return rc;
+    ProcNet N(m);
+    N.sync(m->rank);                      // nobody's halo rows are written before everybody has its inputs in place
+    band_worker(N, m->rank);
+    N.sync(m->rank);
+    m->copies = N.copies[m->rank];
+    m->last_cur = N.cur[m->rank];
+    if (N.failed()) {
+        set_last_error("octane_vof_mp_run (rank " + std::to_string(m->rank) + "): " + (N.error.empty() ? std::string("another rank failed") : N.error));
+        return N.rc != OCTANE_OK ? N.rc : OCTANE_E_HIP;
+    }
+    if (m->rank == 0) {
+        const size_t dense_row = (size_t)m->nx * sizeof(float), pitched_row = (size_t)pl->pitch0 * sizeof(float);
+        const int cur = m->last_cur;
+        if (mem == OCTANE_MEM_HOST) {
+            TILED_TRY(hipMemcpy2DAsync(u, dense_row, pl->U[cur], pitched_row, dense_row, m->ny, hipMemcpyDeviceToHost, pl->own_stream));
+            TILED_TRY(hipMemcpy2DAsync(v, dense_row, pl->V[cur], pitched_row, dense_row, m->ny, hipMemcpyDeviceToHost, pl->own_stream));
+        } else {
+            launch_copy2d(pl->own_stream, pl->U[cur], pl->pitch0, u, m->nx, m->nx, m->ny);
+            launch_copy2d(pl->own_stream, pl->V[cur], pl->pitch0, v, m->nx, m->nx, m->ny);
+        }
+    }
+    TILED_TRY(hipStreamSynchronize(pl->own_stream));
+    TILED_TRY(hipGetLastError());
+    return OCTANE_OK;
 }

@@ -1,0 +1,55 @@
+"""One rank of the multi-process row-band test (tests/test_gpu_tiled_mp.py starts `world` of these; all share GPU 0
+on a one-GPU box).  Rendezvous and the IPC-handle all-gather go through torch.distributed (gloo, 127.0.0.1)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from octane_amd import capi, synth  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    nx, ny, kit, lit, cg, minpix = (int(x) for x in sys.argv[1:7])
+    hint = len(sys.argv) > 7 and sys.argv[7] == "hint"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['MASTER_PORT']}", rank=rank, world_size=world)
+
+    def all_gather(blob):
+        out = [None] * world
+        dist.all_gather_object(out, blob)
+        return out
+
+    a, b = synth.lattice_scene(nx, ny, seed=41)
+    u0 = v0 = None
+    prm = capi.FlowParams(kiters=kit, liters=lit, cgiters=cg, device=0)
+    if hint:
+        rng = np.random.RandomState(4)
+        u0 = (2.0 + 0.2 * rng.randn(ny, nx)).astype(np.float32)
+        v0 = (-1.0 + 0.2 * rng.randn(ny, nx)).astype(np.float32)
+        prm = capi.FlowParams(kiters=kit, liters=lit, cgiters=cg, lambdac=0.4, device=0)
+    mp = capi.MpPlan(nx, ny, 1, prm, rank, world, f"/octane_test_{os.environ['MASTER_PORT']}", all_gather, min_band_pixels=minpix)
+    banded = mp.banded_levels
+    for rep in range(2):                                   # twice: the protocol must be re-enterable
+        u, v = mp.run_host(a, b, u0, v0)
+    ok = True
+    if rank == 0:
+        pl = capi.Plan(nx, ny, 1, prm)
+        up, vp = pl.run_host(a, b, u0, v0)
+        ip = pl.last_iterations()
+        pl.close()
+        d = float(np.sqrt((((u - up).astype(np.float64)) ** 2 + ((v - vp).astype(np.float64)) ** 2).sum() /
+                          ((up.astype(np.float64)) ** 2 + (vp.astype(np.float64)) ** 2).sum()))
+        ok = np.isfinite(u).all() and d < 2e-5 and mp.last_iterations() == ip
+        print(f"MP_RESULT banded={banded} relL2={d:.3e} its={mp.last_iterations()}/{ip} ok={ok}", flush=True)
+    mp.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
