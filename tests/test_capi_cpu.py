@@ -48,6 +48,22 @@ def test_invalid_arguments_are_rejected(capi):
     assert b"invalid" in L.octane_last_error()
 
 
+def test_multi_gpu_entries_validate_before_touching_a_device(capi):
+    L = capi.lib()
+    h = C.c_void_p()
+    p = capi.FlowParams().c()
+    assert L.octane_vof_tiled_create(C.byref(h), 64, 64, 1, C.byref(p), 0, None, 0) == capi.E_INVALID
+    assert L.octane_vof_tiled_create(C.byref(h), 64, 64, 1, C.byref(p), 9, None, 0) == capi.E_INVALID
+    assert L.octane_vof_mp_create(C.byref(h), 64, 64, 1, C.byref(p), 2, 2, 0, b"/x") == capi.E_INVALID      # rank >= world
+    assert L.octane_vof_mp_create(C.byref(h), 64, 64, 1, C.byref(p), 0, 9, 0, b"/x") == capi.E_INVALID      # world > 8
+    assert L.octane_vof_mp_create(C.byref(h), 64, 64, 1, C.byref(p), 0, 2, 0, b"no_slash") == capi.E_INVALID
+    assert L.octane_vof_mp_run(None, None, None, None, None, None, None, 0) == capi.E_INVALID
+    assert L.octane_sosm_run(None, None, 4, 4, None, None, 2, 2, 0) == capi.E_INVALID
+    if L.octane_device_count() == 0:
+        assert L.octane_vof_tiled_create(C.byref(h), 64, 64, 1, C.byref(p), 2, None, 0) == capi.E_NODEVICE
+        assert L.octane_vof_mp_create(C.byref(h), 64, 64, 1, C.byref(p), 0, 1, 0, b"/octane_cpu_test") == capi.E_NODEVICE
+
+
 def test_no_gpu_means_an_error_not_a_fallback(capi):
     if capi.lib().octane_device_count() > 0:
         pytest.skip("a GPU is visible here; the no-device path is exercised on the CPU box")
