@@ -639,7 +639,8 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
     }
     m->arena[rank] = reinterpret_cast<char *>(m->pl->arena);
     m->parts_all[rank] = m->parts;
-    const long minpix = min_band_pixels > 0 ? (long)min_band_pixels : (12L << 20);
+    long minpix = min_band_pixels > 0 ? (long)min_band_pixels : (12L << 20);
+    if (const char *e = getenv("OCTANE_TUNE_MIN_BAND_PIXELS")) minpix = atol(e);
     m->rows.resize(m->pl->lev.size());
     for (size_t k = 0; k < m->pl->lev.size(); k++) {
         const LevelInfo &li = m->pl->lev[k];
