@@ -747,9 +747,11 @@ extern "C" int octane_vof_mp_run(octane_vof_mp *m, const float *img1, const floa
     }
     TILED_TRY(hipSetDevice(m->device));
     octane_vof_plan *pl = m->pl;
-    int rc = plan_load_inputs(pl, img1, img2, u0, v0, mem, pl->own_stream);
-    if (rc) return rc;
     ProcNet N(m);
+    {   // a rank that cannot load its inputs still walks the protocol, so that the others fail fast instead of timing out
+        const int rc = plan_load_inputs(pl, img1, img2, u0, v0, mem, pl->own_stream);
+        if (rc) N.fail(m->rank, rc, "loading the inputs failed");
+    }
     N.sync(m->rank);                      // nobody's halo rows are written before everybody has its inputs in place
     band_worker(N, m->rank);
     N.sync(m->rank);
@@ -757,6 +759,8 @@ extern "C" int octane_vof_mp_run(octane_vof_mp *m, const float *img1, const floa
     m->last_cur = N.cur[m->rank];
     if (N.failed()) {
         set_last_error("octane_vof_mp_run (rank " + std::to_string(m->rank) + "): " + (N.error.empty() ? std::string("another rank failed") : N.error));
+        m->shm->bar.wait(m->world, 20.);          // everybody has seen the flag before rank 0 clears it for the next call
+        if (m->rank == 0) m->shm->failed.store(0);
         return N.rc != OCTANE_OK ? N.rc : OCTANE_E_HIP;
     }
     if (m->rank == 0) {
