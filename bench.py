@@ -302,6 +302,10 @@ def main():
                 "avg_launch_ms": round(dms, 4), "bytes_per_launch": int(round(bpp * n * n)),
                 "pass_a_ms": round(a_ms, 4), "pass_b_ms": round(b_ms, 4),
                 "pcg_iteration_gbs_at_116B_per_pixel": round(iter_gbs, 1),
+                # the same kernel on SURVEY 8(d)'s accounting (pass A 60 B/px with all seven coefficient planes, pass B 56):
+                # this implementation stores five planes (and skips two more in the first GNC step), so the figure above
+                # -- bytes it actually has to move -- is the stricter one
+                "frac_at_survey_bytes": round((60 if dom == "k_pcg_pass_a" else 56) * n * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "assemble_ms": round(pr.assemble_ms / max(1, pr.assemble_launches), 4),
                 "setup_ms_all_levels": round(pr.setup_ms, 3), "profiled_step_ms": round(pr.total_ms, 2)}
 
