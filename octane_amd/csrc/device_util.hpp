@@ -27,6 +27,24 @@ __device__ __forceinline__ double block_sum_256(double v, double *scratch)
     return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
 }
 
+// N sums over the workgroup with one pair of barriers; every thread gets all totals.  scratch: 4 * N doubles.
+template <int N>
+__device__ __forceinline__ void block_sum_multi_256(const double (&v)[N], double *scratch, double (&out)[N])
+{
+    double w[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) w[j] = wave_sum(v[j]);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                       // scratch may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < N; j++) scratch[j * 4 + wave] = w[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = ((scratch[j * 4] + scratch[j * 4 + 1]) + scratch[j * 4 + 2]) + scratch[j * 4 + 3];
+}
+
 // Every block folds the same `n` per-block partials (n <= kMaxParts) in the same order, so all
 // blocks obtain bit-identical totals without atomics, fences or an extra launch: thread t
 // adds partials t, t+256, t+512, ..., then the workgroup tree above.
@@ -49,6 +67,25 @@ __device__ __forceinline__ double fold_band_partials_256(const double *const *bl
         for (int i = threadIdx.x; i < n; i += 256) v += part[i];
     }
     return block_sum_256(v, scratch);
+}
+
+// N sums at once (the fused PCG kernel needs seven): the loads of all kinds are independent, so they cost one memory
+// round trip instead of N, and the workgroup tree runs once.  kind i lives kind_stride doubles after kind i-1.
+template <int N>
+__device__ __forceinline__ void fold_band_partials_multi_256(const double *const *blocks, int first_off, int kind_stride, int n,
+                                                             int nbands, double *scratch /* >= 4 * N */, double (&out)[N])
+{
+    double v[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = 0.;
+    for (int b = 0; b < nbands; b++) {
+        const double *__restrict__ part = blocks[b] + first_off;
+        for (int i = threadIdx.x; i < n; i += 256) {
+#pragma unroll
+            for (int j = 0; j < N; j++) v[j] += part[(size_t)j * kind_stride + i];
+        }
+    }
+    block_sum_multi_256<N>(v, scratch, out);
 }
 
 // Work-item range of this workgroup in a persistent launch.  Plain: items b, b+G, b+2G, ...  Banded: the item

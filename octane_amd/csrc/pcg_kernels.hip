@@ -657,6 +657,314 @@ __global__ __launch_bounds__(256, 3) void k_pcg_pass_a_ring(LevelPtrs L, int k, 
     if (tid == 0) L.part_pq[blockIdx.x] = tot;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused PCG iteration: ONE kernel per iteration instead of pass A + pass B.
+//
+//   G(k):  alpha_{k-1} = (r.z)_{k-1} / (p.q)_{k-1};   x += alpha_{k-1} p_{k-1};   r_k = r_{k-1} - alpha_{k-1} q_{k-1}     [k >= 1]
+//          beta_k = (r.z)_k / (r.z)_{k-1};   p_k = M^-1 r_k + beta_k p_{k-1};   q_k = A p_k
+//          partials of p_k.q_k, q_k.z_k, q_k.M^-1 q_k, r_k.q_k, q_k.q_k and (directly) r_k.z_k, r_k.r_k
+//
+// Pass B's only reason to be a kernel of its own is that beta_k needs (r.z)_k, a sum over the residual pass B has just
+// formed.  But r_k = r_{k-1} - alpha q_{k-1} with everything on the right known before pass B runs, so
+//          (r.z)_k = (r.z)_{k-1} - 2 alpha (q.z)_{k-1} + alpha^2 (q.M^-1 q)_{k-1}          (M^-1 is diagonal)
+//          (r.r)_k = (r.r)_{k-1} - 2 alpha (r.q)_{k-1} + alpha^2 (q.q)_{k-1}
+// are plain algebra on sums the previous kernel can form while it has q in registers -- no symmetry or orthogonality of
+// the operator is assumed (the single-reduction CG variants that do assume it diverge here).  The base
+// values (r.z)_{k-1}, (r.r)_{k-1} are the DIRECT sums the previous kernel formed over the residual it wrote, so nothing
+// is chained: the recurrence value differs from a direct sum over r_k only by the rounding of r_k's elements (~1e-10
+// relative), far below what the reference's own float atomics do to the same numbers.  Element by element x, r, p and q
+// are computed exactly as the two-pass kernels compute them; alpha, beta and the stop test are formed as there from
+// floats of those sums (ref .cu:1131-1178).
+//
+// Traffic: reads r q p x (8 B each) + a1 a2 a4 wx wy (20 B), writes r p q x = 84 B/pixel/iteration instead of 104, and
+// half as many kernel boundaries -- which is what the small, latency-bound levels are made of.  r and q are
+// double-buffered (rb, qb): a workgroup recomputes r_k and p_k on its tile's one-pixel ring from the OLD values of the
+// neighbouring tiles while those are being overwritten.  The last iteration's x update is left to k_flow_update_fused.
+// Row bands: like pass A, plus one sync per iteration instead of two; a band keeps its own copies of r_k and p_k on the
+// neighbouring bands' edge rows and reads only q_{k-1} of those rows from the neighbour.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int R, bool UNITW>
+__global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int nparts_prev, float tol)
+{
+    constexpr int TY = kTileY * R, TX = kTileX, LROW = TX + 8, HL = TX / 4;
+    __shared__ __attribute__((aligned(16))) float s_pu[(TY + 2) * LROW];
+    __shared__ __attribute__((aligned(16))) float s_pv[(TY + 2) * LROW];
+    __shared__ double s_red[4 * kPartKinds];
+    const int tid = threadIdx.x;
+    const bool first = (k == 0);
+
+    const PcgState prev = L.st[k & 1];
+    if (prev.stopped) {                              // uniform: the loop ended in an earlier launch
+        if (blockIdx.x == 0 && tid == 0) L.st[(k + 1) & 1] = prev;
+        return;
+    }
+    // Every launch reads the sums of the previous one and writes its own, and workgroups of one launch do not all run
+    // at the same time: the partials are double-buffered by iteration parity (the assembly writes the "-1" block).
+    const int pin_off = ((k + 1) & 1) * kPartBlock, pout_off = (k & 1) * kPartBlock;
+    float alpha = 0.f, nalpha = 0.f, beta = 0.f, rz_new, rr;
+    if (first) {                                     // r_0 = rhs: the assembly's direct sums
+        double t[2];
+        fold_band_partials_multi_256<2>(L.band_parts, pin_off + kPartRz, kMaxParts, nparts_prev, L.nbands, s_red, t);
+        rz_new = (float)t[0]; rr = (float)t[1];
+    } else {
+        double t[kPartKinds];                        // kinds in block order: rz rr pq qz qmq rq qq
+        fold_band_partials_multi_256<kPartKinds>(L.band_parts, pin_off, kMaxParts, nparts_prev, L.nbands, s_red, t);
+        const double rzd = t[0], rrd = t[1], pq = t[2], qz = t[3], qmq = t[4], rq = t[5], qq = t[6];
+        alpha = prev.rz / (float)pq;                 // ref .cu:1169
+        nalpha = (float)(-1. * (double)alpha);       // ref .cu:1174
+        const double a = (double)alpha;
+        rz_new = (float)(rzd - 2. * a * qz + a * a * qmq);
+        rr = (float)(rrd - 2. * a * rq + a * a * qq);
+        beta = rz_new / prev.rz;
+    }
+    const bool active = rr > tol;                    // ref .cu:1131
+    if (blockIdx.x == 0 && tid == 0) {
+        PcgState n; n.rz = rz_new; n.stopped = active ? 0 : 1; n.iters = prev.iters + (active ? 1 : 0); n.pad = 0;
+        L.st[(k + 1) & 1] = n;
+        if (!first) L.alpha[(k - 1) & 1] = alpha;
+    }
+    if (first && !active) return;                    // nothing ran, nothing to update
+
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int by0 = L.y0, by1 = L.y1;
+    const int tiles_x = (w + TX - 1) / TX, tiles_y = (by1 - by0 + TY - 1) / TY;
+    const int ntiles = tiles_x * tiles_y;
+    const int lx = tid & 31, ly = tid >> 5;
+    const int ko = (k + 1) & 1, kn = k & 1;          // old = k-1 (same parity as k+1), new = k
+    const float *__restrict__ rin_u = first ? L.rb_u[0] : L.rb_u[ko];
+    const float *__restrict__ rin_v = first ? L.rb_v[0] : L.rb_v[ko];
+    float *__restrict__ rout_u = L.rb_u[kn];
+    float *__restrict__ rout_v = L.rb_v[kn];
+    const float *__restrict__ qin_u = L.qb_u[ko];
+    const float *__restrict__ qin_v = L.qb_v[ko];
+    float *__restrict__ qout_u = L.qb_u[kn];
+    float *__restrict__ qout_v = L.qb_v[kn];
+    const float *__restrict__ pin_u = L.pu[ko];
+    const float *__restrict__ pin_v = L.pv[ko];
+    float *__restrict__ pout_u = L.pu[kn];
+    float *__restrict__ pout_v = L.pv[kn];
+    double acc_pq = 0., acc_qz = 0., acc_qmq = 0., acc_rq = 0., acc_qq = 0., acc_rz = 0., acc_rr = 0.;
+
+    const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
+    for (int t = tr.first; t < tr.end; t += tr.step) {
+        const int tx0 = (t % tiles_x) * TX, ty0 = by0 + (t / tiles_x) * TY;
+        float a1[R][4], a4[R][4], a2[R][4], wxc[R][4], wyc[R][4], wys[R][4], npu[R][4], npv[R][4], nru[R][4], nrv[R][4];
+        float wxw[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int x = tx0 + lx * 4, y = ty0 + ly + kTileY * q;
+            const int lrow1 = ly + kTileY * q + 1, lcol = kLInt + lx * 4;
+            const bool rowok = (y < by1) && (x < w);
+            const size_t o = (size_t)y * pitch + x;
+            wxw[q] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { a1[q][e] = 1.f; a4[q][e] = 1.f; a2[q][e] = 0.f; wxc[q][e] = 0.f; wyc[q][e] = 0.f; wys[q][e] = 0.f;
+                                          npu[q][e] = 0.f; npv[q][e] = 0.f; nru[q][e] = 0.f; nrv[q][e] = 0.f; }
+            if (rowok) {
+                float ru[4], rv[4];
+                *(float4 *)ru = ld4(rin_u + o);
+                *(float4 *)rv = ld4(rin_v + o);
+                *(float4 *)a1[q] = ld4(L.a1 + o);
+                *(float4 *)a4[q] = ld4(L.a4 + o);
+                *(float4 *)a2[q] = ld4_if(L.a2 + o, L.nt_hints & 8);
+                if (UNITW) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { wxc[q][e] = -1.f; wyc[q][e] = -1.f; wys[q][e] = -1.f; }
+                    wxw[q] = -1.f;
+                } else {
+                    *(float4 *)wxc[q] = ld4(L.wx + o);
+                    *(float4 *)wyc[q] = ld4(L.wy + o);
+                    if (y > 0) *(float4 *)wys[q] = ld4(L.wy + o - pitch);
+                    if (x > 0) wxw[q] = L.wx[o - 1];
+                }
+                float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
+                if (!first) {
+                    float qu[4], qv[4], xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0};
+                    *(float4 *)pu = ld4(pin_u + o); *(float4 *)pv = ld4(pin_v + o);
+                    *(float4 *)qu = ld4(qin_u + o); *(float4 *)qv = ld4(qin_v + o);
+                    if (k > 1) { *(float4 *)xu = ld4_if(L.xu + o, L.nt_hints & 1); *(float4 *)xv = ld4_if(L.xv + o, L.nt_hints & 1); }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        xu[e] = alpha * pu[e] + xu[e];             // jVecPVec(p0,x0,x0,alphak), ref .cu:1172
+                        xv[e] = alpha * pv[e] + xv[e];
+                        ru[e] = nalpha * qu[e] + ru[e];            // jVecPVec(dummyvec,bcu,rk,-alphak), ref .cu:1174
+                        rv[e] = nalpha * qv[e] + rv[e];
+                    }
+                    st4_if(L.xu + o, *(float4 *)xu, L.nt_hints & 1);
+                    st4_if(L.xv + o, *(float4 *)xv, L.nt_hints & 1);
+                    if (active) { st4(rout_u + o, *(float4 *)ru); st4(rout_v + o, *(float4 *)rv); }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool ok = (x + e) < w;
+                    nru[q][e] = ok ? ru[e] : 0.f; nrv[q][e] = ok ? rv[e] : 0.f;
+                    npu[q][e] = ok ? direction(ru[e], pu[e], a1[q][e], beta, first) : 0.f;
+                    npv[q][e] = ok ? direction(rv[e], pv[e], a4[q][e], beta, first) : 0.f;
+                }
+            }
+            st4(&s_pu[lrow1 * LROW + lcol], *(float4 *)npu[q]);
+            st4(&s_pv[lrow1 * LROW + lcol], *(float4 *)npv[q]);
+        }
+        if (!active) continue;                           // the loop has ended: only x needed its last update (uniform)
+        // one-pixel ring of p_k, recomputed from the old r, q, p of the neighbouring pixels
+        if (tid < 2 * HL) {                              // rows above and below the tile
+            const int hy = (tid < HL) ? ty0 - 1 : ty0 + TY;
+            const int hx = tx0 + (tid % HL) * 4;
+            const int lrow = (tid < HL) ? 0 : TY + 1;
+            float hu[4] = {0, 0, 0, 0}, hv[4] = {0, 0, 0, 0};
+            if (hy >= 0 && hy < h && hx < w) {
+                const size_t ho = (size_t)hy * pitch + hx;
+                const bool outside = (hy < by0 || hy >= by1);          // a neighbouring band's row
+                float r0[4], r1[4], d0[4], d1[4], p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
+                *(float4 *)r0 = ld4(rin_u + ho); *(float4 *)r1 = ld4(rin_v + ho);
+                *(float4 *)d0 = ld4(L.a1 + ho); *(float4 *)d1 = ld4(L.a4 + ho);
+                if (!first) {
+                    float q0[4], q1[4];
+                    // q of a neighbouring band's row comes from that band's plane; r and p of it are this band's own copies
+                    const float *hqu = (hy < by0) ? L.qup_u[ko] : (hy >= by1) ? L.qdn_u[ko] : qin_u;
+                    const float *hqv = (hy < by0) ? L.qup_v[ko] : (hy >= by1) ? L.qdn_v[ko] : qin_v;
+                    *(float4 *)q0 = ld4(hqu + ho); *(float4 *)q1 = ld4(hqv + ho);
+                    *(float4 *)p0 = ld4(pin_u + ho); *(float4 *)p1 = ld4(pin_v + ho);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { r0[e] = nalpha * q0[e] + r0[e]; r1[e] = nalpha * q1[e] + r1[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool ok = (hx + e) < w;
+                    hu[e] = ok ? direction(r0[e], p0[e], d0[e], beta, first) : 0.f;
+                    hv[e] = ok ? direction(r1[e], p1[e], d1[e], beta, first) : 0.f;
+                }
+                if (outside) {                           // keep this band's copies of r_k and p_k on that row current
+                    if (!first) { st4(rout_u + ho, *(float4 *)r0); st4(rout_v + ho, *(float4 *)r1); }
+                    st4(pout_u + ho, *(float4 *)hu); st4(pout_v + ho, *(float4 *)hv);
+                }
+            }
+            st4(&s_pu[lrow * LROW + kLInt + (tid % HL) * 4], *(float4 *)hu);
+            st4(&s_pv[lrow * LROW + kLInt + (tid % HL) * 4], *(float4 *)hv);
+        } else if (tid < 2 * HL + 2 * TY) {              // columns left and right of the tile
+            const int side = (tid - 2 * HL) / TY, row = (tid - 2 * HL) % TY;
+            const int hy = ty0 + row;
+            const int hx = side ? tx0 + TX : tx0 - 1;
+            float hu = 0.f, hv = 0.f;
+            if (hy < by1 && hx >= 0 && hx < w) {
+                const size_t ho = (size_t)hy * pitch + hx;
+                float r0 = rin_u[ho], r1 = rin_v[ho], p0 = 0.f, p1 = 0.f;
+                if (!first) {
+                    r0 = nalpha * qin_u[ho] + r0; r1 = nalpha * qin_v[ho] + r1;
+                    p0 = pin_u[ho]; p1 = pin_v[ho];
+                }
+                hu = direction(r0, p0, L.a1[ho], beta, first);
+                hv = direction(r1, p1, L.a4[ho], beta, first);
+            }
+            const int lcol = side ? kLInt + TX : kLInt - 1;
+            s_pu[(row + 1) * LROW + lcol] = hu;
+            s_pv[(row + 1) * LROW + lcol] = hv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int x = tx0 + lx * 4, y = ty0 + ly + kTileY * q;
+            const int lrow = ly + kTileY * q, lc = kLInt + lx * 4;
+            if ((y < by1) && (x < w)) {
+                float su[4], sv[4], nu[4], nv[4];
+                *(float4 *)su = ld4(&s_pu[lrow * LROW + lc]);
+                *(float4 *)sv = ld4(&s_pv[lrow * LROW + lc]);
+                *(float4 *)nu = ld4(&s_pu[(lrow + 2) * LROW + lc]);
+                *(float4 *)nv = ld4(&s_pv[(lrow + 2) * LROW + lc]);
+                const float uwest = s_pu[(lrow + 1) * LROW + lc - 1];
+                const float vwest = s_pv[(lrow + 1) * LROW + lc - 1];
+                const float ueast = s_pu[(lrow + 1) * LROW + lc + 4];
+                const float veast = s_pv[(lrow + 1) * LROW + lc + 4];
+                float qu[4], qv[4];
+                float d_pq = 0.f, d_qz = 0.f, d_qmq = 0.f, d_rq = 0.f, d_qq = 0.f, d_rz = 0.f, d_rr = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = x + e;
+                    const float pwu = (e == 0) ? uwest : npu[q][(e + 3) & 3], pwv = (e == 0) ? vwest : npv[q][(e + 3) & 3];
+                    const float peu = (e == 3) ? ueast : npu[q][(e + 1) & 3], pev = (e == 3) ? veast : npv[q][(e + 1) & 3];
+                    const float a5 = (e == 0) ? wxw[q] : wxc[q][(e + 3) & 3];
+                    const float wS = (y == h - 1) ? wys[q][e] + wyc[q][e] : wys[q][e];
+                    const float wW = (i == w - 1) ? a5 + wxc[q][e] : a5;
+                    const float wE = (i == 0) ? wxc[q][e] + wxc[q][e] : wxc[q][e];
+                    const float wN = (y == 0) ? wyc[q][e] + wyc[q][e] : wyc[q][e];
+                    float sumu = 0.f, sumv = 0.f;
+                    if (y > 0) { sumu += wS * su[e]; sumv += wS * sv[e]; }
+                    if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
+                    sumu += a1[q][e] * npu[q][e]; sumv += a2[q][e] * npu[q][e];
+                    sumu += a2[q][e] * npv[q][e]; sumv += a4[q][e] * npv[q][e];
+                    if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
+                    if (y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
+                    qu[e] = sumu; qv[e] = sumv;
+                    if (i < w) {
+                        const float iu = 1.0f / a1[q][e], iv = 1.0f / a4[q][e];
+                        const float zu = iu * nru[q][e], zv = iv * nrv[q][e];
+                        d_pq += npu[q][e] * sumu; d_pq += npv[q][e] * sumv;
+                        d_qz += sumu * zu; d_qz += sumv * zv;
+                        d_qmq += sumu * (iu * sumu); d_qmq += sumv * (iv * sumv);
+                        d_rq += nru[q][e] * sumu; d_rq += nrv[q][e] * sumv;
+                        d_qq += sumu * sumu; d_qq += sumv * sumv;
+                        d_rz += nru[q][e] * zu; d_rz += nrv[q][e] * zv;
+                        d_rr += nru[q][e] * nru[q][e]; d_rr += nrv[q][e] * nrv[q][e];
+                    }
+                }
+                const size_t o = (size_t)y * pitch + x;
+                st4(pout_u + o, *(float4 *)npu[q]);
+                st4(pout_v + o, *(float4 *)npv[q]);
+                st4(qout_u + o, *(float4 *)qu);
+                st4(qout_v + o, *(float4 *)qv);
+                acc_pq += (double)d_pq; acc_qz += (double)d_qz; acc_qmq += (double)d_qmq; acc_rq += (double)d_rq;
+                acc_qq += (double)d_qq; acc_rz += (double)d_rz; acc_rr += (double)d_rr;
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    double *own = L.part_own + pout_off;                 // this launch's block: kinds are kMaxParts apart
+    const double accs[kPartKinds] = {acc_rz, acc_rr, acc_pq, acc_qz, acc_qmq, acc_rq, acc_qq};
+    double tot[kPartKinds];
+    block_sum_multi_256<kPartKinds>(accs, s_red, tot);
+    if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j < kPartKinds; j++) own[j * kMaxParts + blockIdx.x] = tot[j];
+    }
+}
+
+// u += dx, v += dy after a solve made of `nlaunched` fused kernels (ref .cu:1185-1195).  A solve that ran into its
+// iteration cap leaves the last alpha p to be added here; one that met the tolerance has a complete x.
+__global__ __launch_bounds__(256) void k_flow_update_fused(LevelPtrs L, int nlaunched, int nparts)
+{
+    __shared__ double s_red[8];
+    const PcgState st = L.st[nlaunched & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *L.iter_total += st.iters;
+    const int n = st.iters;
+    if (n == 0) return;
+    const bool pending = (st.stopped == 0);              // every launch ran an iteration: the last x update is outstanding
+    float apend = 0.f;
+    if (pending)
+        apend = st.rz / (float)fold_band_partials_256(L.band_parts, ((nlaunched - 1) & 1) * kPartBlock + kPartPq, nparts, L.nbands, s_red);
+    const bool have_x = pending ? (n >= 2) : true;
+    const float *__restrict__ ppu = L.pu[(nlaunched - 1) & 1];
+    const float *__restrict__ ppv = L.pv[(nlaunched - 1) & 1];
+    const int w = L.w, pitch = L.pitch;
+    const int gw = (w + 3) / 4;
+    const long ngroups = (long)gw * (L.y1 - L.y0);
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
+        const int y = (int)(g / gw), x = (int)(g - (long)y * gw) * 4;
+        const size_t o = (size_t)(L.y0 + y) * pitch + x;
+        float4 u = ld4(L.u + o), v = ld4(L.v + o), dx = make_float4(0, 0, 0, 0), dy = dx;
+        if (have_x) { dx = ld4(L.xu + o); dy = ld4(L.xv + o); }
+        if (pending) {
+            const float4 pu = ld4(ppu + o), pv = ld4(ppv + o);
+            dx.x = apend * pu.x + dx.x; dx.y = apend * pu.y + dx.y; dx.z = apend * pu.z + dx.z; dx.w = apend * pu.w + dx.w;
+            dy.x = apend * pv.x + dy.x; dy.y = apend * pv.y + dy.y; dy.z = apend * pv.z + dy.z; dy.w = apend * pv.w + dy.w;
+            st4(L.xu + o, dx); st4(L.xv + o, dy);          // keep x complete for the debug tap
+        }
+        u.x = u.x + dx.x; u.y = u.y + dx.y; u.z = u.z + dx.z; u.w = u.w + dx.w;
+        v.x = v.x + dy.x; v.y = v.y + dy.y; v.z = v.z + dy.z; v.w = v.w + dy.w;
+        st4(L.u + o, u); st4(L.v + o, v);
+    }
+}
+
 struct BOperands {
     float4 ru, rv, pu, pv, qu, qv, mu, mv, xu, xv, ou, ov;   // ou/ov: the previous iteration's p (deferred x update)
     size_t o;
@@ -912,6 +1220,40 @@ void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev
 void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid)
 {
     hipLaunchKernelGGL(k_pcg_pass_b, dim3(grid), dim3(256), 0, s, L, k, nparts_a);
+}
+
+// Fused PCG: grid (shared by every launch of a solve, it is also the number of partials), launch, flow update.
+static int g_fused_r = 0;            // tuning: 0 = by size, 1 / 2 = force the 128 x 8 / 128 x 16 tile
+void set_fused_rows(int r) { g_fused_r = (r == 1 || r == 2) ? r : 0; }
+static int fused_rows(int w, int rows) { return g_fused_r ? g_fused_r : (((long)w * rows < (1L << 20)) ? 1 : 2); }
+
+int pcg_fused_grid_size(int w, int rows, int unit_w)
+{
+    const int R = fused_rows(w, rows);                                // small levels: more, smaller tiles
+    const long items = (long)((w + kTileX - 1) / kTileX) * ((rows + kTileY * R - 1) / (kTileY * R));
+    // never more workgroups than are resident at once (a second wave of a persistent grid runs on a half-empty chip):
+    // 128 x 16 tiles need 180 / 163 VGPRs (2 / 3 workgroups per CU), 128 x 8 tiles 135 / 122 (3 / 4)
+    const long cap = 256 * (R == 2 ? (unit_w ? 3 : 2) : (unit_w ? 4 : 3));
+    if (items <= cap) return (int)(items < 1 ? 1 : items);
+    const long rounds = (items + cap - 1) / cap;
+    return (int)((items + rounds - 1) / rounds);
+}
+
+void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
+{
+    const bool small = fused_rows(L.w, L.y1 - L.y0) == 1;
+    if (small) {
+        if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused<1, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        else hipLaunchKernelGGL((k_pcg_fused<1, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    } else {
+        if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused<2, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        else hipLaunchKernelGGL((k_pcg_fused<2, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    }
+}
+
+void launch_flow_update_fused(hipStream_t s, const LevelPtrs &L, int nlaunched, int nparts)
+{
+    hipLaunchKernelGGL(k_flow_update_fused, dim3(stream_grid_size(L.w, L.y1 - L.y0)), dim3(256), 0, s, L, nlaunched, nparts);
 }
 
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int nlaunched)

@@ -18,7 +18,13 @@ constexpr int kMaxChan = 3;
 constexpr int kMaxParts = 2048;      // upper bound on persistent blocks == reduction partials
                                      // (256 CUs x 8 resident 256-thread workgroups)
 constexpr int kMaxBands = 8;         // row bands of one frame solved side by side (vof_tiled.hip)
-constexpr int kPartRz = 0, kPartRr = kMaxParts, kPartPq = 2 * kMaxParts;   // a band's partial block: [rz | rr | pq] x kMaxParts doubles
+// A band's partial block: kPartKinds arrays of kMaxParts doubles.  rz, rr: direct sums over the current residual (written
+// by the assembly, pass B and the fused pass); pq: p.q; the last four only by the fused pass (pcg_kernels.hip):
+// q.z, q.M^-1 q, r.q and q.q, from which the NEXT residual's r.z and r.r follow without another sweep.
+constexpr int kPartKinds = 7;
+constexpr int kPartBlock = kPartKinds * kMaxParts;   // doubles per block; every band owns TWO blocks (see k_pcg_fused)
+constexpr int kPartRz = 0, kPartRr = kMaxParts, kPartPq = 2 * kMaxParts, kPartQz = 3 * kMaxParts, kPartQmq = 4 * kMaxParts,
+              kPartRq = 5 * kMaxParts, kPartQq = 6 * kMaxParts;
 constexpr int kBandAlign = 32;       // band boundaries are multiples of this many rows (a whole number of pass A tiles)
 
 // PCG tile geometry: 256 threads, each owning 4 consecutive pixels of one row.
@@ -45,7 +51,13 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     float *ru, *rv, *qu, *qv, *xu, *xv;             // r (starts as rhs), q = A p, x
     float *pu[2], *pv[2];                           // search direction, ping-pong by iteration parity:
                                                     // pass A(k) reads p[k&1] (halo too) and writes p[(k+1)&1]
-    double *part_rz, *part_rr, *part_pq;            // where THIS launch writes its per-workgroup partials
+    double *part_rz, *part_rr, *part_pq;            // where THIS launch writes its per-workgroup partials (= own block + kind)
+    double *part_own;                               // base of this band's two partial blocks
+    // Fused one-kernel-per-iteration PCG (k_pcg_fused): r and q are double-buffered like p, because a workgroup reads
+    // the old values of its neighbours' pixels while those workgroups write the new ones.  r_k is in rb[k & 1] (r_0 =
+    // the rhs, written by the assembly into rb[0] == ru/rv), q_k in qb[k & 1].
+    float *rb_u[2], *rb_v[2], *qb_u[2], *qb_v[2];
+    const float *qup_u[2], *qup_v[2], *qdn_u[2], *qdn_v[2];   // the q planes rows y0-1 / y1 are read from (neighbouring bands)
     // Row band of the level this launch works on (vof_tiled.hip); a plain plan has one band covering the frame.
     // Planes are always addressed with frame coordinates: a band's neighbours' rows exist in its planes as halos.
     int y0, y1;                     // rows this band owns: PCG passes, flow update and the dot products cover [y0, y1)
@@ -95,6 +107,10 @@ void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P,
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid);
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int niter_launched);
+void set_fused_rows(int r);                  // tuning: tile rows of the fused kernel (0 = by level size)
+int  pcg_fused_grid_size(int w, int rows, int unit_w);   // fused one-kernel-per-iteration PCG (pcg_kernels.hip)
+void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
+void launch_flow_update_fused(hipStream_t s, const LevelPtrs &L, int niter_launched, int nparts);
 bool pcg_small_applicable(int w, int h);
 void pcg_small_configure();
 void launch_pcg_solve_small(hipStream_t s, const LevelPtrs &L, int maxit, float tol);   // whole solve + flow update, one workgroup

@@ -103,8 +103,12 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
     L.pu[0] = pl->pu[0]; L.pu[1] = pl->pu[1]; L.pv[0] = pl->pv[0]; L.pv[1] = pl->pv[1];
     L.qu = pl->qu; L.qv = pl->qv; L.xu = pl->xu; L.xv = pl->xv;
     L.part_rz = pl->d_parts; L.part_rr = pl->d_parts + kMaxParts; L.part_pq = pl->d_parts + 2 * kMaxParts;
+    L.part_own = pl->d_parts;
     for (int b = 0; b < kMaxBands; b++) L.band_parts[b] = pl->d_parts;
     L.ru_up = L.ru_dn = pl->ru; L.rv_up = L.rv_dn = pl->rv;
+    L.rb_u[0] = pl->ru; L.rb_v[0] = pl->rv; L.rb_u[1] = pl->ru2; L.rb_v[1] = pl->rv2;
+    L.qb_u[0] = pl->qu; L.qb_v[0] = pl->qv; L.qb_u[1] = pl->qu2; L.qb_v[1] = pl->qv2;
+    for (int i = 0; i < 2; i++) { L.qup_u[i] = L.qdn_u[i] = L.qb_u[i]; L.qup_v[i] = L.qdn_v[i] = L.qb_v[i]; }
     L.y0 = 0; L.y1 = li.h; L.ya0 = 0; L.ya1 = li.h; L.nbands = 1;
     L.st = pl->d_state; L.iter_total = pl->d_iters; L.alpha = pl->d_alpha; L.defer_x = pl->defer_x;
     L.reverse_b = pl->reverse_b;
@@ -216,6 +220,8 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_DEFER_X")) pl->defer_x = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_GRAPH")) pl->use_graph = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_UNIT_W")) pl->use_unit_w = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_FUSED")) pl->use_fused = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_FUSED_ROWS")) set_fused_rows(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_UNIT_W_CAP")) set_unit_w_cap(atoi(e));
     {
         const char *ea = getenv("OCTANE_TUNE_CAP_A"), *eb = getenv("OCTANE_TUNE_CAP_B");
@@ -254,7 +260,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     }
 
     const int nc = nchan;
-    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 17 + 1;
+    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 17 + 1 + 4;
     size_t skew = 0;                              // developer knob: stagger the planes' base addresses (floats)
     if (const char *e = getenv("OCTANE_TUNE_SKEW")) skew = (size_t)atol(e) / 64 * 64;
     size_t align_f = 0;                           // developer knob: round the plane stride up to a multiple (bytes)
@@ -296,6 +302,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         pl->pu[0] = take(1); pl->pu[1] = take(1); pl->pv[0] = take(1); pl->pv[1] = take(1);
         pl->qu = take(1); pl->qv = take(1); pl->xu = take(1); pl->xv = take(1);
         pl->tmp = take(1);
+        pl->ru2 = take(1); pl->rv2 = take(1); pl->qu2 = take(1); pl->qv2 = take(1);
     };
     carve(pl->arena);
 
@@ -305,14 +312,14 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         if (hipMalloc((void **)&pl->d_taps, ntaps * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         if (!taps.empty() &&
             hipMemcpy(pl->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = OCTANE_E_HIP; break; }
-        if (hipMalloc((void **)&pl->d_parts, 3 * kMaxParts * sizeof(double)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMalloc((void **)&pl->d_parts, 2 * kPartBlock * sizeof(double)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         if (hipMalloc((void **)&pl->d_state, 2 * sizeof(PcgState)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         if (hipMalloc((void **)&pl->d_alpha, 2 * sizeof(float)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         if (hipMemset(pl->d_alpha, 0, 2 * sizeof(float)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMalloc((void **)&pl->d_iters, sizeof(long long)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         if (hipHostMalloc((void **)&pl->h_iters, sizeof(long long)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         *pl->h_iters = 0;
-        if (hipMemset(pl->d_parts, 0, 3 * kMaxParts * sizeof(double)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipMemset(pl->d_parts, 0, 2 * kPartBlock * sizeof(double)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMemset(pl->d_state, 0, 2 * sizeof(PcgState)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipStreamCreateWithFlags(&pl->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = OCTANE_E_HIP; break; }
     } while (0);
@@ -481,6 +488,7 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
     fill_level_ptrs(pl, li, cur, c.lev1, c.lev2, c.ut, c.vt, L);
 
     const int g_asm = assemble_grid_size(li.w, li.h);
+    const int g_f_plain = pcg_fused_grid_size(li.w, li.h, 0), g_f_unit = pcg_fused_grid_size(li.w, li.h, 1);
     const int g_a_plain = pcg_grid_size(li.w, li.h);
     const int g_a_unit = pcg_grid_size_unit_w(li.w, li.h);
     const int g_b = pcg_b_grid_size(li.w, li.h);
@@ -495,9 +503,16 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
         ap.dozim = prm.dozim != 0;
         L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;   // al1 == 1: all neighbour weights are exactly -1
         const int g_a = L.unit_w ? g_a_unit : g_a_plain;
+        const int g_f = L.unit_w ? g_f_unit : g_f_plain;
         for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
             EvPair *e = ev_begin(pl, s, EV_ASM, pf);
-            launch_assemble(s, L, ap, g_asm);
+            if (pl->use_fused && !small) {     // the fused kernels double-buffer the partials; the rhs sums go to the "-1" block
+                LevelPtrs La = L;
+                La.part_rz = L.part_own + kPartBlock + kPartRz; La.part_rr = L.part_own + kPartBlock + kPartRr;
+                launch_assemble(s, La, ap, g_asm);
+            } else {
+                launch_assemble(s, L, ap, g_asm);
+            }
             ev_end(e, s);
             if (pl->trace) {
                 int rc = emit(pl, s, "coef7", k, gnc, l, {pl->a1, pl->a2, pl->a4, pl->wx, pl->wy, pl->ru, pl->rv}, li.w, li.h, li.pitch);
@@ -505,6 +520,15 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
             }
             if (small) {       // coarsest levels: the whole solve and the flow update in one workgroup
                 launch_pcg_solve_small(s, L, prm.cgiters, pl->tol);
+            } else if (pl->use_fused) {
+                for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182, one kernel per iteration
+                    e = ev_begin(pl, s, EV_PASS_A, pf);
+                    launch_pcg_fused(s, L, it, it == 0 ? g_asm : g_f, g_f, pl->tol);
+                    ev_end(e, s);
+                }
+                e = ev_begin(pl, s, EV_UPD, pf);
+                launch_flow_update_fused(s, L, prm.cgiters, g_f);   // ref .cu:1185-1195 (+ the last x update)
+                ev_end(e, s);
             } else {
                 for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182
                     e = ev_begin(pl, s, EV_PASS_A, pf);
@@ -1199,6 +1223,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "defer_x") pl->defer_x = value != 0;
     else if (k == "small") pl->use_small = value != 0;
     else if (k == "unit_w") pl->use_unit_w = value != 0;
+    else if (k == "fused") pl->use_fused = value != 0;
     else return OCTANE_E_INVALID;
     return OCTANE_OK;
 }

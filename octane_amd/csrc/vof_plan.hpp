@@ -32,8 +32,9 @@ struct octane_vof_plan {
     float *gx1, *gy1, *gx2, *gy2, *gxx, *gxy, *gyy;
     float *U[2], *V[2], *ut, *vt;
     float *a1, *a2, *a4, *wx, *wy, *mu, *mv, *ru, *rv, *pu[2], *pv[2], *qu, *qv, *xu, *xv, *tmp;
+    float *ru2, *rv2, *qu2, *qv2;  // second halves of the r / q double buffers of the fused PCG kernel
     float *d_taps = nullptr;
-    double *d_parts = nullptr;     // 3 * kMaxParts
+    double *d_parts = nullptr;     // 2 * kPartBlock
     octane::PcgState *d_state = nullptr;   // 2
     float *d_alpha = nullptr;      // 2
     long long *d_iters = nullptr;
@@ -51,6 +52,7 @@ struct octane_vof_plan {
     int xcd_bands = 0;
     int use_small = 1;
     int defer_x = 1;
+    int use_fused = 1;   // one fused kernel per PCG iteration (84 B/px) instead of pass A + pass B (104 B/px)
     int use_unit_w = 1;  // pass A skips the wx / wy planes while they hold the constant -1 (first GNC step)
     int use_graph = 0;   // OCTANE_TUNE_GRAPH=1: replay the pyramid as one hipGraph (measured: no throughput gain,
                          // the host already runs ahead of the GPU; useful only when calls are latency-bound)

@@ -152,8 +152,8 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
         rc = plan_create_ex(&t->pl[b], nx, ny, nchan, &pb, sharing > 1 ? 1 : 4);
         if (rc != OCTANE_OK) break;
         if (hipSetDevice(t->dev[b]) != hipSuccess ||
-            hipMalloc((void **)&t->parts[b], (size_t)3 * kMaxParts * sizeof(double)) != hipSuccess ||
-            hipMemset(t->parts[b], 0, (size_t)3 * kMaxParts * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&t->parts[b], (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
+            hipMemset(t->parts[b], 0, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
             hipEventCreateWithFlags(&t->ev[b], hipEventDisableTiming) != hipSuccess) {
             set_last_error("octane_vof_tiled_create: device allocation failed");
             rc = OCTANE_E_NOMEM;
@@ -205,7 +205,7 @@ extern "C" long long octane_vof_tiled_last_copies(octane_vof_tiled *t) { return 
 
 extern "C" size_t octane_vof_tiled_device_bytes(const octane_vof_tiled *t)
 {
-    return t ? t->pl[0]->arena_bytes + (size_t)3 * kMaxParts * sizeof(double) : 0;
+    return t ? t->pl[0]->arena_bytes + (size_t)2 * kPartBlock * sizeof(double) : 0;
 }
 
 // ---- how a band reaches the others ---------------------------------------------------------------------------------
@@ -298,7 +298,7 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
     L.ya1 = (b == nb - 1) ? li.h : L.y1 + 1;
     L.nbands = nb;
     double *own = N.parts[b];
-    L.part_rz = own + kPartRz; L.part_rr = own + kPartRr; L.part_pq = own + kPartPq;
+    L.part_rz = own + kPartRz; L.part_rr = own + kPartRr; L.part_pq = own + kPartPq; L.part_own = own;
     for (int c = 0; c < kMaxBands; c++) L.band_parts[c] = N.parts[c < nb ? c : b];
     const int up = b > 0 ? b - 1 : b, dn = b < nb - 1 ? b + 1 : b;
     L.ru_up = N.peer(up, b, pl->ru); L.rv_up = N.peer(up, b, pl->rv);
@@ -631,8 +631,8 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
     int rc = plan_create_ex(&m->pl, nx, ny, nchan, p, 1);
     if (rc != OCTANE_OK) { delete m; return rc; }
     m->device = m->pl->device;
-    if (hipMalloc((void **)&m->parts, (size_t)3 * kMaxParts * sizeof(double)) != hipSuccess ||
-        hipMemset(m->parts, 0, (size_t)3 * kMaxParts * sizeof(double)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    if (hipMalloc((void **)&m->parts, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
+        hipMemset(m->parts, 0, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         set_last_error("octane_vof_mp_create: device allocation failed");
         octane_vof_mp_destroy(m);
         return OCTANE_E_NOMEM;
