@@ -10,8 +10,8 @@ over pairs: no collective in the data path; weak scaling); value = N * pixels / 
 time.
 
 The JSON line also carries
-  roofline      -- dominant kernel (PCG pass A at the finest level): algorithmic bytes per launch
-                   (52 B/pixel, DESIGN.md) / its mean duration from HIP events on the launch stream;
+  roofline      -- dominant kernel (the fused PCG iteration at the finest level): algorithmic bytes per launch
+                   (84 B/pixel, 76 in the first GNC step; DESIGN.md) / its mean duration from HIP events on the launch stream;
   cpu_baseline  -- the CPU oracle ("port", OpenMP over the host cores) timed on a bounded sample (rank 0, N=1 only).
 """
 import argparse
@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 PASS_A_BYTES_PER_PIXEL = 36 + 16   # reads r(2) p(2) a1 a2 a4 wx wy, writes p(2) q(2)  -- DESIGN.md
 PASS_A_BYTES_PER_PIXEL_GNC0 = 28 + 16   # first GNC step (a third of the launches): wx == wy == -1, the planes are not read
 PASS_B_BYTES_PER_PIXEL = 40 + 16   # reads x(2) r(2) p(2) q(2) a1 a4, writes x(2) r(2)
+FUSED_BYTES_PER_PIXEL = 52 + 32    # one fused kernel per iteration: reads r q p x (32) a1 a2 a4 wx wy (20), writes r p q x (32)
+FUSED_BYTES_PER_PIXEL_GNC0 = 44 + 32   # first GNC step: wx == wy == -1, not read
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -278,14 +280,20 @@ def main():
         plan.set_profiling(False)
         a_ms = pr.pass_a_ms / max(1, pr.pass_a_launches)
         b_ms = pr.pass_b_ms / max(1, pr.pass_b_launches)
-        # mean algorithmic bytes of a finest-level pass A launch: the three GNC steps run the same number of launches
-        bpp_a = PASS_A_BYTES_PER_PIXEL
-        if os.environ.get("OCTANE_TUNE_UNIT_W", "1") != "0":
-            bpp_a = (PASS_A_BYTES_PER_PIXEL_GNC0 + 2 * PASS_A_BYTES_PER_PIXEL) / 3.0
-        if pr.pass_a_ms >= pr.pass_b_ms:
-            dom, dms, bpp = "k_pcg_pass_a", a_ms, bpp_a
+        unit_w = os.environ.get("OCTANE_TUNE_UNIT_W", "1") != "0"
+        fused = pr.pass_b_launches == 0          # one kernel per PCG iteration (the default); its launches are timed as "pass A"
+        if fused:
+            # mean algorithmic bytes of a finest-level launch: 84 B/px, 76 in the first of the three GNC steps
+            bpp = (FUSED_BYTES_PER_PIXEL_GNC0 + 2 * FUSED_BYTES_PER_PIXEL) / 3.0 if unit_w else FUSED_BYTES_PER_PIXEL
+            dom, dms = "k_pcg_fused", a_ms
+            iter_ms = a_ms
         else:
-            dom, dms, bpp = "k_pcg_pass_b", b_ms, PASS_B_BYTES_PER_PIXEL
+            bpp_a = (PASS_A_BYTES_PER_PIXEL_GNC0 + 2 * PASS_A_BYTES_PER_PIXEL) / 3.0 if unit_w else PASS_A_BYTES_PER_PIXEL
+            if pr.pass_a_ms >= pr.pass_b_ms:
+                dom, dms, bpp = "k_pcg_pass_a", a_ms, bpp_a
+            else:
+                dom, dms, bpp = "k_pcg_pass_b", b_ms, PASS_B_BYTES_PER_PIXEL
+            iter_ms = a_ms + b_ms
         # HBM-side traffic of that kernel from the PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be
         # collected inside this run; tools/profile_round.sh + tools/summarize_rocprof.py produce the file)
         traffic = None
@@ -296,16 +304,16 @@ def main():
         except (OSError, ValueError):
             pass
         achieved = bpp * n * n / (dms * 1e-3) / 1e9
-        iter_gbs = (PASS_A_BYTES_PER_PIXEL + PASS_B_BYTES_PER_PIXEL + 8) * n * n / ((a_ms + b_ms) * 1e-3) / 1e9
+        iter_gbs = 116 * n * n / (iter_ms * 1e-3) / 1e9
+        survey_bpp = 116 if fused else (60 if dom == "k_pcg_pass_a" else 56)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(dms, 4), "bytes_per_launch": int(round(bpp * n * n)),
-                "pass_a_ms": round(a_ms, 4), "pass_b_ms": round(b_ms, 4),
+                "pcg_iteration_ms": round(iter_ms, 4),
+                # one whole PCG iteration on SURVEY 8(d)'s accounting (116 B/px: pass A with seven coefficient planes + pass B).
+                # This implementation moves 84 (fused kernel, five planes) -- the figure above counts those, the stricter one.
                 "pcg_iteration_gbs_at_116B_per_pixel": round(iter_gbs, 1),
-                # the same kernel on SURVEY 8(d)'s accounting (pass A 60 B/px with all seven coefficient planes, pass B 56):
-                # this implementation stores five planes (and skips two more in the first GNC step), so the figure above
-                # -- bytes it actually has to move -- is the stricter one
-                "frac_at_survey_bytes": round((60 if dom == "k_pcg_pass_a" else 56) * n * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_at_survey_bytes": round(survey_bpp * n * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "assemble_ms": round(pr.assemble_ms / max(1, pr.assemble_launches), 4),
                 "setup_ms_all_levels": round(pr.setup_ms, 3), "profiled_step_ms": round(pr.total_ms, 2)}
 

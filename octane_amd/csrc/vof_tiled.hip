@@ -310,6 +310,12 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
     const int g_asm = assemble_grid_size(li.w, maxrows + 2);
     const int g_a = pcg_band_grid_size(li.w, maxrows);
     const int g_b = pcg_b_grid_size(li.w, maxrows);
+    const bool fused = pl->use_fused != 0;
+    if (fused)          // q of the neighbouring bands' edge rows is read from their planes (both halves of the double buffer)
+        for (int i = 0; i < 2; i++) {
+            L.qup_u[i] = N.peer(up, b, L.qb_u[i]); L.qup_v[i] = N.peer(up, b, L.qb_v[i]);
+            L.qdn_u[i] = N.peer(dn, b, L.qb_u[i]); L.qdn_v[i] = N.peer(dn, b, L.qb_v[i]);
+        }
 
     for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
         AssembleParams ap;
@@ -319,16 +325,29 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
         ap.lambdac = li.lambdac;
         ap.dozim = prm.dozim != 0;
         L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;
+        const int g_f = pcg_fused_grid_size(li.w, maxrows, L.unit_w);
         for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
-            if (!N.failed()) launch_assemble(s, L, ap, g_asm);
-            N.sync(b);
-            for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182
-                if (!N.failed()) launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
-                N.sync(b);
-                if (!N.failed()) launch_pcg_pass_b(s, L, it, g_a, g_b);
-                N.sync(b);
+            if (!N.failed()) {
+                LevelPtrs La = L;
+                if (fused) { La.part_rz = L.part_own + kPartBlock + kPartRz; La.part_rr = L.part_own + kPartBlock + kPartRr; }
+                launch_assemble(s, La, ap, g_asm);
             }
-            if (!N.failed()) launch_flow_update(s, L, prm.cgiters);          // ref .cu:1185-1195
+            N.sync(b);
+            if (fused) {
+                for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182: one kernel and one boundary per iteration
+                    if (!N.failed()) launch_pcg_fused(s, L, it, it == 0 ? g_asm : g_f, g_f, pl->tol);
+                    N.sync(b);
+                }
+                if (!N.failed()) launch_flow_update_fused(s, L, prm.cgiters, g_f);     // ref .cu:1185-1195
+            } else {
+                for (int it = 0; it < prm.cgiters; it++) {
+                    if (!N.failed()) launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
+                    N.sync(b);
+                    if (!N.failed()) launch_pcg_pass_b(s, L, it, g_a, g_b);
+                    N.sync(b);
+                }
+                if (!N.failed()) launch_flow_update(s, L, prm.cgiters);
+            }
             // the next assembly reads u, v two rows beyond the band (one for the halo row it fills, one for that
             // row's own 3 x 3 neighbourhood)
             if (b > 0) {

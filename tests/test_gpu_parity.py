@@ -307,3 +307,25 @@ def test_full_disk_frame_runs_on_one_gpu(capi):
     tu, tv = synth.true_lattice_flow(n, n, xp=torch)
     assert (cu - tu[m:-m:16, m:-m:16]).abs().mean() < 0.1 and (cv - tv[m:-m:16, m:-m:16]).abs().mean() < 0.1
     pl.close()
+
+
+@pytest.mark.parametrize("nx,ny,prm", [(700, 520, dict(kiters=3, liters=2, cgiters=17)),      # 128 x 8 tiles, odd iteration count
+                                        (1500, 1100, dict(kiters=2, liters=1, cgiters=12)),     # 128 x 16 tiles, more workgroups than are resident
+                                        (300, 260, dict(kiters=4, liters=1, cgiters=1))])       # a single iteration: only the pending update
+def test_fused_iteration_equals_two_pass_form(capi, nx, ny, prm):
+    """One fused kernel per PCG iteration (r.z, r.r of the next residual by recurrence) against pass A + pass B (direct
+    sums): same iterates up to the rounding of those scalars, same iteration counts, and bit-identical from run to run
+    (the partial sums are double-buffered: workgroups of one launch do not all run at the same time)."""
+    a, b = synth.lattice_scene(nx, ny, seed=nx + 3 * ny)
+    outs, its = {}, {}
+    for fused in (0, 1):
+        pl = capi.Plan(nx, ny, 1, capi.FlowParams(**prm))
+        pl.tune("fused", fused)
+        outs[fused] = [pl.run_host(a, b) for _ in range(2)]
+        its[fused] = pl.last_iterations()
+        pl.close()
+    assert its[0] == its[1]
+    assert np.array_equal(outs[1][0][0], outs[1][1][0]) and np.array_equal(outs[1][0][1], outs[1][1][1])
+    assert np.isfinite(outs[1][0][0]).all()
+    d = rel_l2(outs[1][0][0], outs[1][0][1], outs[0][0][0], outs[0][0][1])
+    assert d < INVESTIGATE, f"fused vs two-pass: {d:.3e}"

@@ -13,6 +13,17 @@ import sys
 from collections import defaultdict
 
 
+def norm(short):
+    """Template instances and the fused flow update under one name each."""
+    if short.startswith("k_pcg_pass_a"):
+        return "k_pcg_pass_a"
+    if short.startswith("k_pcg_fused"):
+        return "k_pcg_fused"
+    if short.startswith("k_flow_update"):
+        return "k_flow_update"
+    return short
+
+
 def pmc_section(d, size, kiters, per_level, two_pass_levels):
     """HBM traffic of the finest level from the FETCH_SIZE / WRITE_SIZE passes (sub-directories fetch/ and
     write/ of the profile directory).  Units and the gfx950 correction follow MI355X_MICROARCH.md 'HBM':
@@ -30,12 +41,11 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
                 if "octane::" not in r["Kernel_Name"] or r["Counter_Name"] != cname:
                     continue
                 short = r["Kernel_Name"].split("octane::")[1].split("(")[0]
-                if short.startswith("k_pcg_pass_a"):
-                    short = "k_pcg_pass_a"
+                short = norm(short)
                 agg[short].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         if "k_assemble" in agg:      # placement-trial launches precede the first assembly
             d_first = min(d for d, _ in agg["k_assemble"])
-            for k in ("k_pcg_pass_a", "k_pcg_pass_b"):
+            for k in ("k_pcg_pass_a", "k_pcg_pass_b", "k_pcg_fused"):
                 if k in agg:
                     agg[k] = [x for x in agg[k] if x[0] > d_first]
         for k, n in per_level.items():
@@ -44,13 +54,18 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
             v = [x for _, x in sorted(agg[k])]
             nl = len(two_pass_levels[k])
             per_pyr = n * nl
+            if len(v) < per_pyr:
+                continue
             sel = []
             for p in range(len(v) // per_pyr):
                 sel += v[p * per_pyr + (nl - 1) * n:(p + 1) * per_pyr]
             vals[(k, cname)] = sum(sel) / len(sel)
     px = size * size
     # pass A reads 36 B/px, 28 in the first of the three GNC steps (wx / wy are the constant -1 there): mean 33.33
-    alg = {"k_pcg_pass_a": (100.0 / 3.0, 16), "k_pcg_pass_b": (40, 16), "k_assemble": (52, 36), "k_flow_update": (16, 8)}
+    # the fused iteration reads r q p x + five coefficient planes = 52 B/px (44 in the first GNC step), writes r p q x = 32;
+    # its flow update also reads the last p (the pending x update)
+    alg = {"k_pcg_pass_a": (100.0 / 3.0, 16), "k_pcg_pass_b": (40, 16), "k_pcg_fused": (148.0 / 3.0, 32), "k_assemble": (52, 36),
+           "k_flow_update": (24 if ("k_pcg_fused", "FETCH_SIZE") in vals else 16, 16 if ("k_pcg_fused", "FETCH_SIZE") in vals else 8)}
     out += ["", "## HBM traffic per launch at the finest level (rocprofv3 --pmc, separate passes)", "",
             "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE x1, both KiB -> bytes. Infinity-Cache hits are",
             "counted by these counters (they sit on the L2's fabric side), so this is L2<->fabric traffic, an upper",
@@ -58,7 +73,7 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
             "| kernel | read MB (FETCH_SIZE x 2) | algorithmic read MB | write MB (WRITE_SIZE) | algorithmic write MB | total / algorithmic |",
             "|---|---|---|---|---|---|"]
     traffic = {}
-    for k in ("k_pcg_pass_a", "k_pcg_pass_b", "k_assemble", "k_flow_update"):
+    for k in ("k_pcg_fused", "k_pcg_pass_a", "k_pcg_pass_b", "k_assemble", "k_flow_update"):
         if (k, "FETCH_SIZE") not in vals:
             continue
         rd = vals[(k, "FETCH_SIZE")] * 1024 * 2
@@ -89,18 +104,17 @@ def main():
             if "octane::" not in name:
                 continue
             short = name.split("octane::")[1].split("(")[0]
-            if short.startswith("k_pcg_pass_a"):
-                short = "k_pcg_pass_a"
+            short = norm(short)
             rows[short].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])))
             meta[short] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Workgroup_Size_X"])
     # the plan's placement trials (vof_plan.hip) launch a few PCG passes before the first pyramid: drop everything
     # that starts before the first assembly
     if "k_assemble" in rows:
         t_first = min(r[0] for r in rows["k_assemble"])
-        for k in ("k_pcg_pass_a", "k_pcg_pass_b"):
+        for k in ("k_pcg_pass_a", "k_pcg_pass_b", "k_pcg_fused"):
             if k in rows:
                 rows[k] = [r for r in rows[k] if r[0] > t_first]
-    per_level = {"k_pcg_pass_a": 3 * liters * cgiters, "k_pcg_pass_b": 3 * liters * cgiters,
+    per_level = {"k_pcg_fused": 3 * liters * cgiters, "k_pcg_pass_a": 3 * liters * cgiters, "k_pcg_pass_b": 3 * liters * cgiters,
                  "k_assemble": 3 * liters, "k_flow_update": 3 * liters}
     # levels of at most 6144 pixels are solved by k_pcg_solve_small (one launch per solve, flow update included)
     def lev_w(lev):
@@ -120,6 +134,8 @@ def main():
         levs = two_pass_levels[k]
         per_pyr = n_per_level * len(levs)
         npyr = len(v) // per_pyr
+        if npyr == 0:          # only the handful of launches of the plan's placement probe
+            continue
         for li, lev in enumerate(levs):
             sel = []
             for p in range(npyr):
@@ -136,16 +152,24 @@ def main():
             continue
         durs = [s[1] for s in v]
         lines.append(f"| {k} | {len(durs)} | {sum(durs) / len(durs) / 1e3:.2f} | {sum(durs) / 1e6:.3f} |")
-    fin = {k: None for k in ("k_pcg_pass_a", "k_pcg_pass_b")}
+    fin = {k: None for k in ("k_pcg_fused", "k_pcg_pass_a", "k_pcg_pass_b")}
     for k in fin:
-        if k in rows:
+        if k in rows and len(rows[k]) >= per_level[k] * len(two_pass_levels[k]):
             v = sorted(rows[k]); n = per_level[k]; nl = len(two_pass_levels[k]); per_pyr = n * nl; npyr = len(v) // per_pyr
             d_ = []
             for p in range(npyr):
                 d_ += [s[1] for s in v[p * per_pyr + (nl - 1) * n: (p + 1) * per_pyr]]
             fin[k] = sum(d_) / len(d_)
-    if all(fin.values()):
-        px = size * size
+    px = size * size
+    if fin["k_pcg_fused"]:
+        f_ns = fin["k_pcg_fused"]
+        lines += ["", "## Finest level against the HBM roofline (algorithmic bytes, DESIGN.md)", "",
+                  f"* fused PCG iteration: 81.33 B/px (84; 76 in the first GNC step, a third of the launches) x {px} px = "
+                  f"{244 / 3 * px / 1e9:.3f} GB per launch / {f_ns / 1e3:.1f} us = **{244 / 3 * px / f_ns:.0f} GB/s** "
+                  f"({244 / 3 * px / f_ns / 80:.1f} % of 8 TB/s)",
+                  f"* the same iteration at SURVEY 8(d)'s 116 B/px (pass A + pass B with seven coefficient planes): "
+                  f"{116 * px / f_ns:.0f} GB/s ({116 * px / f_ns / 80:.1f} % of 8 TB/s)"]
+    elif fin["k_pcg_pass_a"] and fin["k_pcg_pass_b"]:
         lines += ["", "## Finest level against the HBM roofline (algorithmic bytes, DESIGN.md)", "",
                   f"* pass A: 49.33 B/px (52; 44 in the first GNC step, a third of the launches) x {px} px = {148 / 3 * px / 1e9:.3f} GB "
                   f"per launch / {fin['k_pcg_pass_a'] / 1e3:.1f} us = **{148 / 3 * px / fin['k_pcg_pass_a']:.0f} GB/s** "
