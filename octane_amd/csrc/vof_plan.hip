@@ -140,7 +140,16 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
     LevelPtrs L;
     fill_level_ptrs(pl, li, 0, pl->img1p, pl->img2p, pl->uh, pl->vh, L);
     const int g_a = pcg_grid_size(li.w, li.h), g_b = pcg_b_grid_size(li.w, li.h);
-    std::vector<double> ones(2 * kMaxParts, 1.0);
+    const int g_f = pcg_fused_grid_size(li.w, li.h, 0);
+    const bool fused = pl->use_fused && !(a_ms && b_ms);      // the split timing is defined for the two-pass form only
+    // sums that keep the stop test open and every scalar finite whatever the planes hold: with all seven sums equal
+    // to 1 the fused kernel's recurrences give alpha = 1, r.z = 0, r.r = 0 + ... -> use values that stay positive
+    std::vector<double> ones(2 * (size_t)kPartBlock, 0.0);
+    for (int half = 0; half < 2; half++) {
+        double *blk = ones.data() + (size_t)half * kPartBlock;
+        blk[kPartRz] = 4.0; blk[kPartRr] = 4.0; blk[kPartPq] = 1.0; blk[kPartQz] = 1.0; blk[kPartQmq] = 1.0; blk[kPartRq] = 1.0; blk[kPartQq] = 1.0;
+    }
+    if (!fused) for (size_t i = 0; i < 2 * (size_t)kMaxParts; i++) ones[i] = 1.0;
     PcgState st[2];
     st[0].rz = 1.f; st[0].stopped = 0; st[0].iters = 0; st[0].pad = 0;
     st[1] = st[0];
@@ -158,8 +167,12 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
     for (int it = 1; it <= reps && ok; it++) {     // it = 1 is a warm-up
         if (it == 2) ok = hipEventRecord(e0, s) == hipSuccess;
         // keep the stop test open whatever the previous pass wrote
-        ok = ok && hipMemcpyAsync(pl->d_parts, ones.data(), 2 * kMaxParts * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(pl->d_parts, ones.data(), (fused ? 2 * (size_t)kPartBlock : 2 * (size_t)kMaxParts) * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
         ok = ok && hipMemcpyAsync(pl->d_state, st, sizeof(st), hipMemcpyHostToDevice, s) == hipSuccess;
+        if (fused) {       // the kernel the solve actually runs: one block of partials -> rz = 4 - 2 + 1 > 0, rr likewise
+            launch_pcg_fused(s, L, it + 1, 1, g_f, 0.f);
+            continue;
+        }
         if (split) ok = ok && hipEventRecord(ev[3 * (it - 1)], s) == hipSuccess;
         launch_pcg_pass_a(s, L, it, g_b, g_a, 0.f);
         if (split) ok = ok && hipEventRecord(ev[3 * (it - 1) + 1], s) == hipSuccess;
