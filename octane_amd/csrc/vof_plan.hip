@@ -202,7 +202,7 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
 
 extern "C" int octane_vof_plan_create(octane_vof_plan **out, int nx, int ny, int nchan, const octane_vof_params *p)
 {
-    return octane::plan_create_ex(out, nx, ny, nchan, p, 4);
+    return octane::plan_create_ex(out, nx, ny, nchan, p, 8);
 }
 
 int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, const octane_vof_params *p, int placement_trials)
@@ -341,16 +341,23 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         octane_vof_plan_destroy(pl);
         return rc;
     }
-    // Placement trials.  Where the arena lands in physical memory decides how the 13 concurrent streams of a PCG
-    // pass spread over the HBM channels: the same binary runs pass A at 245 or 264 us at 5000^2 depending on the
-    // allocation alone.  For large frames a few candidate arenas are therefore allocated, a short
-    // pass A / pass B sequence is timed on each, the fastest is kept and the others are freed.
+    // Placement trials.  Where the arena lands in physical memory decides how the concurrent streams of a PCG kernel
+    // spread over the HBM channels: arenas come in two kinds, 0.41 or 0.45-0.46 ms per fused iteration at 5000^2, and
+    // consecutive allocations of one process tend to be of the same kind.  For large frames up to eight
+    // candidate arenas are therefore allocated, a few PCG iterations are timed on each, the fastest is kept and the
+    // others are freed.
     int trials = placement_trials;
     if (const char *e = getenv("OCTANE_TUNE_PLACEMENT_TRIALS")) trials = atoi(e) < trials ? atoi(e) : trials;
-    if (trials > 4) trials = 4;
-    if (trials > 1 && (long)nx * ny >= (1L << 22) && pl->arena_bytes < ((size_t)24 << 30)) {
-        float *cand[4] = {pl->arena, nullptr, nullptr, nullptr};
-        double ms[4] = {0, 0, 0, 0};
+    constexpr int kMaxTrials = 8;
+    if (const char *e = getenv("OCTANE_TUNE_PLACEMENT_TRIALS_FORCE")) trials = atoi(e);       // experiments: more than the caller's default
+    if (trials > kMaxTrials) trials = kMaxTrials;
+    {   // the candidates exist side by side while they are timed: keep that within 48 GB
+        const long fit = (long)(((size_t)48 << 30) / pl->arena_bytes);
+        if (trials > fit) trials = (int)fit;
+    }
+    if (trials > 1 && (long)nx * ny >= (1L << 22)) {
+        float *cand[kMaxTrials] = {pl->arena};
+        double ms[kMaxTrials] = {0};
         int ncand = 1;
         for (int t = 1; t < trials; t++) {
             if (hipMalloc((void **)&cand[t], pl->arena_bytes) != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
@@ -362,8 +369,11 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
             ms[t] = probe_placement(pl);
             if (ms[t] > 0 && (ms[best] <= 0 || ms[t] < ms[best])) best = t;
         }
-        if (getenv("OCTANE_TUNE_VERBOSE"))
-            fprintf(stderr, "[octane] placement trials: %.4f %.4f %.4f %.4f ms per PCG iteration -> candidate %d\n", ms[0], ms[1], ms[2], ms[3], best);
+        if (getenv("OCTANE_TUNE_VERBOSE")) {
+            fprintf(stderr, "[octane] placement trials, ms per PCG iteration:");
+            for (int t = 0; t < ncand; t++) fprintf(stderr, " %.4f", ms[t]);
+            fprintf(stderr, " -> candidate %d\n", best);
+        }
         for (int t = 0; t < ncand; t++)
             if (t != best) (void)hipFree(cand[t]);
         pl->arena = cand[best];

@@ -149,7 +149,7 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
         // placement trials only when the band has its device to itself (they allocate four arenas)
         int sharing = 0;
         for (int c = 0; c < nbands; c++) sharing += (t->dev[c] == t->dev[b]);
-        rc = plan_create_ex(&t->pl[b], nx, ny, nchan, &pb, sharing > 1 ? 1 : 4);
+        rc = plan_create_ex(&t->pl[b], nx, ny, nchan, &pb, sharing > 1 ? 1 : 8);
         if (rc != OCTANE_OK) break;
         if (hipSetDevice(t->dev[b]) != hipSuccess ||
             hipMalloc((void **)&t->parts[b], (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
