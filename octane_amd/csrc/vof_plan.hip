@@ -371,7 +371,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         }
         if (getenv("OCTANE_TUNE_VERBOSE")) {
             fprintf(stderr, "[octane] placement trials, ms per PCG iteration:");
-            for (int t = 0; t < ncand; t++) fprintf(stderr, " %.4f", ms[t]);
+            for (int t = 0; t < ncand; t++) fprintf(stderr, " %.4f@%p", ms[t], (void *)cand[t]);
             fprintf(stderr, " -> candidate %d\n", best);
         }
         for (int t = 0; t < ncand; t++)
