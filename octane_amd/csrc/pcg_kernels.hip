@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256) void k_flow_update_fused(LevelPtrs L, int nlau
             const float4 pu = ld4(ppu + o), pv = ld4(ppv + o);
             dx.x = apend * pu.x + dx.x; dx.y = apend * pu.y + dx.y; dx.z = apend * pu.z + dx.z; dx.w = apend * pu.w + dx.w;
             dy.x = apend * pv.x + dy.x; dy.y = apend * pv.y + dy.y; dy.z = apend * pv.z + dy.z; dy.w = apend * pv.w + dy.w;
-            st4(L.xu + o, dx); st4(L.xv + o, dy);          // keep x complete for the debug tap
+            if (!L.lean) { st4(L.xu + o, dx); st4(L.xv + o, dy); }     // keep x complete for the debug tap
         }
         u.x = u.x + dx.x; u.y = u.y + dx.y; u.z = u.z + dx.z; u.w = u.w + dx.w;
         v.x = v.x + dy.x; v.y = v.y + dy.y; v.z = v.z + dy.z; v.w = v.w + dy.w;

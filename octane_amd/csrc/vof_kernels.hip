@@ -333,12 +333,13 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
         float bv = (float)(al1 * ((double)t6 / alpha + loa * (double)g6 - (double)hint_v + (double)snvq - (double)(pstotq * vc))
                            + (1 - al1) * (double)(pd * t6 + pd2 * g6 - hint_v + snv - pstot * vc));
         const size_t o = rc + ii;
-        L.a1[o] = a1; L.a2[o] = a2; L.a4[o] = a4; L.wx[o] = a7; L.wy[o] = a8;
+        L.a1[o] = a1; L.a2[o] = a2; L.a4[o] = a4;
+        if (!(L.lean && L.unit_w)) { L.wx[o] = a7; L.wy[o] = a8; }     // exactly -1 in the first GNC step: nobody reads them then
         L.ru[o] = bu; L.rv[o] = bv;
-        // Jacobi preconditioner, M <- 1./M in double (ref .cu:141-149); stored so that the
-        // streaming PCG pass never divides
+        // Jacobi preconditioner, M <- 1./M in double (ref .cu:141-149); stored for the two-pass form's pass B and the
+        // single-workgroup solver (the fused kernel divides instead)
         const float mu = jacobi_inv(a1), mv = jacobi_inv(a4);
-        L.mu[o] = mu; L.mv[o] = mv;
+        if (!L.lean) { L.mu[o] = mu; L.mv[o] = mv; }
         // r.r and r.z of the initial residual (ref .cu:1115-1126, 1157): z = M r
         float zu = mu * bu;
         float zv = mv * bv;

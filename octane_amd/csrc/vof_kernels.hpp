@@ -75,6 +75,8 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     int nt_hints;                   // bit mask of streaming-load/store hints (tuning)
     int xcd_bands;                  // give each XCD (blockIdx % 8) one contiguous band of the frame
     int unit_w;                     // this linearisation has al1 == 1: wx == wy == -1 everywhere, pass A need not read them
+    int lean;                       // the fused kernels are the only readers: the assembly skips the planes they never read
+                                    // (mu, mv; wx, wy while unit_w) and the flow update does not write x back
 };
 
 struct AssembleParams {

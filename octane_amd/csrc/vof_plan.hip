@@ -115,6 +115,7 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
     L.xcd_bands = pl->xcd_bands;
     L.nt_hints = pl->nt_hints;
     L.unit_w = 0;
+    L.lean = 0;
 }
 
 void octane::plan_fill_level_ptrs(octane_vof_plan *pl, int k, int cur, const LevelCtx &c, LevelPtrs &L)
@@ -525,6 +526,7 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
         ap.lambdac = li.lambdac;
         ap.dozim = prm.dozim != 0;
         L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;   // al1 == 1: all neighbour weights are exactly -1
+        L.lean = (pl->use_fused && !small && !pl->trace) ? 1 : 0;
         const int g_a = L.unit_w ? g_a_unit : g_a_plain;
         const int g_f = L.unit_w ? g_f_unit : g_f_plain;
         for (int l = 0; l < prm.liters; l++) {          // ref .cu:608

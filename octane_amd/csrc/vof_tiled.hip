@@ -325,6 +325,7 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
         ap.lambdac = li.lambdac;
         ap.dozim = prm.dozim != 0;
         L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;
+        L.lean = fused ? 1 : 0;
         const int g_f = pcg_fused_grid_size(li.w, maxrows, L.unit_w);
         for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
             if (!N.failed()) {
