@@ -11,7 +11,7 @@ time.
 
 The JSON line also carries
   roofline      -- dominant kernel (the fused PCG iteration at the finest level): algorithmic bytes per launch
-                   (84 B/pixel, 76 in the first GNC step; DESIGN.md) / its mean duration from HIP events on the launch stream;
+                   (80 B/pixel, 72 in the first GNC step; DESIGN.md) / its mean duration from HIP events on the launch stream;
   cpu_baseline  -- the CPU oracle ("port", OpenMP over the host cores) timed on a bounded sample (rank 0, N=1 only).
 """
 import argparse
@@ -26,8 +26,10 @@ sys.path.insert(0, ROOT)
 PASS_A_BYTES_PER_PIXEL = 36 + 16   # reads r(2) p(2) a1 a2 a4 wx wy, writes p(2) q(2)  -- DESIGN.md
 PASS_A_BYTES_PER_PIXEL_GNC0 = 28 + 16   # first GNC step (a third of the launches): wx == wy == -1, the planes are not read
 PASS_B_BYTES_PER_PIXEL = 40 + 16   # reads x(2) r(2) p(2) q(2) a1 a4, writes x(2) r(2)
-FUSED_BYTES_PER_PIXEL = 52 + 32    # one fused kernel per iteration: reads r q p x (32) a1 a2 a4 wx wy (20), writes r p q x (32)
-FUSED_BYTES_PER_PIXEL_GNC0 = 44 + 32   # first GNC step: wx == wy == -1, not read
+# one fused kernel per iteration: reads r q p (24) + a1 a2 a4 wx wy (20), writes r p q (24) = 68 B/pixel; x is updated by every second
+# launch only, which then also reads x and the p before last (16) and writes x (8): 92.  Mean 80 (84 with OCTANE_TUNE_DEFER_X=0).
+FUSED_BYTES_PER_PIXEL = 80
+FUSED_BYTES_PER_PIXEL_GNC0 = 72        # first GNC step: wx == wy == -1, not read
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -283,8 +285,9 @@ def main():
         unit_w = os.environ.get("OCTANE_TUNE_UNIT_W", "1") != "0"
         fused = pr.pass_b_launches == 0          # one kernel per PCG iteration (the default); its launches are timed as "pass A"
         if fused:
-            # mean algorithmic bytes of a finest-level launch: 84 B/px, 76 in the first of the three GNC steps
-            bpp = (FUSED_BYTES_PER_PIXEL_GNC0 + 2 * FUSED_BYTES_PER_PIXEL) / 3.0 if unit_w else FUSED_BYTES_PER_PIXEL
+            # mean algorithmic bytes of a finest-level launch: 80 B/px, 72 in the first of the three GNC steps
+            imm = 4 if os.environ.get("OCTANE_TUNE_DEFER_X", "1") == "0" else 0     # immediate x updates move 4 B/px more on average
+            bpp = ((FUSED_BYTES_PER_PIXEL_GNC0 + 2 * FUSED_BYTES_PER_PIXEL) / 3.0 if unit_w else FUSED_BYTES_PER_PIXEL) + imm
             dom, dms = "k_pcg_fused", a_ms
             iter_ms = a_ms
         else:
@@ -311,7 +314,7 @@ def main():
                 "avg_launch_ms": round(dms, 4), "bytes_per_launch": int(round(bpp * n * n)),
                 "pcg_iteration_ms": round(iter_ms, 4),
                 # one whole PCG iteration on SURVEY 8(d)'s accounting (116 B/px: pass A with seven coefficient planes + pass B).
-                # This implementation moves 84 (fused kernel, five planes) -- the figure above counts those, the stricter one.
+                # This implementation moves 80 (fused kernel, five planes, x every second launch) -- the figure above counts those, the stricter one.
                 "pcg_iteration_gbs_at_116B_per_pixel": round(iter_gbs, 1),
                 "frac_at_survey_bytes": round(survey_bpp * n * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "assemble_ms": round(pr.assemble_ms / max(1, pr.assemble_launches), 4),

@@ -739,10 +739,21 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
     const float *__restrict__ qin_v = L.qb_v[ko];
     float *__restrict__ qout_u = L.qb_u[kn];
     float *__restrict__ qout_v = L.qb_v[kn];
-    const float *__restrict__ pin_u = L.pu[ko];
-    const float *__restrict__ pin_v = L.pv[ko];
-    float *__restrict__ pout_u = L.pu[kn];
-    float *__restrict__ pout_v = L.pv[kn];
+    const float *__restrict__ pin_u = L.pf_u[(k + 2) % 3];          // p_{k-1}
+    const float *__restrict__ pin_v = L.pf_v[(k + 2) % 3];
+    const float *__restrict__ pin2_u = L.pf_u[(k + 1) % 3];         // p_{k-2}
+    const float *__restrict__ pin2_v = L.pf_v[(k + 1) % 3];
+    float *__restrict__ pout_u = L.pf_u[k % 3];
+    float *__restrict__ pout_v = L.pf_v[k % 3];
+    // x handling.  Immediate: x += alpha_{k-1} p_{k-1} in every launch.  Deferred (default): odd launches leave their update
+    // pending and even launches apply two in the reference's order, x <- alpha_{k-1} p_{k-1} + (alpha_{k-2} p_{k-2} + x),
+    // reading p_{k-2} from the third p buffer: same operations, same roundings, but x moves every second launch only
+    // (12 instead of 16 B/pixel/iteration).  A launch that ends the loop applies whatever is pending.
+    const bool defer = L.defer_x != 0;
+    const bool x_two = defer && !first && (k & 1) == 0;               // k >= 2, even: two updates
+    const bool x_one = !first && (!defer || ((k & 1) == 1 && !active));   // one update: immediate mode, or an odd launch that stops
+    const bool x_read = x_two ? (k > 2) : (defer ? (k >= 3) : (k > 1));  // x holds something already
+    const float alpha2 = x_two ? L.alpha[(k - 2) & 1] : 0.f;          // alpha_{k-2}, stored by the previous launch
     double acc_pq = 0., acc_qz = 0., acc_qmq = 0., acc_rq = 0., acc_qq = 0., acc_rz = 0., acc_rr = 0.;
 
     const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
@@ -779,19 +790,31 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
                 }
                 float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
                 if (!first) {
-                    float qu[4], qv[4], xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0};
+                    float qu[4], qv[4];
                     *(float4 *)pu = ld4(pin_u + o); *(float4 *)pv = ld4(pin_v + o);
                     *(float4 *)qu = ld4(qin_u + o); *(float4 *)qv = ld4(qin_v + o);
-                    if (k > 1) { *(float4 *)xu = ld4_if(L.xu + o, L.nt_hints & 1); *(float4 *)xv = ld4_if(L.xv + o, L.nt_hints & 1); }
+                    if (x_two || x_one) {
+                        float xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0};
+                        if (x_read) { *(float4 *)xu = ld4_if(L.xu + o, L.nt_hints & 1); *(float4 *)xv = ld4_if(L.xv + o, L.nt_hints & 1); }
+                        if (x_two) {                               // the previous launch's update first
+                            float ou[4], ov[4];
+                            *(float4 *)ou = ld4(pin2_u + o); *(float4 *)ov = ld4(pin2_v + o);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { xu[e] = alpha2 * ou[e] + xu[e]; xv[e] = alpha2 * ov[e] + xv[e]; }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            xu[e] = alpha * pu[e] + xu[e];         // jVecPVec(p0,x0,x0,alphak), ref .cu:1172
+                            xv[e] = alpha * pv[e] + xv[e];
+                        }
+                        st4_if(L.xu + o, *(float4 *)xu, L.nt_hints & 1);
+                        st4_if(L.xv + o, *(float4 *)xv, L.nt_hints & 1);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        xu[e] = alpha * pu[e] + xu[e];             // jVecPVec(p0,x0,x0,alphak), ref .cu:1172
-                        xv[e] = alpha * pv[e] + xv[e];
                         ru[e] = nalpha * qu[e] + ru[e];            // jVecPVec(dummyvec,bcu,rk,-alphak), ref .cu:1174
                         rv[e] = nalpha * qv[e] + rv[e];
                     }
-                    st4_if(L.xu + o, *(float4 *)xu, L.nt_hints & 1);
-                    st4_if(L.xv + o, *(float4 *)xv, L.nt_hints & 1);
                     if (active) { st4(rout_u + o, *(float4 *)ru); st4(rout_v + o, *(float4 *)rv); }
                 }
 #pragma unroll
@@ -934,17 +957,27 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
 __global__ __launch_bounds__(256) void k_flow_update_fused(LevelPtrs L, int nlaunched, int nparts)
 {
     __shared__ double s_red[8];
-    const PcgState st = L.st[nlaunched & 1];
+    const int K = nlaunched;
+    const PcgState st = L.st[K & 1];
     if (blockIdx.x == 0 && threadIdx.x == 0) *L.iter_total += st.iters;
     const int n = st.iters;
     if (n == 0) return;
-    const bool pending = (st.stopped == 0);              // every launch ran an iteration: the last x update is outstanding
-    float apend = 0.f;
-    if (pending)
-        apend = st.rz / (float)fold_band_partials_256(L.band_parts, ((nlaunched - 1) & 1) * kPartBlock + kPartPq, nparts, L.nbands, s_red);
-    const bool have_x = pending ? (n >= 2) : true;
-    const float *__restrict__ ppu = L.pu[(nlaunched - 1) & 1];
-    const float *__restrict__ ppv = L.pv[(nlaunched - 1) & 1];
+    // A solve that met the tolerance has a complete x (the launch that ended the loop applied what was pending).  One that
+    // ran into its iteration cap (all K launches ran an iteration) still owes alpha_{K-1} p_{K-1}, and with deferred x
+    // updates also alpha_{K-2} p_{K-2} when the last launch was an odd one.
+    const bool capped = (st.stopped == 0);
+    const bool defer = L.defer_x != 0;
+    const bool owe2 = capped && defer && K >= 2 && ((K - 1) & 1) == 1;
+    bool have_x = true;
+    if (capped) have_x = defer ? (owe2 ? (K >= 4) : (K >= 3)) : (K >= 2);
+    float a1 = 0.f, a2 = 0.f;
+    if (capped)
+        a1 = st.rz / (float)fold_band_partials_256(L.band_parts, ((K - 1) & 1) * kPartBlock + kPartPq, nparts, L.nbands, s_red);
+    if (owe2) a2 = L.alpha[(K - 2) & 1];
+    const float *__restrict__ p1u = L.pf_u[(K + 2) % 3];            // p_{K-1}
+    const float *__restrict__ p1v = L.pf_v[(K + 2) % 3];
+    const float *__restrict__ p2u = L.pf_u[(K + 1) % 3];            // p_{K-2}
+    const float *__restrict__ p2v = L.pf_v[(K + 1) % 3];
     const int w = L.w, pitch = L.pitch;
     const int gw = (w + 3) / 4;
     const long ngroups = (long)gw * (L.y1 - L.y0);
@@ -953,10 +986,15 @@ __global__ __launch_bounds__(256) void k_flow_update_fused(LevelPtrs L, int nlau
         const size_t o = (size_t)(L.y0 + y) * pitch + x;
         float4 u = ld4(L.u + o), v = ld4(L.v + o), dx = make_float4(0, 0, 0, 0), dy = dx;
         if (have_x) { dx = ld4(L.xu + o); dy = ld4(L.xv + o); }
-        if (pending) {
-            const float4 pu = ld4(ppu + o), pv = ld4(ppv + o);
-            dx.x = apend * pu.x + dx.x; dx.y = apend * pu.y + dx.y; dx.z = apend * pu.z + dx.z; dx.w = apend * pu.w + dx.w;
-            dy.x = apend * pv.x + dy.x; dy.y = apend * pv.y + dy.y; dy.z = apend * pv.z + dy.z; dy.w = apend * pv.w + dy.w;
+        if (owe2) {
+            const float4 pu = ld4(p2u + o), pv = ld4(p2v + o);
+            dx.x = a2 * pu.x + dx.x; dx.y = a2 * pu.y + dx.y; dx.z = a2 * pu.z + dx.z; dx.w = a2 * pu.w + dx.w;
+            dy.x = a2 * pv.x + dy.x; dy.y = a2 * pv.y + dy.y; dy.z = a2 * pv.z + dy.z; dy.w = a2 * pv.w + dy.w;
+        }
+        if (capped) {
+            const float4 pu = ld4(p1u + o), pv = ld4(p1v + o);
+            dx.x = a1 * pu.x + dx.x; dx.y = a1 * pu.y + dx.y; dx.z = a1 * pu.z + dx.z; dx.w = a1 * pu.w + dx.w;
+            dy.x = a1 * pv.x + dy.x; dy.y = a1 * pv.y + dy.y; dy.z = a1 * pv.z + dy.z; dy.w = a1 * pv.w + dy.w;
             if (!L.lean) { st4(L.xu + o, dx); st4(L.xv + o, dy); }     // keep x complete for the debug tap
         }
         u.x = u.x + dx.x; u.y = u.y + dx.y; u.z = u.z + dx.z; u.w = u.w + dx.w;

@@ -57,6 +57,8 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     // the old values of its neighbours' pixels while those workgroups write the new ones.  r_k is in rb[k & 1] (r_0 =
     // the rhs, written by the assembly into rb[0] == ru/rv), q_k in qb[k & 1].
     float *rb_u[2], *rb_v[2], *qb_u[2], *qb_v[2];
+    float *pf_u[3], *pf_v[3];       // p of the fused kernel: p_k in pf[k % 3]; three halves because with defer_x every second
+                                    // launch applies two x updates at once and reads p_{k-2} besides p_{k-1}
     const float *qup_u[2], *qup_v[2], *qdn_u[2], *qdn_v[2];   // the q planes rows y0-1 / y1 are read from (neighbouring bands)
     // Row band of the level this launch works on (vof_tiled.hip); a plain plan has one band covering the frame.
     // Planes are always addressed with frame coordinates: a band's neighbours' rows exist in its planes as halos.

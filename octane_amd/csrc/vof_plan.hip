@@ -109,6 +109,8 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
     L.rb_u[0] = pl->ru; L.rb_v[0] = pl->rv; L.rb_u[1] = pl->ru2; L.rb_v[1] = pl->rv2;
     L.qb_u[0] = pl->qu; L.qb_v[0] = pl->qv; L.qb_u[1] = pl->qu2; L.qb_v[1] = pl->qv2;
     for (int i = 0; i < 2; i++) { L.qup_u[i] = L.qdn_u[i] = L.qb_u[i]; L.qup_v[i] = L.qdn_v[i] = L.qb_v[i]; }
+    L.pf_u[0] = pl->pu[0]; L.pf_u[1] = pl->pu[1]; L.pf_u[2] = pl->pu3;
+    L.pf_v[0] = pl->pv[0]; L.pf_v[1] = pl->pv[1]; L.pf_v[2] = pl->pv3;
     L.y0 = 0; L.y1 = li.h; L.ya0 = 0; L.ya1 = li.h; L.nbands = 1;
     L.st = pl->d_state; L.iter_total = pl->d_iters; L.alpha = pl->d_alpha; L.defer_x = pl->defer_x;
     L.reverse_b = pl->reverse_b;
@@ -274,7 +276,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     }
 
     const int nc = nchan;
-    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 17 + 1 + 4;
+    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 17 + 1 + 6;
     size_t skew = 0;                              // developer knob: stagger the planes' base addresses (floats)
     if (const char *e = getenv("OCTANE_TUNE_SKEW")) skew = (size_t)atol(e) / 64 * 64;
     size_t align_f = 0;                           // developer knob: round the plane stride up to a multiple (bytes)
@@ -317,6 +319,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         pl->qu = take(1); pl->qv = take(1); pl->xu = take(1); pl->xv = take(1);
         pl->tmp = take(1);
         pl->ru2 = take(1); pl->rv2 = take(1); pl->qu2 = take(1); pl->qv2 = take(1);
+        pl->pu3 = take(1); pl->pv3 = take(1);
     };
     carve(pl->arena);
 

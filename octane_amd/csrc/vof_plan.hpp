@@ -33,6 +33,7 @@ struct octane_vof_plan {
     float *U[2], *V[2], *ut, *vt;
     float *a1, *a2, *a4, *wx, *wy, *mu, *mv, *ru, *rv, *pu[2], *pv[2], *qu, *qv, *xu, *xv, *tmp;
     float *ru2, *rv2, *qu2, *qv2;  // second halves of the r / q double buffers of the fused PCG kernel
+    float *pu3, *pv3;              // third p buffer of the fused kernel (deferred x update)
     float *d_taps = nullptr;
     double *d_parts = nullptr;     // 2 * kPartBlock
     octane::PcgState *d_state = nullptr;   // 2

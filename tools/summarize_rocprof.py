@@ -62,9 +62,10 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
             vals[(k, cname)] = sum(sel) / len(sel)
     px = size * size
     # pass A reads 36 B/px, 28 in the first of the three GNC steps (wx / wy are the constant -1 there): mean 33.33
-    # the fused iteration reads r q p x + five coefficient planes = 52 B/px (44 in the first GNC step), writes r p q x = 32;
+    # the fused iteration reads r q p + five coefficient planes = 44 B/px (36 in the first GNC step) and, every second launch,
+    # x and the p before last (16): mean 52 - 8/3; it writes r p q = 24 and x every second launch (8): mean 28;
     # its flow update also reads the last p (the pending x update)
-    alg = {"k_pcg_pass_a": (100.0 / 3.0, 16), "k_pcg_pass_b": (40, 16), "k_pcg_fused": (148.0 / 3.0, 32), "k_assemble": (52, 36),
+    alg = {"k_pcg_pass_a": (100.0 / 3.0, 16), "k_pcg_pass_b": (40, 16), "k_pcg_fused": (52 - 8.0 / 3.0, 28), "k_assemble": (52, 36),
            "k_flow_update": (24 if ("k_pcg_fused", "FETCH_SIZE") in vals else 16, 16 if ("k_pcg_fused", "FETCH_SIZE") in vals else 8)}
     out += ["", "## HBM traffic per launch at the finest level (rocprofv3 --pmc, separate passes)", "",
             "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE x1, both KiB -> bytes. Infinity-Cache hits are",
@@ -164,9 +165,9 @@ def main():
     if fin["k_pcg_fused"]:
         f_ns = fin["k_pcg_fused"]
         lines += ["", "## Finest level against the HBM roofline (algorithmic bytes, DESIGN.md)", "",
-                  f"* fused PCG iteration: 81.33 B/px (84; 76 in the first GNC step, a third of the launches) x {px} px = "
-                  f"{244 / 3 * px / 1e9:.3f} GB per launch / {f_ns / 1e3:.1f} us = **{244 / 3 * px / f_ns:.0f} GB/s** "
-                  f"({244 / 3 * px / f_ns / 80:.1f} % of 8 TB/s)",
+                  f"* fused PCG iteration: 77.33 B/px (80 on average over odd / even launches: 68 / 92; 72 in the first GNC step, a "
+                  f"third of the launches) x {px} px = {232 / 3 * px / 1e9:.3f} GB per launch / {f_ns / 1e3:.1f} us = "
+                  f"**{232 / 3 * px / f_ns:.0f} GB/s** ({232 / 3 * px / f_ns / 80:.1f} % of 8 TB/s)",
                   f"* the same iteration at SURVEY 8(d)'s 116 B/px (pass A + pass B with seven coefficient planes): "
                   f"{116 * px / f_ns:.0f} GB/s ({116 * px / f_ns / 80:.1f} % of 8 TB/s)"]
     elif fin["k_pcg_pass_a"] and fin["k_pcg_pass_b"]:
