@@ -30,6 +30,8 @@ PASS_B_BYTES_PER_PIXEL = 40 + 16   # reads x(2) r(2) p(2) q(2) a1 a4, writes x(2
 # launch only, which then also reads x and the p before last (16) and writes x (8): 92.  Mean 80 (84 with OCTANE_TUNE_DEFER_X=0).
 FUSED_BYTES_PER_PIXEL = 80
 FUSED_BYTES_PER_PIXEL_GNC0 = 72        # first GNC step: wx == wy == -1, not read
+FUSED_Q_BYTES_PER_PIXEL = 64           # k_pcg_fused_q (levels of >= 2^22 pixels): q = A p is formed again, neither written nor read
+FUSED_Q_BYTES_PER_PIXEL_GNC0 = 56
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -287,8 +289,11 @@ def main():
         if fused:
             # mean algorithmic bytes of a finest-level launch: 80 B/px, 72 in the first of the three GNC steps
             imm = 4 if os.environ.get("OCTANE_TUNE_DEFER_X", "1") == "0" else 0     # immediate x updates move 4 B/px more on average
-            bpp = ((FUSED_BYTES_PER_PIXEL_GNC0 + 2 * FUSED_BYTES_PER_PIXEL) / 3.0 if unit_w else FUSED_BYTES_PER_PIXEL) + imm
-            dom, dms = "k_pcg_fused", a_ms
+            qform = os.environ.get("OCTANE_TUNE_FUSED_Q", "1") != "0" and n * n >= (1 << 22)
+            b_all, b_gnc0 = ((FUSED_Q_BYTES_PER_PIXEL, FUSED_Q_BYTES_PER_PIXEL_GNC0) if qform
+                             else (FUSED_BYTES_PER_PIXEL, FUSED_BYTES_PER_PIXEL_GNC0))
+            bpp = ((b_gnc0 + 2 * b_all) / 3.0 if unit_w else b_all) + imm
+            dom, dms = ("k_pcg_fused_q" if qform else "k_pcg_fused"), a_ms
             iter_ms = a_ms
         else:
             bpp_a = (PASS_A_BYTES_PER_PIXEL_GNC0 + 2 * PASS_A_BYTES_PER_PIXEL) / 3.0 if unit_w else PASS_A_BYTES_PER_PIXEL
@@ -302,8 +307,9 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get(dom, {}).get("size") == n:
-                traffic = tj[dom]["read_bytes"] + tj[dom]["write_bytes"]
+            tk = "k_pcg_fused" if fused else dom          # the summariser files every fused instance under one name
+            if tj.get(tk, {}).get("size") == n and tj[tk].get("kernel", dom) == dom:
+                traffic = tj[tk]["read_bytes"] + tj[tk]["write_bytes"]
         except (OSError, ValueError):
             pass
         achieved = bpp * n * n / (dms * 1e-3) / 1e9
@@ -314,7 +320,8 @@ def main():
                 "avg_launch_ms": round(dms, 4), "bytes_per_launch": int(round(bpp * n * n)),
                 "pcg_iteration_ms": round(iter_ms, 4),
                 # one whole PCG iteration on SURVEY 8(d)'s accounting (116 B/px: pass A with seven coefficient planes + pass B).
-                # This implementation moves 80 (fused kernel, five planes, x every second launch) -- the figure above counts those, the stricter one.
+                # This implementation moves 64 (fused kernel, five planes, x every second launch, q formed twice instead of stored;
+                # 80 with OCTANE_TUNE_FUSED_Q=0) -- the figure above counts those, the stricter one.
                 "pcg_iteration_gbs_at_116B_per_pixel": round(iter_gbs, 1),
                 "frac_at_survey_bytes": round(survey_bpp * n * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "assemble_ms": round(pr.assemble_ms / max(1, pr.assemble_launches), 4),

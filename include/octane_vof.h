@@ -112,11 +112,13 @@ typedef struct octane_vof_profile {
 } octane_vof_profile;
 int octane_vof_plan_set_profiling(octane_vof_plan *plan, int enable);
 int octane_vof_plan_get_profile(octane_vof_plan *plan, octane_vof_profile *out);
-/* Diagnostic: time `iterations` (>= 2) PCG iterations of pyramid level `level` (0 = coarsest) in isolation, on
- * whatever the plan's planes hold (the stop test is held open, values are irrelevant, the planes are clobbered). */
 /* Developer knob (what the OCTANE_TUNE_* environment variables set): key in {pass_a, max_blocks, reverse_b, xcd, nt,
- * defer_x, small}.  Results are the same for every setting; only speed changes. */
+ * defer_x, small, unit_w, fused, fused_q, fused_rows}.  Results agree for every setting to the last bits of the PCG
+ * scalars (the grouping of the fp64 partial sums follows the grid); only speed changes. */
 int octane_vof_tune(octane_vof_plan *plan, const char *key, int value);
+/* Diagnostic: time `iterations` (>= 2) PCG iterations of pyramid level `level` (0 = coarsest) in isolation, on
+ * whatever the plan's planes hold (the stop test is held open, values are irrelevant, the planes are clobbered).
+ * With the one-kernel iteration (the default) its time comes back in *pass_a_ms and *pass_b_ms is 0. */
 int octane_vof_plan_probe(octane_vof_plan *plan, int level, int iterations, double *pass_a_ms, double *pass_b_ms);
 
 /* Independent pairs sharded over GPUs: pair b runs on devices[b % ndevices]; one host thread per

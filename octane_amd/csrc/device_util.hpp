@@ -111,6 +111,20 @@ __device__ __forceinline__ ItemRange item_range(int nitems, bool banded)
     return r;
 }
 
+// mode 0: items round-robin over workgroups; 1: one contiguous band per XCD (above); 2: one contiguous run of items per
+// workgroup -- a workgroup walking along a row of tiles finds the lines its left / right halo shares with the previous
+// tile still in its own L1 / L2, whatever the other workgroups are doing
+__device__ __forceinline__ ItemRange item_range_walk(int nitems, int mode)
+{
+    if (mode == 2) {
+        ItemRange r;
+        const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+        r.base = 0; r.first = (int)blockIdx.x * per; r.end = min(nitems, r.first + per); r.step = 1;
+        return r;
+    }
+    return item_range(nitems, mode == 1);
+}
+
 // Jacobi preconditioner entry exactly as the reference forms it: M = 1./M in double, stored
 // as float (ref .cu:141-149).
 __device__ __forceinline__ float jacobi_inv(float a) { return (float)(1. / (double)a); }

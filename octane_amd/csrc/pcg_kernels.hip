@@ -50,6 +50,10 @@ __device__ __forceinline__ void st4_nt(float *p, float4 v)
     f4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
     __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));
 }
+// plane base + 32-bit byte offset: the scalar-base addressing form, one VGPR of offset shared by every plane instead of
+// a 64-bit address pair per plane and group (planes addressed this way are smaller than 4 GiB)
+__device__ __forceinline__ const float *at(const float *base, unsigned byte_off) { return (const float *)((const char *)base + byte_off); }
+__device__ __forceinline__ float *at(float *base, unsigned byte_off) { return (float *)((char *)base + byte_off); }
 __device__ __forceinline__ float4 ld4_if(const float *p, bool nt) { return nt ? ld4_nt(p) : ld4(p); }
 __device__ __forceinline__ void st4_if(float *p, float4 v, bool nt) { if (nt) st4_nt(p, v); else st4(p, v); }
 
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a(LevelPtrs L, int k, int npar
     float *__restrict__ pout_u = L.pu[(k + 1) & 1];
     float *__restrict__ pout_v = L.pv[(k + 1) & 1];
 
-    const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
+    const ItemRange tr = item_range(ntiles, L.xcd_bands == 1);
     for (int t = tr.first; t < tr.end; t += tr.step) {
         const int tx0 = (t % tiles_x) * TX, ty0 = by0 + (t / tiles_x) * TY;
         float a1[R][4], a4[R][4], a2[R][4], wxc[R][4], wyc[R][4], wys[R][4], npu[R][4], npv[R][4];
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_a_lat(LevelPtrs L, int k, int 
     const float *__restrict__ pin_v = L.pv[k & 1];
     float *__restrict__ pout_u = L.pu[(k + 1) & 1];
     float *__restrict__ pout_v = L.pv[(k + 1) & 1];
-    const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
+    const ItemRange tr = item_range(ntiles, L.xcd_bands == 1);
 
     // Phase 1 of a tile: nothing but loads -- none of them depends on beta or on the stop decision.
     auto load_tile = [&](int t, PassATile<R> &g) {
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
     const float alpha2 = x_two ? L.alpha[(k - 2) & 1] : 0.f;          // alpha_{k-2}, stored by the previous launch
     double acc_pq = 0., acc_qz = 0., acc_qmq = 0., acc_rq = 0., acc_qq = 0., acc_rz = 0., acc_rr = 0.;
 
-    const ItemRange tr = item_range(ntiles, L.xcd_bands != 0);
+    const ItemRange tr = item_range_walk(ntiles, L.xcd_bands);
     for (int t = tr.first; t < tr.end; t += tr.step) {
         const int tx0 = (t % tiles_x) * TX, ty0 = by0 + (t / tiles_x) * TY;
         float a1[R][4], a4[R][4], a2[R][4], wxc[R][4], wyc[R][4], wys[R][4], npu[R][4], npv[R][4], nru[R][4], nrv[R][4];
@@ -952,6 +956,298 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused PCG iteration WITHOUT a stored q (the large levels of a plain plan).
+//
+// q_{k-1} = A p_{k-1} is written by one launch only to be read once by the next (r_k = r_{k-1} - alpha q_{k-1}).  p_{k-1}
+// is stored anyway, so the next launch can form q_{k-1} again -- same inputs, same operations, same bits -- and the 16
+// B/pixel of q traffic (of 80) disappear: 64 B/pixel/iteration.  The price is a second stencil per pixel (free, the kernel
+// is bandwidth-bound) and wider halos: a workgroup needs r_k and p_k on its tile's one-pixel ring, so it forms q_{k-1}
+// there too, from p_{k-1} two pixels out.  The ring is handled as 100 more float4 groups of the same per-group routine
+// (the row above, the row below, the group left and right of every row), not as scalar special cases:
+//   phase 0   p_{k-1} of the tile + 2 rows / 4 columns around it -> LDS
+//   phase 1   per group of the tile and its ring: q_{k-1} (stencil on that LDS tile), r_k, z_k, p_k -> second LDS tile;
+//             tile groups also update x and store r_k, p_k
+//   phase 2   tile groups: q_k (stencil on the second LDS tile) and the seven partial sums; q_k is NOT stored
+// Everything else (scalars from the previous launch's sums, double-buffered r / partials, triple-buffered p, deferred x)
+// is k_pcg_fused's.  Row bands keep k_pcg_fused: the ring of a band edge would need two rows of the neighbour's p.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kQTY = 2 * kTileY;            // 16 tile rows
+constexpr int kQCols = kTileX + 16;         // LDS row: 8 floats of margin either side of the 128 tile columns
+constexpr int kQOff = 8;                    // LDS column of the tile's first pixel
+
+struct QCoef { float a1[4], a2[4], a4[4], wx[4], wy[4], wys[4]; float wxw; };
+
+// the 5-point operator on one float4 group at frame position (x0, y), from an LDS tile whose row `lrow` / column `lcol`
+// hold the group's own pixels (same arithmetic, in the same order, as every other form of A p in this file)
+__device__ __forceinline__ void stencil_group(const float *s_u, const float *s_v, int lrow, int lcol, int x0, int y, int w, int h,
+                                              const QCoef &c, float (&qu)[4], float (&qv)[4])
+{
+    float cu[4], cv[4], su[4], sv[4], nu[4], nv[4];
+    *(float4 *)cu = ld4(&s_u[lrow * kQCols + lcol]); *(float4 *)cv = ld4(&s_v[lrow * kQCols + lcol]);
+    *(float4 *)su = ld4(&s_u[(lrow - 1) * kQCols + lcol]); *(float4 *)sv = ld4(&s_v[(lrow - 1) * kQCols + lcol]);
+    *(float4 *)nu = ld4(&s_u[(lrow + 1) * kQCols + lcol]); *(float4 *)nv = ld4(&s_v[(lrow + 1) * kQCols + lcol]);
+    const float uwest = s_u[lrow * kQCols + lcol - 1], vwest = s_v[lrow * kQCols + lcol - 1];
+    const float ueast = s_u[lrow * kQCols + lcol + 4], veast = s_v[lrow * kQCols + lcol + 4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int i = x0 + e;
+        const float pwu = (e == 0) ? uwest : cu[(e + 3) & 3], pwv = (e == 0) ? vwest : cv[(e + 3) & 3];
+        const float peu = (e == 3) ? ueast : cu[(e + 1) & 3], pev = (e == 3) ? veast : cv[(e + 1) & 3];
+        const float a5 = (e == 0) ? c.wxw : c.wx[(e + 3) & 3];
+        const float wS = (y == h - 1) ? c.wys[e] + c.wy[e] : c.wys[e];
+        const float wW = (i == w - 1) ? a5 + c.wx[e] : a5;
+        const float wE = (i == 0) ? c.wx[e] + c.wx[e] : c.wx[e];
+        const float wN = (y == 0) ? c.wy[e] + c.wy[e] : c.wy[e];
+        float sumu = 0.f, sumv = 0.f;
+        if (y > 0) { sumu += wS * su[e]; sumv += wS * sv[e]; }
+        if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
+        sumu += c.a1[e] * cu[e]; sumv += c.a2[e] * cu[e];
+        sumu += c.a2[e] * cv[e]; sumv += c.a4[e] * cv[e];
+        if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
+        if (y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
+        qu[e] = sumu; qv[e] = sumv;
+    }
+}
+
+template <bool UNITW>
+__global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int nparts_prev, float tol)
+{
+    constexpr int TY = kQTY, TX = kTileX;
+    __shared__ __attribute__((aligned(16))) float s_ou[(TY + 4) * kQCols], s_ov[(TY + 4) * kQCols];   // p_{k-1}: rows ty0-2 .. ty0+TY+1
+    __shared__ __attribute__((aligned(16))) float s_nu[(TY + 2) * kQCols], s_nv[(TY + 2) * kQCols];   // p_k:     rows ty0-1 .. ty0+TY
+    __shared__ double s_red[4 * kPartKinds];
+    const int tid = threadIdx.x;
+    const bool first = (k == 0);
+
+    const PcgState prev = L.st[k & 1];
+    if (prev.stopped) {
+        if (blockIdx.x == 0 && tid == 0) L.st[(k + 1) & 1] = prev;
+        return;
+    }
+    const int pin_off = ((k + 1) & 1) * kPartBlock, pout_off = (k & 1) * kPartBlock;
+    float alpha = 0.f, nalpha = 0.f, beta = 0.f, rz_new, rr;
+    if (first) {
+        double t[2];
+        fold_band_partials_multi_256<2>(L.band_parts, pin_off + kPartRz, kMaxParts, nparts_prev, L.nbands, s_red, t);
+        rz_new = (float)t[0]; rr = (float)t[1];
+    } else {
+        double t[kPartKinds];
+        fold_band_partials_multi_256<kPartKinds>(L.band_parts, pin_off, kMaxParts, nparts_prev, L.nbands, s_red, t);
+        const double rzd = t[0], rrd = t[1], pq = t[2], qz = t[3], qmq = t[4], rq = t[5], qq = t[6];
+        alpha = prev.rz / (float)pq;                 // ref .cu:1169
+        nalpha = (float)(-1. * (double)alpha);       // ref .cu:1174
+        const double a = (double)alpha;
+        rz_new = (float)(rzd - 2. * a * qz + a * a * qmq);
+        rr = (float)(rrd - 2. * a * rq + a * a * qq);
+        beta = rz_new / prev.rz;
+    }
+    const bool active = rr > tol;                    // ref .cu:1131
+    if (blockIdx.x == 0 && tid == 0) {
+        PcgState n; n.rz = rz_new; n.stopped = active ? 0 : 1; n.iters = prev.iters + (active ? 1 : 0); n.pad = 0;
+        L.st[(k + 1) & 1] = n;
+        if (!first) L.alpha[(k - 1) & 1] = alpha;
+    }
+    if (first && !active) return;
+
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int tiles_x = (w + TX - 1) / TX, tiles_y = (h + TY - 1) / TY;
+    const int ntiles = tiles_x * tiles_y;
+    const int ko = (k + 1) & 1, kn = k & 1;
+    const float *__restrict__ rin_u = first ? L.rb_u[0] : L.rb_u[ko];
+    const float *__restrict__ rin_v = first ? L.rb_v[0] : L.rb_v[ko];
+    float *__restrict__ rout_u = L.rb_u[kn];
+    float *__restrict__ rout_v = L.rb_v[kn];
+    const float *__restrict__ pin_u = L.pf_u[(k + 2) % 3];          // p_{k-1}
+    const float *__restrict__ pin_v = L.pf_v[(k + 2) % 3];
+    const float *__restrict__ pin2_u = L.pf_u[(k + 1) % 3];         // p_{k-2}
+    const float *__restrict__ pin2_v = L.pf_v[(k + 1) % 3];
+    float *__restrict__ pout_u = L.pf_u[k % 3];
+    float *__restrict__ pout_v = L.pf_v[k % 3];
+    const bool defer = L.defer_x != 0;
+    const bool x_two = defer && !first && (k & 1) == 0;
+    const bool x_one = !first && (!defer || ((k & 1) == 1 && !active));
+    const bool x_read = x_two ? (k > 2) : (defer ? (k >= 3) : (k > 1));
+    const float alpha2 = x_two ? L.alpha[(k - 2) & 1] : 0.f;
+    double acc_pq = 0., acc_qz = 0., acc_qmq = 0., acc_rq = 0., acc_qq = 0., acc_rz = 0., acc_rr = 0.;
+
+    const ItemRange tr = item_range_walk(ntiles, L.xcd_bands);
+    for (int t = tr.first; t < tr.end; t += tr.step) {
+        const int tx0 = (t % tiles_x) * TX, ty0 = (t / tiles_x) * TY;
+        // ---- loads of the thread's two tile groups first (r_{k-1} and the operator; addresses of groups beyond a ragged
+        // edge are clamped into the frame, their values never used), so that they are in flight while phase 0 waits for p
+        QCoef c3[2];
+        float r3u[2][4], r3v[2][4];
+#pragma unroll
+        for (int slot = 0; slot < 2; slot++) {
+            const int gx = tid & 31, gy = (tid >> 5) + kTileY * slot;
+            const int x0 = tx0 + 4 * gx, y = ty0 + gy;
+            const bool valid = y < h && x0 < w;
+            const unsigned o = valid ? (unsigned)(y * pitch + x0) * 4u : 0u;
+            QCoef &c = c3[slot];
+            *(float4 *)r3u[slot] = ld4(at(rin_u, o)); *(float4 *)r3v[slot] = ld4(at(rin_v, o));
+            *(float4 *)c.a1 = ld4(at(L.a1, o)); *(float4 *)c.a4 = ld4(at(L.a4, o));
+            *(float4 *)c.a2 = ld4_if(at(L.a2, o), L.nt_hints & 8);
+            if (UNITW) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { c.wx[e] = -1.f; c.wy[e] = -1.f; c.wys[e] = -1.f; }
+                c.wxw = -1.f;
+            } else {
+                *(float4 *)c.wx = ld4(at(L.wx, o)); *(float4 *)c.wy = ld4(at(L.wy, o));
+                *(float4 *)c.wys = ld4(at(L.wy, (valid && y > 0) ? o - 4u * (unsigned)pitch : o));     // unused in the frame's first row
+                c.wxw = *at(L.wx, (valid && x0 > 0) ? o - 4u : o);                                      // unused in its first column
+            }
+        }
+        // ---- phase 0: p_{k-1} on the tile + 2 rows / one float4 group around it (zero outside the frame)
+        if (!first) {
+            constexpr int GW = TX / 4 + 2;                        // groups per staged row: one left, one right of the tile
+            for (int i = tid; i < GW * (TY + 4); i += 256) {
+                const int gx = i % GW - 1, gy = i / GW - 2;
+                const int x0 = tx0 + 4 * gx, y = ty0 + gy;
+                float4 pu = make_float4(0, 0, 0, 0), pv = pu;
+                if (y >= 0 && y < h && x0 >= 0 && x0 < w) {
+                    const unsigned o = (unsigned)(y * pitch + x0) * 4u;
+                    pu = ld4(at(pin_u, o)); pv = ld4(at(pin_v, o));   // planes are padded to a multiple of 64 floats: in bounds
+                    if (x0 + 3 >= w) {                            // beyond the frame's last column: zero, as the other forms do
+                        if (x0 + 1 >= w) { pu.y = 0.f; pv.y = 0.f; }
+                        if (x0 + 2 >= w) { pu.z = 0.f; pv.z = 0.f; }
+                        pu.w = 0.f; pv.w = 0.f;
+                    }
+                }
+                st4(&s_ou[(gy + 2) * kQCols + kQOff + 4 * gx], pu);
+                st4(&s_ov[(gy + 2) * kQCols + kQOff + 4 * gx], pv);
+            }
+            __syncthreads();
+        }
+        // ---- phase 1: the ring group (one each for the first 100 threads), then the two tile groups
+#pragma unroll
+        for (int sl = 0; sl < 3; sl++) {
+            const int slot = (sl + 2) % 3;
+            int gx, gy;
+            const bool own = slot < 2;
+            if (own) { gx = tid & 31; gy = (tid >> 5) + kTileY * slot; }
+            else if (tid < 34) { gx = tid - 1; gy = -1; }
+            else if (tid < 68) { gx = tid - 35; gy = TY; }
+            else if (tid < 84) { gx = -1; gy = tid - 68; }
+            else if (tid < 100) { gx = TX / 4; gy = tid - 84; }
+            else { gx = 0; gy = -9; }                              // no ring group for this thread
+            const int x0 = tx0 + 4 * gx, y = ty0 + gy;
+            const bool valid = (gy >= -1) && y >= 0 && y < h && x0 >= 0 && x0 < w;
+            QCoef cr;
+            float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0}, pnu[4] = {0, 0, 0, 0}, pnv[4] = {0, 0, 0, 0};
+            if (!own) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { cr.a1[e] = 1.f; cr.a4[e] = 1.f; cr.a2[e] = 0.f; cr.wx[e] = 0.f; cr.wy[e] = 0.f; cr.wys[e] = 0.f; }
+                cr.wxw = 0.f;
+                if (valid) {
+                    const unsigned o = (unsigned)(y * pitch + x0) * 4u;
+                    *(float4 *)ru = ld4(at(rin_u, o)); *(float4 *)rv = ld4(at(rin_v, o));
+                    *(float4 *)cr.a1 = ld4(at(L.a1, o)); *(float4 *)cr.a4 = ld4(at(L.a4, o));
+                    *(float4 *)cr.a2 = ld4(at(L.a2, o));
+                    if (UNITW) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { cr.wx[e] = -1.f; cr.wy[e] = -1.f; cr.wys[e] = -1.f; }
+                        cr.wxw = -1.f;
+                    } else {
+                        *(float4 *)cr.wx = ld4(at(L.wx, o)); *(float4 *)cr.wy = ld4(at(L.wy, o));
+                        if (y > 0) *(float4 *)cr.wys = ld4(at(L.wy, o - 4u * (unsigned)pitch));
+                        if (x0 > 0) cr.wxw = *at(L.wx, o - 4u);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { ru[e] = r3u[slot & 1][e]; rv[e] = r3v[slot & 1][e]; }
+            }
+            const QCoef &c = own ? c3[slot & 1] : cr;
+            if (valid) {
+                const unsigned o = (unsigned)(y * pitch + x0) * 4u;
+                float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
+                if (!first) {
+                    float qu[4], qv[4];
+                    stencil_group(s_ou, s_ov, gy + 2, kQOff + 4 * gx, x0, y, w, h, c, qu, qv);        // q_{k-1}, again
+                    *(float4 *)pu = ld4(&s_ou[(gy + 2) * kQCols + kQOff + 4 * gx]);
+                    *(float4 *)pv = ld4(&s_ov[(gy + 2) * kQCols + kQOff + 4 * gx]);
+                    if (own && (x_two || x_one)) {
+                        float xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0};
+                        if (x_read) { *(float4 *)xu = ld4_if(at(L.xu, o), L.nt_hints & 1); *(float4 *)xv = ld4_if(at(L.xv, o), L.nt_hints & 1); }
+                        if (x_two) {
+                            float ou[4], ov[4];
+                            *(float4 *)ou = ld4(at(pin2_u, o)); *(float4 *)ov = ld4(at(pin2_v, o));
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { xu[e] = alpha2 * ou[e] + xu[e]; xv[e] = alpha2 * ov[e] + xv[e]; }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { xu[e] = alpha * pu[e] + xu[e]; xv[e] = alpha * pv[e] + xv[e]; }   // ref .cu:1172
+                        st4_if(at(L.xu, o), *(float4 *)xu, L.nt_hints & 1);
+                        st4_if(at(L.xv, o), *(float4 *)xv, L.nt_hints & 1);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { ru[e] = nalpha * qu[e] + ru[e]; rv[e] = nalpha * qv[e] + rv[e]; }    // ref .cu:1174
+                    if (own && active) { st4(at(rout_u, o), *(float4 *)ru); st4(at(rout_v, o), *(float4 *)rv); }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const bool ok = (x0 + e) < w;
+                    if (!ok) { ru[e] = 0.f; rv[e] = 0.f; }
+                    pnu[e] = ok ? direction(ru[e], pu[e], c.a1[e], beta, first) : 0.f;
+                    pnv[e] = ok ? direction(rv[e], pv[e], c.a4[e], beta, first) : 0.f;
+                }
+                if (own && active) { st4(at(pout_u, o), *(float4 *)pnu); st4(at(pout_v, o), *(float4 *)pnv); }
+            }
+            if (gy >= -1) {
+                st4(&s_nu[(gy + 1) * kQCols + kQOff + 4 * gx], *(float4 *)pnu);
+                st4(&s_nv[(gy + 1) * kQCols + kQOff + 4 * gx], *(float4 *)pnv);
+            }
+            if (own) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { r3u[slot & 1][e] = ru[e]; r3v[slot & 1][e] = rv[e]; }     // r_k, for the sums of phase 2
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: q_k on the tile and the partial sums (q_k is not stored: the next launch forms it again)
+        if (active) {
+#pragma unroll
+            for (int slot = 0; slot < 2; slot++) {
+                const int gx = tid & 31, gy = (tid >> 5) + kTileY * slot;
+                const int x0 = tx0 + 4 * gx, y = ty0 + gy;
+                if (y < h && x0 < w) {
+                    float qu[4], qv[4];
+                    stencil_group(s_nu, s_nv, gy + 1, kQOff + 4 * gx, x0, y, w, h, c3[slot], qu, qv);
+                    float pku[4], pkv[4];
+                    *(float4 *)pku = ld4(&s_nu[(gy + 1) * kQCols + kQOff + 4 * gx]); *(float4 *)pkv = ld4(&s_nv[(gy + 1) * kQCols + kQOff + 4 * gx]);
+                    float d_pq = 0.f, d_qz = 0.f, d_qmq = 0.f, d_rq = 0.f, d_qq = 0.f, d_rz = 0.f, d_rr = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (x0 + e < w) {
+                            const float iu = 1.0f / c3[slot].a1[e], iv = 1.0f / c3[slot].a4[e];
+                            const float zu = iu * r3u[slot][e], zv = iv * r3v[slot][e];
+                            d_pq += pku[e] * qu[e]; d_pq += pkv[e] * qv[e];
+                            d_qz += qu[e] * zu; d_qz += qv[e] * zv;
+                            d_qmq += qu[e] * (iu * qu[e]); d_qmq += qv[e] * (iv * qv[e]);
+                            d_rq += r3u[slot][e] * qu[e]; d_rq += r3v[slot][e] * qv[e];
+                            d_qq += qu[e] * qu[e]; d_qq += qv[e] * qv[e];
+                            d_rz += r3u[slot][e] * zu; d_rz += r3v[slot][e] * zv;
+                            d_rr += r3u[slot][e] * r3u[slot][e]; d_rr += r3v[slot][e] * r3v[slot][e];
+                        }
+                    }
+                    acc_pq += (double)d_pq; acc_qz += (double)d_qz; acc_qmq += (double)d_qmq; acc_rq += (double)d_rq;
+                    acc_qq += (double)d_qq; acc_rz += (double)d_rz; acc_rr += (double)d_rr;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    double *own_blk = L.part_own + pout_off;
+    const double accs[kPartKinds] = {acc_rz, acc_rr, acc_pq, acc_qz, acc_qmq, acc_rq, acc_qq};
+    double tot[kPartKinds];
+    block_sum_multi_256<kPartKinds>(accs, s_red, tot);
+    if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j < kPartKinds; j++) own_blk[j * kMaxParts + blockIdx.x] = tot[j];
+    }
+}
+
 // u += dx, v += dy after a solve made of `nlaunched` fused kernels (ref .cu:1185-1195).  A solve that ran into its
 // iteration cap leaves the last alpha p to be added here; one that met the tolerance has a complete x.
 __global__ __launch_bounds__(256) void k_flow_update_fused(LevelPtrs L, int nlaunched, int nparts)
@@ -1060,7 +1356,7 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
     // each pass begins on the planes the previous one touched last (p, q, r and the diagonal are
     // still in the 256 MiB Infinity Cache there).
     const int nchunks = (int)((ngroups + 255) / 256);
-    const ItemRange cr = item_range(nchunks, L.xcd_bands != 0);
+    const ItemRange cr = item_range(nchunks, L.xcd_bands == 1);
     BOperands cur, nxt;
     pass_b_issue(L, k, xmode, cr, cr.first, ngroups, gw, pitch, cur);
 
@@ -1261,28 +1557,45 @@ void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, i
 }
 
 // Fused PCG: grid (shared by every launch of a solve, it is also the number of partials), launch, flow update.
+static int g_fused_q = 1;            // large levels of a plain plan recompute q instead of storing it (k_pcg_fused_q); 0 = always store q
+void set_fused_q(int v) { g_fused_q = v != 0; }
 static int g_fused_r = 0;            // tuning: 0 = by size, 1 / 2 = force the 128 x 8 / 128 x 16 tile
 void set_fused_rows(int r) { g_fused_r = (r == 1 || r == 2) ? r : 0; }
 static int fused_rows(int w, int rows) { return g_fused_r ? g_fused_r : (((long)w * rows < (1L << 20)) ? 1 : 2); }
+// q is recomputed where that pays: from about 4 M pixels (measured, tools/probe_forms.py: 1250^2 33 -> 35 us, 2500^2 112 -> 109 us,
+// 5000^2 395 -> 369 us); below, the level sits in the Infinity Cache and the extra ring work costs more than q's traffic
+static bool fused_q_form(int w, int rows, bool banded)
+{
+    return g_fused_q && !banded && fused_rows(w, rows) == 2 && (long)w * rows >= (1L << 22) &&
+           (long)(w + 64) * rows < (1L << 30);            // 32-bit byte offsets inside a plane
+}
 
-int pcg_fused_grid_size(int w, int rows, int unit_w)
+int pcg_fused_grid_size(int w, int rows, int unit_w, int banded)
 {
     const int R = fused_rows(w, rows);                                // small levels: more, smaller tiles
     const long items = (long)((w + kTileX - 1) / kTileX) * ((rows + kTileY * R - 1) / (kTileY * R));
     // never more workgroups than are resident at once (a second wave of a persistent grid runs on a half-empty chip):
     // 128 x 16 tiles need 180 / 163 VGPRs (2 / 3 workgroups per CU), 128 x 8 tiles 135 / 122 (3 / 4)
-    const long cap = 256 * (R == 2 ? (unit_w ? 3 : 2) : (unit_w ? 4 : 3));
+    // (the q-recomputing form of the 128 x 16 tile: 207 / 229 VGPRs and 44 KB of LDS, 2 per CU)
+    const bool qform = fused_q_form(w, rows, banded != 0);
+    const long cap = 256 * (R == 2 ? ((unit_w && !qform) ? 3 : 2) : (unit_w ? 4 : 3));
     if (items <= cap) return (int)(items < 1 ? 1 : items);
     const long rounds = (items + cap - 1) / cap;
-    return (int)((items + rounds - 1) / rounds);
+    int g = (int)((items + rounds - 1) / rounds);
+    if (grid_multiple() > 1 && g >= 8 * grid_multiple()) g = g / grid_multiple() * grid_multiple();   // XCD bands want a multiple of 8
+    return g;
 }
 
 void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
     const bool small = fused_rows(L.w, L.y1 - L.y0) == 1;
+    const bool whole = L.nbands == 1 && L.y0 == 0 && L.y1 == L.h;
     if (small) {
         if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused<1, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
         else hipLaunchKernelGGL((k_pcg_fused<1, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    } else if (fused_q_form(L.w, L.h, !whole)) {                        // plain plan: do not store q, form it again
+        if (L.unit_w) hipLaunchKernelGGL(k_pcg_fused_q<true>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        else hipLaunchKernelGGL(k_pcg_fused_q<false>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
     } else {
         if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused<2, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
         else hipLaunchKernelGGL((k_pcg_fused<2, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);

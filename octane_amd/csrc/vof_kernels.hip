@@ -366,6 +366,7 @@ static int g_max_blocks = kMaxParts;
 static int g_grid_multiple = 1;
 void set_max_blocks(int n) { g_max_blocks = (n >= 64 && n <= kMaxParts) ? n : kMaxParts; }
 void set_grid_multiple(int m) { g_grid_multiple = m > 0 ? m : 1; }
+int grid_multiple() { return g_grid_multiple; }
 
 int balanced_grid(long items)
 {

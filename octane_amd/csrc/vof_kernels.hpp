@@ -75,7 +75,7 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     long long *iter_total;
     int reverse_b;                  // pass B walks the frame backwards (Infinity-Cache reuse)
     int nt_hints;                   // bit mask of streaming-load/store hints (tuning)
-    int xcd_bands;                  // give each XCD (blockIdx % 8) one contiguous band of the frame
+    int xcd_bands;                  // 1: give each XCD (blockIdx % 8) one contiguous band of the frame; 2 (fused PCG): one run of tiles per workgroup
     int unit_w;                     // this linearisation has al1 == 1: wx == wy == -1 everywhere, pass A need not read them
     int lean;                       // the fused kernels are the only readers: the assembly skips the planes they never read
                                     // (mu, mv; wx, wy while unit_w) and the flow update does not write x back
@@ -98,6 +98,7 @@ void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpi
                      float *fine, int fw, int fh, int fpitch, float sf);
 void set_max_blocks(int n);
 void set_grid_multiple(int m);           // tuning knob (<= kMaxParts)
+int  grid_multiple();
 int  balanced_grid(long work_items);   // persistent grid: every block gets the same number of items (+-1)
 int  pcg_grid_size(int w, int h);
 int  pcg_grid_size_unit_w(int w, int h);     // pass A grid of the unit-weight (first GNC step) launches
@@ -111,8 +112,9 @@ void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P,
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid);
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int niter_launched);
+void set_fused_q(int v);                     // tuning: the q-recomputing form of the fused kernel on large levels
 void set_fused_rows(int r);                  // tuning: tile rows of the fused kernel (0 = by level size)
-int  pcg_fused_grid_size(int w, int rows, int unit_w);   // fused one-kernel-per-iteration PCG (pcg_kernels.hip)
+int  pcg_fused_grid_size(int w, int rows, int unit_w, int banded = 0);   // fused one-kernel-per-iteration PCG (pcg_kernels.hip)
 void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 void launch_flow_update_fused(hipStream_t s, const LevelPtrs &L, int niter_launched, int nparts);
 bool pcg_small_applicable(int w, int h);

@@ -230,7 +230,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_MAXBLOCKS")) set_max_blocks(atoi(e));   // developer tuning knobs
     if (const char *e = getenv("OCTANE_TUNE_REVERSE_B")) pl->reverse_b = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_PASS_A")) set_pass_a_variant(atoi(e));
-    if (const char *e = getenv("OCTANE_TUNE_XCD")) pl->xcd_bands = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_XCD")) pl->xcd_bands = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_SMALL")) pl->use_small = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_NT")) pl->nt_hints = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_DEFER_X")) pl->defer_x = atoi(e) != 0;
@@ -238,13 +238,14 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_UNIT_W")) pl->use_unit_w = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_FUSED")) pl->use_fused = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_FUSED_ROWS")) set_fused_rows(atoi(e));
+    if (const char *e = getenv("OCTANE_TUNE_FUSED_Q")) set_fused_q(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_UNIT_W_CAP")) set_unit_w_cap(atoi(e));
     {
         const char *ea = getenv("OCTANE_TUNE_CAP_A"), *eb = getenv("OCTANE_TUNE_CAP_B");
         if (ea || eb) set_pass_caps(ea ? atoi(ea) : 768, eb ? atoi(eb) : 1024);
     }
     pcg_small_configure();
-    set_grid_multiple(pl->xcd_bands ? 8 : 1);
+    set_grid_multiple(pl->xcd_bands == 1 ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
 
     const float scale = (float)p->scaleF;
@@ -1233,6 +1234,12 @@ extern "C" int octane_vof_plan_probe(octane_vof_plan *pl, int level, int iterati
         return OCTANE_E_INVALID;
     }
     HIP_TRY(hipSetDevice(pl->device));
+    if (pl->use_fused) {            // one kernel per iteration: its time is reported as "pass A", pass B as 0
+        const double ms = probe_level(pl, level, iterations, nullptr, nullptr);
+        if (ms < 0) { g_last_error = "octane_vof_plan_probe failed"; return OCTANE_E_HIP; }
+        *pass_a_ms = ms; *pass_b_ms = 0.;
+        return OCTANE_OK;
+    }
     if (probe_level(pl, level, iterations, pass_a_ms, pass_b_ms) < 0) { g_last_error = "octane_vof_plan_probe failed"; return OCTANE_E_HIP; }
     return OCTANE_OK;
 }
@@ -1246,12 +1253,14 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     if (k == "max_blocks") { set_max_blocks(value); return OCTANE_OK; }
     if (!pl) return OCTANE_E_INVALID;
     if (k == "reverse_b") pl->reverse_b = value != 0;
-    else if (k == "xcd") { pl->xcd_bands = value != 0; set_grid_multiple(value ? 8 : 1); }
+    else if (k == "xcd") { pl->xcd_bands = value; set_grid_multiple(value == 1 ? 8 : 1); }
     else if (k == "nt") pl->nt_hints = value;
     else if (k == "defer_x") pl->defer_x = value != 0;
     else if (k == "small") pl->use_small = value != 0;
     else if (k == "unit_w") pl->use_unit_w = value != 0;
     else if (k == "fused") pl->use_fused = value != 0;
+    else if (k == "fused_q") set_fused_q(value);
+    else if (k == "fused_rows") set_fused_rows(value);
     else return OCTANE_E_INVALID;
     return OCTANE_OK;
 }

@@ -326,7 +326,7 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
         ap.dozim = prm.dozim != 0;
         L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;
         L.lean = fused ? 1 : 0;
-        const int g_f = pcg_fused_grid_size(li.w, maxrows, L.unit_w);
+        const int g_f = pcg_fused_grid_size(li.w, maxrows, L.unit_w, 1);
         for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
             if (!N.failed()) {
                 LevelPtrs La = L;

@@ -329,3 +329,28 @@ def test_fused_iteration_equals_two_pass_form(capi, nx, ny, prm):
     assert np.isfinite(outs[1][0][0]).all()
     d = rel_l2(outs[1][0][0], outs[1][0][1], outs[0][0][0], outs[0][0][1])
     assert d < INVESTIGATE, f"fused vs two-pass: {d:.3e}"
+
+
+def test_q_recomputing_form_equals_stored_q_form(capi):
+    """k_pcg_fused_q (levels of at least 2^22 pixels; OCTANE_TUNE_FUSED_Q=0 / tune("fused_q", 0) turns it off) does not
+    store q = A p but forms it again in the next launch from the stored p, on the tile and its one-pixel ring: same
+    inputs, same operations as the form that stores q.  Frame with ragged right / bottom tiles and more tiles than
+    workgroups."""
+    nx, ny = 2500, 1750
+    a, b = synth.lattice_scene(nx, ny, seed=91)
+    prm = capi.FlowParams(kiters=2, liters=1, cgiters=11)
+    outs = []
+    for q in (0, 1):
+        pl = capi.Plan(nx, ny, 1, prm)
+        try:
+            pl.tune("fused_q", q)
+            outs.append(pl.run_host(a, b))
+        finally:
+            pl.tune("fused_q", 1)
+            pl.close()
+    assert np.isfinite(outs[1][0]).all()
+    d = rel_l2(outs[1][0], outs[1][1], outs[0][0], outs[0][1])
+    nbad = int((outs[0][0] != outs[1][0]).sum())
+    # element by element the two forms compute the same bits; their persistent grids differ, hence the grouping of the
+    # fp64 partial sums, hence -- rarely -- the last bit of an alpha or beta
+    assert d < 1e-6, f"{d:.3e}, {nbad} pixels differ"

@@ -24,7 +24,7 @@ def norm(short):
     return short
 
 
-def pmc_section(d, size, kiters, per_level, two_pass_levels):
+def pmc_section(d, size, kiters, per_level, two_pass_levels, qform=False):
     """HBM traffic of the finest level from the FETCH_SIZE / WRITE_SIZE passes (sub-directories fetch/ and
     write/ of the profile directory).  Units and the gfx950 correction follow MI355X_MICROARCH.md 'HBM':
     both counters are in KiB; FETCH_SIZE reads exactly half the bytes of a wide (16 B/lane) coalesced
@@ -64,8 +64,10 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
     # pass A reads 36 B/px, 28 in the first of the three GNC steps (wx / wy are the constant -1 there): mean 33.33
     # the fused iteration reads r q p + five coefficient planes = 44 B/px (36 in the first GNC step) and, every second launch,
     # x and the p before last (16): mean 52 - 8/3; it writes r p q = 24 and x every second launch (8): mean 28;
-    # its flow update also reads the last p (the pending x update)
-    alg = {"k_pcg_pass_a": (100.0 / 3.0, 16), "k_pcg_pass_b": (40, 16), "k_pcg_fused": (52 - 8.0 / 3.0, 28), "k_assemble": (52, 36),
+    # its flow update also reads the last p (the pending x update).  The q-recomputing form (k_pcg_fused_q, large levels)
+    # neither reads nor writes q: 8 B/px less on either side
+    alg = {"k_pcg_pass_a": (100.0 / 3.0, 16), "k_pcg_pass_b": (40, 16),
+           "k_pcg_fused": (44 - 8.0 / 3.0, 20) if qform else (52 - 8.0 / 3.0, 28), "k_assemble": (52, 36),
            "k_flow_update": (24 if ("k_pcg_fused", "FETCH_SIZE") in vals else 16, 16 if ("k_pcg_fused", "FETCH_SIZE") in vals else 8)}
     out += ["", "## HBM traffic per launch at the finest level (rocprofv3 --pmc, separate passes)", "",
             "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE x1, both KiB -> bytes. Infinity-Cache hits are",
@@ -81,6 +83,7 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels):
         wr = vals[(k, "WRITE_SIZE")] * 1024
         ar, aw = alg[k][0] * px, alg[k][1] * px
         traffic[k] = {"read_bytes": round(rd), "write_bytes": round(wr), "size": size,
+                      "kernel": "k_pcg_fused_q" if (k == "k_pcg_fused" and qform) else k,
                       "how": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) and --pmc WRITE_SIZE, separate passes, "
                              "mean over the finest-level launches of bench.py"}
         out.append(f"| {k} | {rd / 1e6:.0f} | {ar / 1e6:.0f} | {wr / 1e6:.0f} | {aw / 1e6:.0f} | {(rd + wr) / (ar + aw):.3f} |")
@@ -99,15 +102,18 @@ def main():
     trace = cands[0]
     rows = defaultdict(list)
     meta = {}
+    qform = False
     with open(trace) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
             if "octane::" not in name:
                 continue
             short = name.split("octane::")[1].split("(")[0]
+            qform = qform or short.startswith("k_pcg_fused_q")
             short = norm(short)
-            rows[short].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])))
-            meta[short] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Workgroup_Size_X"])
+            m = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Workgroup_Size_X"])
+            rows[short].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"]), m))
+            meta[short] = m
     # the plan's placement trials (vof_plan.hip) launch a few PCG passes before the first pyramid: drop everything
     # that starts before the first assembly
     if "k_assemble" in rows:
@@ -144,7 +150,7 @@ def main():
             durs = [s[1] for s in sel]
             f = 0.5 ** (kiters - 1 - lev)
             lw = int(size * f + 0.5)
-            m = meta[k]
+            m = sel[-1][3]         # template instances differ per level (tile height, q stored or recomputed)
             lines.append(f"| {k} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} | {lev} ({lw}x{lw}) | {len(durs)} | "
                          f"{sum(durs) / len(durs) / 1e3:.2f} | {min(durs) / 1e3:.2f} | {max(durs) / 1e3:.2f} | {sel[0][2]} |")
     lines += ["", "| other kernels | launches | mean us | total ms |", "|---|---|---|---|"]
@@ -164,10 +170,14 @@ def main():
     px = size * size
     if fin["k_pcg_fused"]:
         f_ns = fin["k_pcg_fused"]
+        bpp = 184 / 3 if qform else 232 / 3
+        what = ("fused PCG iteration, q recomputed: 61.33 B/px (64 on average over odd / even launches: 52 / 76; 56 in the first GNC step, a "
+                if qform else
+                "fused PCG iteration: 77.33 B/px (80 on average over odd / even launches: 68 / 92; 72 in the first GNC step, a ")
         lines += ["", "## Finest level against the HBM roofline (algorithmic bytes, DESIGN.md)", "",
-                  f"* fused PCG iteration: 77.33 B/px (80 on average over odd / even launches: 68 / 92; 72 in the first GNC step, a "
-                  f"third of the launches) x {px} px = {232 / 3 * px / 1e9:.3f} GB per launch / {f_ns / 1e3:.1f} us = "
-                  f"**{232 / 3 * px / f_ns:.0f} GB/s** ({232 / 3 * px / f_ns / 80:.1f} % of 8 TB/s)",
+                  f"* {what}"
+                  f"third of the launches) x {px} px = {bpp * px / 1e9:.3f} GB per launch / {f_ns / 1e3:.1f} us = "
+                  f"**{bpp * px / f_ns:.0f} GB/s** ({bpp * px / f_ns / 80:.1f} % of 8 TB/s)",
                   f"* the same iteration at SURVEY 8(d)'s 116 B/px (pass A + pass B with seven coefficient planes): "
                   f"{116 * px / f_ns:.0f} GB/s ({116 * px / f_ns / 80:.1f} % of 8 TB/s)"]
     elif fin["k_pcg_pass_a"] and fin["k_pcg_pass_b"]:
@@ -179,7 +189,7 @@ def main():
                   f"**{56 * px / fin['k_pcg_pass_b']:.0f} GB/s** ({56 * px / fin['k_pcg_pass_b'] / 80:.1f} % of 8 TB/s)",
                   f"* one PCG iteration at SURVEY 8(d)'s 116 B/px: {116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']):.0f} GB/s "
                   f"({116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']) / 80:.1f} % of 8 TB/s)"]
-    lines += pmc_section(d, size, kiters, per_level, two_pass_levels)
+    lines += pmc_section(d, size, kiters, per_level, two_pass_levels, qform)
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
