@@ -53,6 +53,14 @@ void oct_merc_navcal_cuda(float *data2, short *data2s, short *x, short *y, short
                           int minx, int maxx, int miny, int maxy, float *data3, float *lat, float *lon, float xScale,
                           float xOffset, float yScale, float yOffset, float lon0, float R, int donav, OFFlags args);
 
+// ref src/oct_zoom.cc:12,51,180 (host code in the reference too): resampling of a calibrated channel onto the grid of
+// channel 1, used by the readers for -ic21/-ic22/-ic31/-ic32.  zoom_out: Gaussian blur (sigma = 0.6 sqrt(1/factor^2 - 1))
+// + bicubic decimation to (int)(n factor + 0.5) pixels, a plain copy for factor >= 0.999999; zoom_in: bicubic (interp
+// == 1) or nearest up-sampling with the half-pixel shift.  Channel `cnum` of the output is written.
+void oct_zoom_size(int nx, int ny, int &nxx, int &nyy, double factor);
+void oct_zoom_out_float(float *image, float *imageout, int nx, int ny, double factor, int verb, int cnum);
+void oct_zoom_in_float(float *flow, float *flowout, int nx, int ny, int nxx, int nyy, int cnum, int interp);
+
 // The `octane` command line (ref src/main.cc:42-50 spellings, :53-108 defaults, :166-350 scan), including
 // its quirks: -scsig squares its argument, -set_device is 1-based, -corn clears docorn, -cgiters is not parsed.
 struct OctaneCommandLine {

@@ -1,5 +1,5 @@
 # Builds the file layer of the reference's CLI on this library (SURVEY 8f N3):
-#   liboctane_io.so  -- oct_fileread / oct_goesread / oct_fgread / oct_filewrite / oct_goeswrite on nc4lite (HDF5)
+#   liboctane_io.so  -- oct_fileread (GOES / polar / Mercator / CLAVR-x / first guess) and oct_filewrite (outfile*.nc) on nc4lite (HDF5)
 #   octane           -- the command line: octane -i1 a.nc -i2 b.nc [-o outdir/] ...
 # Needs an HDF5 >= 1.10 with the high-level library (H5DS).  This image has one under /opt/conda only; where none is
 # found the targets are skipped (the flow library itself does not depend on any of this).

@@ -2,6 +2,8 @@
 //   io_demo --make-goes out.nc nx ny rad.bin t band xoff yoff   writes a GOES-R L1b look-alike: Rad (int16 counts from rad.bin,
 //                                                            deflate-compressed), x, y, t, band_id, goes_imager_projection,
 //                                                            planck_* and kappa0, with the attributes oct_goesread needs
+//   io_demo --make-proj out.nc polar|merc nx ny rad.bin t xs xo ys yo lon lat1 R    a re-mapped image (float Rad)
+//   io_demo --make-cth out.nc nx ny cth.bin                    cloud-top heights as CLAVR-x names them
 //   io_demo --make-fg out.nc nx ny uv.bin                     a first-guess file: UFG, VFG (float32 from uv.bin)
 //   io_demo --dump file.nc                                    one line per variable: name|shape|att=value;...
 //   io_demo --read file.nc var type out.bin                   whole variable as short|int|float|double
@@ -18,7 +20,8 @@ using nc4lite::Type;
 int main(int argc, char **argv)
 {
     try {
-        if (argc == 10 && !strcmp(argv[1], "--make-goes")) {
+        if ((argc == 10 || argc == 11) && !strcmp(argv[1], "--make-goes")) {
+            const float smul = argc == 11 ? (float)atof(argv[10]) : 1.f;      // pixel size in units of 56 urad (2 km)
             const int nx = atoi(argv[3]), ny = atoi(argv[4]);
             std::vector<short> rad((size_t)nx * ny), x(nx), y(ny);
             FILE *f = fopen(argv[5], "rb");
@@ -34,9 +37,9 @@ int main(int argc, char **argv)
             w.put_att("Rad", "scale_factor", 0.04572892f); w.put_att("Rad", "add_offset", -1.6443f);
             w.put_att("Rad", "long_name", std::string("ABI L1b Radiances"));
             w.def_var("x", Type::Short, {"x"});
-            w.put_att("x", "scale_factor", 5.6e-05f); w.put_att("x", "add_offset", (float)atof(argv[8]));
+            w.put_att("x", "scale_factor", 5.6e-05f * smul); w.put_att("x", "add_offset", (float)atof(argv[8]));
             w.def_var("y", Type::Short, {"y"});
-            w.put_att("y", "scale_factor", -5.6e-05f); w.put_att("y", "add_offset", (float)atof(argv[9]));
+            w.put_att("y", "scale_factor", -5.6e-05f * smul); w.put_att("y", "add_offset", (float)atof(argv[9]));
             w.def_var("t", Type::Double);
             w.put_att("t", "units", std::string("seconds since 2000-01-01 12:00:00"));
             w.def_var("band_id", Type::Byte, {"band"});
@@ -57,6 +60,49 @@ int main(int argc, char **argv)
             w.put_var("band_id", &band);
             const int gip = -2147483647;
             w.put_var(gp, &gip);
+            w.close();
+            return 0;
+        }
+        if (argc == 15 && !strcmp(argv[1], "--make-proj")) {       // a re-mapped image as oct_polarread / oct_mercread expect it
+            const bool polar = !strcmp(argv[3], "polar");
+            const int nx = atoi(argv[4]), ny = atoi(argv[5]);
+            std::vector<float> rad((size_t)nx * ny);
+            std::vector<short> x(nx), y(ny);
+            FILE *f = fopen(argv[6], "rb");
+            if (!f || fread(rad.data(), 4, rad.size(), f) != rad.size()) { printf("bad input\n"); return 2; }
+            fclose(f);
+            for (int i = 0; i < nx; i++) x[i] = (short)i;
+            for (int j = 0; j < ny; j++) y[j] = (short)j;
+            const double t = atof(argv[7]);
+            nc4lite::Writer w(argv[2]);
+            w.def_dim("y", ny); w.def_dim("x", nx);
+            w.def_var("Rad", Type::Float, {"y", "x"}, 4);
+            w.def_var("x", Type::Short, {"x"});
+            w.put_att("x", "scale_factor", (float)atof(argv[8])); w.put_att("x", "add_offset", (float)atof(argv[9]));
+            w.def_var("y", Type::Short, {"y"});
+            w.put_att("y", "scale_factor", (float)atof(argv[10])); w.put_att("y", "add_offset", (float)atof(argv[11]));
+            w.def_var("t", Type::Double);
+            w.put_att("t", "units", std::string("seconds since 2000-01-01 12:00:00"));
+            w.def_var("grid_mapping", Type::Int);
+            if (polar) { w.put_att("grid_mapping", "lon0", (float)atof(argv[12])); w.put_att("grid_mapping", "lat1", (float)atof(argv[13])); }
+            else w.put_att("grid_mapping", "lon1", (float)atof(argv[12]));
+            w.put_att("grid_mapping", "R", (float)atof(argv[14]));
+            w.put_var("Rad", rad.data()); w.put_var("x", x.data()); w.put_var("y", y.data()); w.put_var("t", &t);
+            const int gip = 7;
+            w.put_var("grid_mapping", &gip);
+            w.close();
+            return 0;
+        }
+        if (argc == 6 && !strcmp(argv[1], "--make-cth")) {          // CLAVR-x look-alike: Cloud_Top_Height_Effective(ny, nx)
+            const int nx = atoi(argv[3]), ny = atoi(argv[4]);
+            std::vector<float> cth((size_t)nx * ny);
+            FILE *f = fopen(argv[5], "rb");
+            if (!f || fread(cth.data(), 4, cth.size(), f) != cth.size()) { printf("bad input\n"); return 2; }
+            fclose(f);
+            nc4lite::Writer w(argv[2]);
+            w.def_dim("ny", ny); w.def_dim("nx", nx);
+            w.def_var("Cloud_Top_Height_Effective", Type::Float, {"ny", "nx"}, 4);
+            w.put_var("Cloud_Top_Height_Effective", cth.data());
             w.close();
             return 0;
         }

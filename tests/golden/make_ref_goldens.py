@@ -32,6 +32,9 @@ zoom_out.argtypes = [D, D, C.c_int, C.c_int, C.c_double, C.c_int]
 zoom_in_float = R._Z17oct_zoom_in_floatPfS_iiiiii
 zoom_in_float.argtypes = [F, F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
 
+zoom_out_float = R._Z18oct_zoom_out_floatPfS_iidii
+zoom_out_float.argtypes = [F, F, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+
 rng = np.random.RandomState(1234)
 out = {}
 
@@ -68,6 +71,27 @@ flow = (rng.randn(cy, cx) * 2).astype(np.float32)
 up = np.zeros((fy, fx), np.float32)
 zoom_in_float(flow, up, cx, cy, fx, fy, 0, 1)
 out.update(zi_flow=flow, zi_out=up)
+
+# 5. channel resampling as the readers use it (own generator so that the entries above keep their values):
+#    oct_zoom_out_float at factors 0.5, 0.4 (non-integer ratio) and 1.0 (the copy branch), channel 0;
+#    oct_zoom_in_float with bicubic into channel 1 of a two-channel buffer and nearest into channel 0
+rng5 = np.random.RandomState(4321)
+nx, ny = 50, 35
+img = (rng5.rand(ny, nx) * 255).astype(np.float32)
+out["zof_img"] = img
+for tag, f in (("05", 0.5), ("04", 0.4), ("10", 1.0)):
+    lx, ly = int(nx * f + 0.5), int(ny * f + 0.5)
+    o = np.zeros((ly, lx), np.float32)
+    zoom_out_float(img, o, nx, ny, f, 0, 0)
+    out["zof_out_" + tag] = o
+cx, cy, fx, fy = 17, 13, 50, 35
+src = (rng5.rand(cy, cx) * 255).astype(np.float32)
+two = np.full((2, fy, fx), -1.0, np.float32)
+zoom_in_float(src, two, cx, cy, fx, fy, 1, 1)
+out.update(zif_src=src, zif_out_c1=two)
+near = np.zeros((24, 33), np.float32)          # nearest: sizes for which the reference's unclamped index stays in range
+zoom_in_float(src, near, cx, cy, 33, 24, 0, 0)
+out.update(zif_near=near)
 
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_helpers.npz"), **out)
 print("wrote ref_helpers.npz with", sorted(out))

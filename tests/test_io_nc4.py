@@ -185,3 +185,145 @@ def test_octane_command_line_with_first_guess_file(io_demo, capi, tmp_path):
     assert np.array_equal(gv, v)
     s = _dump(io_demo, out)["optical_flow_settings"]["atts"]
     assert s["dofirstguess"] == "1" and abs(float(s["lambdac"]) - 0.3) < 1e-12
+
+
+def _make_goes(io_demo, tmp, name, counts, t, band="13", xoff="-0.031332", yoff="0.081212", smul=None):
+    ny, nx = counts.shape
+    raw = tmp / (name + ".bin")
+    counts.tofile(raw)
+    f = tmp / (name + ".nc")
+    cmd = [io_demo, "--make-goes", str(f), str(nx), str(ny), str(raw), repr(t), band, xoff, yoff]
+    subprocess.check_call(cmd + ([repr(smul)] if smul is not None else []))
+    return f
+
+
+def _host_zoom():
+    import ctypes as C
+    L = C.CDLL(os.path.join(LIBD, "liboctane_host.so"))
+    F = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+    zi = L._Z17oct_zoom_in_floatPfS_iiiiii
+    zi.argtypes = [F, F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    zo = L._Z18oct_zoom_out_floatPfS_iidii
+    zo.argtypes = [F, F, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+    return zi, zo
+
+
+GOES_KW = dict(radScale=0.04572892, radOffset=-1.6443, rpol=6356752.31414, req=6378137.0,
+               H=np.float32(35786023.0) + np.float32(6378137.0), lam0=LAM0, fk1=10803.3, fk2=1392.74, bc1=0.07550, bc2=0.99975,
+               kap1=0.0015839, maxout=255.0, minout=0.0, cal=0)
+
+
+@pytest.mark.gpu
+def test_octane_command_line_two_channels_and_cloud_top_heights(io_demo, capi, tmp_path):
+    """-ic21/-ic22: a second channel on a grid twice as coarse is calibrated, interpolated onto channel 1's grid
+    (oct_zoom_in_float) and solved as a two-channel image; -i1cth: CLAVR-x heights on a coarser grid become CTP shorts."""
+    nx, ny = 200, 144
+    c1, c2 = _counts(nx, ny, 31)
+    h1, h2 = _counts(nx // 2, ny // 2, 32)                               # channel 2 (band 14), 4 km pixels on the same sector
+    f = [_make_goes(io_demo, tmp_path, "a1", c1, 7.1e8), _make_goes(io_demo, tmp_path, "a2", c2, 7.1e8 + 300.0),
+         _make_goes(io_demo, tmp_path, "b1", h1, 7.1e8, band="14", smul=2.0), _make_goes(io_demo, tmp_path, "b2", h2, 7.1e8 + 300.0, band="14", smul=2.0)]
+    rng = np.random.RandomState(5)
+    cb = tmp_path / "cth.bin"
+    fc = tmp_path / "cth.nc"
+    outdir = str(tmp_path) + "/"
+    r = subprocess.run([os.path.join(LIBD, "octane"), "-i1", str(f[0]), "-i2", str(f[1]), "-ic21", str(f[2]), "-ic22", str(f[3]),
+                        "-o", outdir, "-pd", "-kiters", "3"], capture_output=True, text=True)
+    assert r.returncode == 0 and "outfile.nc written" in r.stdout, r.stdout + r.stderr
+    out = tmp_path / "outfile.nc"
+    zi, _ = _host_zoom()
+    x = np.arange(nx, dtype=np.int16); y = np.arange(ny, dtype=np.int16)
+    xh = np.arange(nx // 2, dtype=np.int16); yh = np.arange(ny // 2, dtype=np.int16)
+    mx, mn = capi.bandminmax(13)
+    mx2, mn2 = capi.bandminmax(14)
+    k1 = dict(GOES_KW, xScale=5.6e-05, xOffset=-0.031332, yScale=-5.6e-05, yOffset=0.081212, maxin=mx, minin=mn, minx=0, maxx=nx, miny=0, maxy=ny)
+    k2 = dict(GOES_KW, xScale=np.float32(5.6e-05) * np.float32(2.0), xOffset=-0.031332, yScale=np.float32(-5.6e-05) * np.float32(2.0),
+              yOffset=0.081212, maxin=mx2, minin=mn2, minx=0, maxx=nx // 2, miny=0, maxy=ny // 2)
+    imgs = []
+    for full, half, donav in ((c1, h1, 1), (c2, h2, 0)):
+        a = capi.navcal(full, x, y, capi.NavcalParams(donav=donav, **k1))[0]
+        b = capi.navcal(half, xh, yh, capi.NavcalParams(donav=donav, **k2))[0]
+        two = np.zeros((2, ny, nx), np.float32)
+        two[0] = a
+        zi(np.ascontiguousarray(b), two, nx // 2, ny // 2, nx, ny, 1, 1)
+        imgs.append(two)
+    assert imgs[0][1].std() > 1.0                                        # the second channel carries signal
+    u, v = capi.flow(imgs[0], imgs[1], capi.FlowParams(kiters=3))
+    u1, v1 = capi.flow(imgs[0][0], imgs[1][0], capi.FlowParams(kiters=3))
+    assert np.abs(u - u1).max() > 1e-3                                   # and takes part in the solve
+    assert np.array_equal(_read(io_demo, out, "Upix", "float", tmp_path).reshape(ny, nx), u)
+    assert np.array_equal(_read(io_demo, out, "Vpix", "float", tmp_path).reshape(ny, nx), v)
+
+    # cloud-top heights: band 2 makes the CLAVR-x window a quarter of the image grid (ref fr:321-327), the heights are
+    # interpolated up (interpcth = 1) and stored as shorts
+    q1, q2 = _counts(nx, ny, 33)
+    g = [_make_goes(io_demo, tmp_path, "v1", q1, 7.1e8, band="2"), _make_goes(io_demo, tmp_path, "v2", q2, 7.1e8 + 300.0, band="2")]
+    cth4 = (2000.0 + 9000.0 * rng.rand(ny // 4, nx // 4)).astype(np.float32)
+    cth4.tofile(cb)
+    subprocess.check_call([io_demo, "--make-cth", str(fc), str(nx // 4), str(ny // 4), str(cb)])
+    r = subprocess.run([os.path.join(LIBD, "octane"), "-i1", str(g[0]), "-i2", str(g[1]), "-i1cth", str(fc), "-o", outdir, "-kiters", "2"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "outfile.nc written" in r.stdout, r.stdout + r.stderr
+    up = np.zeros((ny, nx), np.float32)
+    zi(cth4, up, nx // 4, ny // 4, nx, ny, 0, 1)
+    d = _dump(io_demo, out)
+    assert d["CTP"]["type"] == "i2" and float(d["CTP"]["atts"]["interpcth"]) == 1.0
+    assert np.array_equal(_read(io_demo, out, "CTP", "short", tmp_path).reshape(ny, nx), up.astype(np.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("proj", ["polar", "merc"])
+def test_octane_command_line_on_remapped_images(io_demo, capi, tmp_path, proj):
+    """-Polar / -Merc: float Rad passes through, navigation is the projection's, outfile_polar.nc holds the pixel
+    displacements as doubles, outfile_merc.nc the navigated winds x 100 as doubles with scale_factor 0.01."""
+    nx, ny = 192, 128
+    a, b = synth.lattice_scene(nx, ny, seed=41)
+    a, b = a[0], b[0]
+    if proj == "polar":
+        geo = dict(xs=4000.0, xo=-384000.0, ys=-4000.0, yo=256000.0, lon=-45.0, lat1=70.0, R=6371228.0)
+    else:
+        geo = dict(xs=4000.0, xo=-384000.0, ys=-4000.0, yo=3500000.0, lon=-100.0, lat1=0.0, R=6378137.0)
+    files = []
+    for i, (img, t) in enumerate(((a, 7.1e8), (b, 7.1e8 + 600.0))):
+        raw = tmp_path / f"p{i}.bin"
+        img.astype(np.float32).tofile(raw)
+        f = tmp_path / f"p{i}.nc"
+        subprocess.check_call([io_demo, "--make-proj", str(f), proj, str(nx), str(ny), str(raw), repr(t), repr(geo["xs"]), repr(geo["xo"]),
+                               repr(geo["ys"]), repr(geo["yo"]), repr(geo["lon"]), repr(geo["lat1"]), repr(geo["R"])])
+        files.append(f)
+    outdir = str(tmp_path) + "/"
+    flag = "-Polar" if proj == "polar" else "-Merc"
+    name = "outfile_polar.nc" if proj == "polar" else "outfile_merc.nc"
+    r = subprocess.run([os.path.join(LIBD, "octane"), "-i1", str(files[0]), "-i2", str(files[1]), flag, "-o", outdir, "-kiters", "3"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and name + " written" in r.stdout, r.stdout + r.stderr
+    out = tmp_path / name
+    d = _dump(io_demo, out)
+    x = np.arange(nx, dtype=np.int16); y = np.arange(ny, dtype=np.int16)
+    mode = capi.NAV_POLAR if proj == "polar" else capi.NAV_MERC
+    pk = capi.ProjNavcalParams(xScale=geo["xs"], xOffset=geo["xo"], yScale=geo["ys"], yOffset=geo["yo"], lon0=geo["lon"], lat1=geo["lat1"],
+                               R=geo["R"], donav=1, mode=mode, minx=0, maxx=nx, miny=0, maxy=ny)
+    im1 = capi.proj_navcal(a, x, y, pk)[0]
+    im2 = capi.proj_navcal(b, x, y, pk)[0]
+    assert np.array_equal(im1, a.astype(np.float32))                      # re-mapped images are already calibrated
+    u, v = capi.flow(im1, im2, capi.FlowParams(kiters=3))
+    assert np.abs(u).mean() > 0.3
+    gu = _read(io_demo, out, "U", "double", tmp_path).reshape(ny, nx)
+    gv = _read(io_demo, out, "V", "double", tmp_path).reshape(ny, nx)
+    assert d["U"]["type"] == "f8" and d["Rad"]["type"] == "f4"
+    assert np.array_equal(_read(io_demo, out, "Rad", "float", tmp_path).reshape(ny, nx), im1)
+    if proj == "polar":
+        assert np.array_equal(gu, u.astype(np.float64)) and np.array_equal(gv, v.astype(np.float64))
+        assert d["U"]["atts"]["grid_mapping"] == "polar_orthonormal" and d["U"]["atts"]["units"] == "meters per second"
+        p = d["polar_imager_projection"]["atts"]
+        assert float(p["lat1"]) == 70.0 and float(p["lon0"]) == -45.0 and abs(float(p["R"]) - 6371228.0) < 1.0
+        assert _read(io_demo, out, "polar_imager_projection", "int", tmp_path)[0] == 7
+    else:
+        nav = capi.Nav(xScale=geo["xs"], xOffset=geo["xo"], yScale=geo["ys"], yOffset=geo["yo"], g2xOffset=geo["xo"], g2yOffset=geo["yo"],
+                       lon1=geo["lon"], R=geo["R"], nx=nx, ny=ny)
+        want = capi.pix2uv(nav, 7.1e8, 7.1e8 + 600.0, u, v, mode=capi.NAV_MERC)
+        assert np.abs(want[0]).max() > 100                                 # several m/s somewhere
+        assert np.array_equal(gu, want[0].astype(np.float64)) and np.array_equal(gv, want[1].astype(np.float64))
+        assert abs(float(d["U"]["atts"]["scale_factor"]) - 0.01) < 1e-9 and d["U"]["atts"]["grid_mapping"] == "Mercator Sphere"
+        assert abs(float(d["merc_imager_projection"]["atts"]["lon1"]) + 100.0) < 1e-6
+    s = d["optical_flow_settings"]["atts"]
+    assert s["K_Iterations"] == "3" and abs(float(s["dt_seconds"]) - 600.0) < 1e-3
