@@ -970,7 +970,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
 //             tile groups also update x and store r_k, p_k
 //   phase 2   tile groups: q_k (stencil on the second LDS tile) and the seven partial sums; q_k is NOT stored
 // Everything else (scalars from the previous launch's sums, double-buffered r / partials, triple-buffered p, deferred x)
-// is k_pcg_fused's.  Row bands keep k_pcg_fused: the ring of a band edge would need two rows of the neighbour's p.
+// is k_pcg_fused's.  In row bands (BANDED) the two rows beyond a band edge are read from the neighbour's planes in place.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kQTY = 2 * kTileY;            // 16 tile rows
 constexpr int kQCols = kTileX + 16;         // LDS row: 8 floats of margin either side of the 128 tile columns
@@ -1010,7 +1010,7 @@ __device__ __forceinline__ void stencil_group(const float *s_u, const float *s_v
     }
 }
 
-template <bool UNITW>
+template <bool UNITW, bool BANDED>
 __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int nparts_prev, float tol)
 {
     constexpr int TY = kQTY, TX = kTileX;
@@ -1051,7 +1051,12 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
     if (first && !active) return;
 
     const int w = L.w, h = L.h, pitch = L.pitch;
-    const int tiles_x = (w + TX - 1) / TX, tiles_y = (h + TY - 1) / TY;
+    // Row bands (BANDED): the tiles cover the band's own rows [y0, y1); what a tile needs from the two rows beyond a band
+    // edge -- r_{k-1} on the ring row, p_{k-1} on the ring row and the one after -- is read in place from the neighbouring
+    // band's planes, which the previous launch completed (one phase boundary per iteration).  The operator on the ring
+    // row is this band's own (the assembly covers one halo row), except wy of the row above the upper ring row.
+    const int y0 = BANDED ? L.y0 : 0, y1 = BANDED ? L.y1 : h;
+    const int tiles_x = (w + TX - 1) / TX, tiles_y = (y1 - y0 + TY - 1) / TY;
     const int ntiles = tiles_x * tiles_y;
     const int ko = (k + 1) & 1, kn = k & 1;
     const float *__restrict__ rin_u = first ? L.rb_u[0] : L.rb_u[ko];
@@ -1073,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
 
     const ItemRange tr = item_range_walk(ntiles, L.xcd_bands);
     for (int t = tr.first; t < tr.end; t += tr.step) {
-        const int tx0 = (t % tiles_x) * TX, ty0 = (t / tiles_x) * TY;
+        const int tx0 = (t % tiles_x) * TX, ty0 = y0 + (t / tiles_x) * TY;
         // ---- loads of the thread's two tile groups first (r_{k-1} and the operator; addresses of groups beyond a ragged
         // edge are clamped into the frame, their values never used), so that they are in flight while phase 0 waits for p
         QCoef c3[2];
@@ -1082,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
         for (int slot = 0; slot < 2; slot++) {
             const int gx = tid & 31, gy = (tid >> 5) + kTileY * slot;
             const int x0 = tx0 + 4 * gx, y = ty0 + gy;
-            const bool valid = y < h && x0 < w;
+            const bool valid = y < y1 && x0 < w;
             const unsigned o = valid ? (unsigned)(y * pitch + x0) * 4u : 0u;
             QCoef &c = c3[slot];
             *(float4 *)r3u[slot] = ld4(at(rin_u, o)); *(float4 *)r3v[slot] = ld4(at(rin_v, o));
@@ -1107,7 +1112,9 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                 float4 pu = make_float4(0, 0, 0, 0), pv = pu;
                 if (y >= 0 && y < h && x0 >= 0 && x0 < w) {
                     const unsigned o = (unsigned)(y * pitch + x0) * 4u;
-                    pu = ld4(at(pin_u, o)); pv = ld4(at(pin_v, o));   // planes are padded to a multiple of 64 floats: in bounds
+                    if (BANDED && y < y0) { pu = ld4(at(L.pup_u[(k + 2) % 3], o)); pv = ld4(at(L.pup_v[(k + 2) % 3], o)); }
+                    else if (BANDED && y >= y1) { pu = ld4(at(L.pdn_u[(k + 2) % 3], o)); pv = ld4(at(L.pdn_v[(k + 2) % 3], o)); }
+                    else { pu = ld4(at(pin_u, o)); pv = ld4(at(pin_v, o)); }   // planes are padded to a multiple of 64 floats: in bounds
                     if (x0 + 3 >= w) {                            // beyond the frame's last column: zero, as the other forms do
                         if (x0 + 1 >= w) { pu.y = 0.f; pv.y = 0.f; }
                         if (x0 + 2 >= w) { pu.z = 0.f; pv.z = 0.f; }
@@ -1132,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
             else if (tid < 100) { gx = TX / 4; gy = tid - 84; }
             else { gx = 0; gy = -9; }                              // no ring group for this thread
             const int x0 = tx0 + 4 * gx, y = ty0 + gy;
-            const bool valid = (gy >= -1) && y >= 0 && y < h && x0 >= 0 && x0 < w;
+            const bool valid = (gy >= -1) && y >= 0 && y < h && x0 >= 0 && x0 < w && (!own || y < y1);
             QCoef cr;
             float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0}, pnu[4] = {0, 0, 0, 0}, pnv[4] = {0, 0, 0, 0};
             if (!own) {
@@ -1141,7 +1148,10 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                 cr.wxw = 0.f;
                 if (valid) {
                     const unsigned o = (unsigned)(y * pitch + x0) * 4u;
-                    *(float4 *)ru = ld4(at(rin_u, o)); *(float4 *)rv = ld4(at(rin_v, o));
+                    const int kr = first ? 0 : ko;
+                    if (BANDED && y < y0) { *(float4 *)ru = ld4(at(L.rup_u[kr], o)); *(float4 *)rv = ld4(at(L.rup_v[kr], o)); }
+                    else if (BANDED && y >= y1) { *(float4 *)ru = ld4(at(L.rdn_u[kr], o)); *(float4 *)rv = ld4(at(L.rdn_v[kr], o)); }
+                    else { *(float4 *)ru = ld4(at(rin_u, o)); *(float4 *)rv = ld4(at(rin_v, o)); }
                     *(float4 *)cr.a1 = ld4(at(L.a1, o)); *(float4 *)cr.a4 = ld4(at(L.a4, o));
                     *(float4 *)cr.a2 = ld4(at(L.a2, o));
                     if (UNITW) {
@@ -1150,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                         cr.wxw = -1.f;
                     } else {
                         *(float4 *)cr.wx = ld4(at(L.wx, o)); *(float4 *)cr.wy = ld4(at(L.wy, o));
-                        if (y > 0) *(float4 *)cr.wys = ld4(at(L.wy, o - 4u * (unsigned)pitch));
+                        if (y > 0) *(float4 *)cr.wys = ld4(at((BANDED && y < y0) ? L.wy_up : L.wy, o - 4u * (unsigned)pitch));
                         if (x0 > 0) cr.wxw = *at(L.wx, o - 4u);
                     }
                 }
@@ -1210,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
             for (int slot = 0; slot < 2; slot++) {
                 const int gx = tid & 31, gy = (tid >> 5) + kTileY * slot;
                 const int x0 = tx0 + 4 * gx, y = ty0 + gy;
-                if (y < h && x0 < w) {
+                if (y < y1 && x0 < w) {
                     float qu[4], qv[4];
                     stencil_group(s_nu, s_nv, gy + 1, kQOff + 4 * gx, x0, y, w, h, c3[slot], qu, qv);
                     float pku[4], pkv[4];
@@ -1564,20 +1574,20 @@ void set_fused_rows(int r) { g_fused_r = (r == 1 || r == 2) ? r : 0; }
 static int fused_rows(int w, int rows) { return g_fused_r ? g_fused_r : (((long)w * rows < (1L << 20)) ? 1 : 2); }
 // q is recomputed where that pays: from about 4 M pixels (measured, tools/probe_forms.py: 1250^2 33 -> 35 us, 2500^2 112 -> 109 us,
 // 5000^2 395 -> 369 us); below, the level sits in the Infinity Cache and the extra ring work costs more than q's traffic
-static bool fused_q_form(int w, int rows, bool banded)
+int pcg_fused_q_form(int w, int rows, int h)
 {
-    return g_fused_q && !banded && fused_rows(w, rows) == 2 && (long)w * rows >= (1L << 22) &&
-           (long)(w + 64) * rows < (1L << 30);            // 32-bit byte offsets inside a plane
+    return g_fused_q && fused_rows(w, rows) == 2 && (long)w * rows >= (1L << 22) &&
+           (long)(w + 64) * h < (1L << 30);               // 32-bit byte offsets inside a plane
 }
 
-int pcg_fused_grid_size(int w, int rows, int unit_w, int banded)
+int pcg_fused_grid_size(int w, int rows, int unit_w, int q_form)
 {
     const int R = fused_rows(w, rows);                                // small levels: more, smaller tiles
     const long items = (long)((w + kTileX - 1) / kTileX) * ((rows + kTileY * R - 1) / (kTileY * R));
     // never more workgroups than are resident at once (a second wave of a persistent grid runs on a half-empty chip):
     // 128 x 16 tiles need 180 / 163 VGPRs (2 / 3 workgroups per CU), 128 x 8 tiles 135 / 122 (3 / 4)
-    // (the q-recomputing form of the 128 x 16 tile: 207 / 229 VGPRs and 44 KB of LDS, 2 per CU)
-    const bool qform = fused_q_form(w, rows, banded != 0);
+    // (the q-recomputing form of the 128 x 16 tile: 199 / 227 VGPRs and 44 KB of LDS, 2 per CU)
+    const bool qform = q_form && R == 2;
     const long cap = 256 * (R == 2 ? ((unit_w && !qform) ? 3 : 2) : (unit_w ? 4 : 3));
     if (items <= cap) return (int)(items < 1 ? 1 : items);
     const long rounds = (items + cap - 1) / cap;
@@ -1590,12 +1600,17 @@ void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev,
 {
     const bool small = fused_rows(L.w, L.y1 - L.y0) == 1;
     const bool whole = L.nbands == 1 && L.y0 == 0 && L.y1 == L.h;
-    if (small) {
+    if (L.q_form) {                                                    // q = A p is not stored but formed again
+        if (whole) {
+            if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused_q<true, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+            else hipLaunchKernelGGL((k_pcg_fused_q<false, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        } else {
+            if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused_q<true, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+            else hipLaunchKernelGGL((k_pcg_fused_q<false, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        }
+    } else if (small) {
         if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused<1, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
         else hipLaunchKernelGGL((k_pcg_fused<1, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-    } else if (fused_q_form(L.w, L.h, !whole)) {                        // plain plan: do not store q, form it again
-        if (L.unit_w) hipLaunchKernelGGL(k_pcg_fused_q<true>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-        else hipLaunchKernelGGL(k_pcg_fused_q<false>, dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
     } else {
         if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused<2, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
         else hipLaunchKernelGGL((k_pcg_fused<2, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);

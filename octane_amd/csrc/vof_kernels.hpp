@@ -60,6 +60,11 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     float *pf_u[3], *pf_v[3];       // p of the fused kernel: p_k in pf[k % 3]; three halves because with defer_x every second
                                     // launch applies two x updates at once and reads p_{k-2} besides p_{k-1}
     const float *qup_u[2], *qup_v[2], *qdn_u[2], *qdn_v[2];   // the q planes rows y0-1 / y1 are read from (neighbouring bands)
+    // q-recomputing fused PCG in row bands: the neighbours' planes, read in place on the two rows beyond a band edge
+    const float *rup_u[2], *rup_v[2], *rdn_u[2], *rdn_v[2];   // r double buffer of the band above / below
+    const float *pup_u[3], *pup_v[3], *pdn_u[3], *pdn_v[3];   // p triple buffer of the band above / below
+    const float *wy_up;                                       // wy of the band above (its row y0 - 2 is not assembled here)
+    int q_form;                     // the host's choice for this level: 1 = k_pcg_fused_q (q recomputed), 0 = q stored
     // Row band of the level this launch works on (vof_tiled.hip); a plain plan has one band covering the frame.
     // Planes are always addressed with frame coordinates: a band's neighbours' rows exist in its planes as halos.
     int y0, y1;                     // rows this band owns: PCG passes, flow update and the dot products cover [y0, y1)
@@ -114,7 +119,8 @@ void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, i
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int niter_launched);
 void set_fused_q(int v);                     // tuning: the q-recomputing form of the fused kernel on large levels
 void set_fused_rows(int r);                  // tuning: tile rows of the fused kernel (0 = by level size)
-int  pcg_fused_grid_size(int w, int rows, int unit_w, int banded = 0);   // fused one-kernel-per-iteration PCG (pcg_kernels.hip)
+int  pcg_fused_q_form(int w, int rows, int h);            // 1: a level / band of this size recomputes q (pcg_kernels.hip)
+int  pcg_fused_grid_size(int w, int rows, int unit_w, int q_form);   // fused one-kernel-per-iteration PCG
 void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 void launch_flow_update_fused(hipStream_t s, const LevelPtrs &L, int niter_launched, int nparts);
 bool pcg_small_applicable(int w, int h);

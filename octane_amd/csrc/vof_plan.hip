@@ -111,6 +111,10 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
     for (int i = 0; i < 2; i++) { L.qup_u[i] = L.qdn_u[i] = L.qb_u[i]; L.qup_v[i] = L.qdn_v[i] = L.qb_v[i]; }
     L.pf_u[0] = pl->pu[0]; L.pf_u[1] = pl->pu[1]; L.pf_u[2] = pl->pu3;
     L.pf_v[0] = pl->pv[0]; L.pf_v[1] = pl->pv[1]; L.pf_v[2] = pl->pv3;
+    for (int i = 0; i < 2; i++) { L.rup_u[i] = L.rdn_u[i] = L.rb_u[i]; L.rup_v[i] = L.rdn_v[i] = L.rb_v[i]; }
+    for (int i = 0; i < 3; i++) { L.pup_u[i] = L.pdn_u[i] = L.pf_u[i]; L.pup_v[i] = L.pdn_v[i] = L.pf_v[i]; }
+    L.wy_up = pl->wy;
+    L.q_form = 0;
     L.y0 = 0; L.y1 = li.h; L.ya0 = 0; L.ya1 = li.h; L.nbands = 1;
     L.st = pl->d_state; L.iter_total = pl->d_iters; L.alpha = pl->d_alpha; L.defer_x = pl->defer_x;
     L.reverse_b = pl->reverse_b;
@@ -143,7 +147,8 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
     LevelPtrs L;
     fill_level_ptrs(pl, li, 0, pl->img1p, pl->img2p, pl->uh, pl->vh, L);
     const int g_a = pcg_grid_size(li.w, li.h), g_b = pcg_b_grid_size(li.w, li.h);
-    const int g_f = pcg_fused_grid_size(li.w, li.h, 0);
+    L.q_form = pcg_fused_q_form(li.w, li.h, li.h);
+    const int g_f = pcg_fused_grid_size(li.w, li.h, 0, L.q_form);
     const bool fused = pl->use_fused && !(a_ms && b_ms);      // the split timing is defined for the two-pass form only
     // sums that keep the stop test open and every scalar finite whatever the planes hold: with all seven sums equal
     // to 1 the fused kernel's recurrences give alpha = 1, r.z = 0, r.r = 0 + ... -> use values that stay positive
@@ -516,7 +521,8 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
     fill_level_ptrs(pl, li, cur, c.lev1, c.lev2, c.ut, c.vt, L);
 
     const int g_asm = assemble_grid_size(li.w, li.h);
-    const int g_f_plain = pcg_fused_grid_size(li.w, li.h, 0), g_f_unit = pcg_fused_grid_size(li.w, li.h, 1);
+    L.q_form = pcg_fused_q_form(li.w, li.h, li.h);
+    const int g_f_plain = pcg_fused_grid_size(li.w, li.h, 0, L.q_form), g_f_unit = pcg_fused_grid_size(li.w, li.h, 1, L.q_form);
     const int g_a_plain = pcg_grid_size(li.w, li.h);
     const int g_a_unit = pcg_grid_size_unit_w(li.w, li.h);
     const int g_b = pcg_b_grid_size(li.w, li.h);

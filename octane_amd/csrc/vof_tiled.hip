@@ -14,13 +14,14 @@
 //     them would cost more than it saves) -- every band then holds the same bits;
 //   * on the banded levels a band owns rows [y0, y1) (multiples of kBandAlign).  Its assembly also fills rows y0-1
 //     and y1, so the coefficients, the preconditioner and the initial residual of the halo rows are bit-identical
-//     copies of the owner's without an exchange; pass A keeps its own copy of p on those rows current
-//     (pcg_kernels.hip).  What crosses bands per PCG iteration is READ IN PLACE by the consuming kernel through
-//     peer-mapped pointers, not copied: the per-workgroup partials of the two reductions ({p.q} written by pass A,
-//     {r.z, r.r} by pass B: every band folds all bands' partials in the same order and so takes the same alpha, beta
-//     and stop decision) and ONE row of r per inner edge (pass A reads it from the neighbour's plane).  Copied, per
-//     linearisation: two rows of u, v per inner edge; per level: the bands of the flow, all-gathered for the next
-//     level's up-sampling.
+//     copies of the owner's without an exchange.  What crosses bands per PCG iteration is READ IN PLACE by the
+//     consuming kernel through peer-mapped pointers, not copied: the per-workgroup partial sums (every band folds all
+//     bands' partials in the same order and so takes the same alpha, beta and stop decision) and a few rows per inner
+//     edge -- fused kernel, bands of >= 2^22 pixels (q recomputed): r on the row beyond the edge, p on the two rows
+//     beyond it, wy of the row above the upper one; fused kernel, smaller bands (q stored; halo rows of r and p kept
+//     current locally): one row of q; two-pass form: one row of r, pass A keeps its own copy of p on the halo rows
+//     (pcg_kernels.hip).  Copied, per linearisation: two rows of u, v per inner edge; per level: the bands of the flow,
+//     all-gathered for the next level's up-sampling.
 //
 // Ordering: every cross-band read is made by a kernel launched after an event wait on the producing band's stream,
 // i.e. after the producing kernel completed -- the visibility point HIP defines for device memory shared between
@@ -311,11 +312,24 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
     const int g_a = pcg_band_grid_size(li.w, maxrows);
     const int g_b = pcg_b_grid_size(li.w, maxrows);
     const bool fused = pl->use_fused != 0;
-    if (fused)          // q of the neighbouring bands' edge rows is read from their planes (both halves of the double buffer)
+    // one form of the fused kernel for all bands (they read each other's planes): decided on the largest band
+    L.q_form = (fused && pcg_fused_q_form(li.w, maxrows, li.h)) ? 1 : 0;
+    if (fused && !L.q_form)   // q of the neighbouring bands' edge rows is read from their planes (both halves of the double buffer)
         for (int i = 0; i < 2; i++) {
             L.qup_u[i] = N.peer(up, b, L.qb_u[i]); L.qup_v[i] = N.peer(up, b, L.qb_v[i]);
             L.qdn_u[i] = N.peer(dn, b, L.qb_u[i]); L.qdn_v[i] = N.peer(dn, b, L.qb_v[i]);
         }
+    if (L.q_form) {           // q is recomputed: r on the row beyond an edge, p on the two rows beyond it, wy of the row above the upper one
+        for (int i = 0; i < 2; i++) {
+            L.rup_u[i] = N.peer(up, b, L.rb_u[i]); L.rup_v[i] = N.peer(up, b, L.rb_v[i]);
+            L.rdn_u[i] = N.peer(dn, b, L.rb_u[i]); L.rdn_v[i] = N.peer(dn, b, L.rb_v[i]);
+        }
+        for (int i = 0; i < 3; i++) {
+            L.pup_u[i] = N.peer(up, b, L.pf_u[i]); L.pup_v[i] = N.peer(up, b, L.pf_v[i]);
+            L.pdn_u[i] = N.peer(dn, b, L.pf_u[i]); L.pdn_v[i] = N.peer(dn, b, L.pf_v[i]);
+        }
+        L.wy_up = N.peer(up, b, pl->wy);
+    }
 
     for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
         AssembleParams ap;
@@ -326,7 +340,7 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
         ap.dozim = prm.dozim != 0;
         L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;
         L.lean = fused ? 1 : 0;
-        const int g_f = pcg_fused_grid_size(li.w, maxrows, L.unit_w, 1);
+        const int g_f = pcg_fused_grid_size(li.w, maxrows, L.unit_w, L.q_form);
         for (int l = 0; l < prm.liters; l++) {          // ref .cu:608
             if (!N.failed()) {
                 LevelPtrs La = L;

@@ -173,3 +173,25 @@ def test_full_disk_quarter_scale_four_bands(capi):
     tp.close()
     assert np.isfinite(ut).all() and np.isfinite(vt).all()
     assert rel_l2(ut, vt, up, vp) < ORDER_BAR
+
+
+@pytest.mark.parametrize("nbands", [2, 3])
+def test_bands_above_four_megapixels_recompute_q(capi, oracle, nbands):
+    """Bands of 2^22 pixels and more run the q-recomputing fused kernel: nothing is stored on halo rows, a band reads r on
+    the row beyond its edge and p on the two rows beyond it from the neighbour's planes.  The coarser level of the same
+    plan keeps the stored-q form, so both exchange schemes run in one solve.  Checked against the plain plan (same
+    kernels, one band) and, on a single level, against the oracle."""
+    nx = 2432
+    ny = 1792 * nbands                       # 4.36 Mpixel per band at the finest level
+    a, b = synth.lattice_scene(nx, ny, seed=61)
+    prm = dict(kiters=2, liters=1, cgiters=9)
+    up, vp, ip = _plain(capi, a, b, prm)
+    ut, vt, info = _tiled(capi, a, b, prm, nbands)
+    assert info["banded"] == 2 and info["its"] == ip
+    assert np.isfinite(ut).all()
+    assert rel_l2(ut, vt, up, vp) < ORDER_BAR
+    if nbands == 2:
+        prm1 = dict(kiters=1, liters=1, cgiters=5)
+        ut, vt, info = _tiled(capi, a, b, prm1, nbands)
+        uo, vo, _ = oracle.flow(a, b, oracle.FlowParams(**prm1), flavour="omp", dot_threads=oracle.REF_GRID_THREADS)
+        assert rel_l2(ut, vt, uo, vo) < ORDER_BAR
