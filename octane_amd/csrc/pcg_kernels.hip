@@ -1574,9 +1574,11 @@ void set_fused_rows(int r) { g_fused_r = (r == 1 || r == 2) ? r : 0; }
 static int fused_rows(int w, int rows) { return g_fused_r ? g_fused_r : (((long)w * rows < (1L << 20)) ? 1 : 2); }
 // q is recomputed where that pays: from about 4 M pixels (measured, tools/probe_forms.py: 1250^2 33 -> 35 us, 2500^2 112 -> 109 us,
 // 5000^2 395 -> 369 us); below, the level sits in the Infinity Cache and the extra ring work costs more than q's traffic
+static long g_fused_q_min = 1L << 22; // pixels from which q is recomputed
+void set_fused_q_min(long px) { g_fused_q_min = px > 0 ? px : (1L << 22); }
 int pcg_fused_q_form(int w, int rows, int h)
 {
-    return g_fused_q && fused_rows(w, rows) == 2 && (long)w * rows >= (1L << 22) &&
+    return g_fused_q && fused_rows(w, rows) == 2 && (long)w * rows >= g_fused_q_min &&
            (long)(w + 64) * h < (1L << 30);               // 32-bit byte offsets inside a plane
 }
 

@@ -244,6 +244,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_FUSED")) pl->use_fused = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_FUSED_ROWS")) set_fused_rows(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_FUSED_Q")) set_fused_q(atoi(e));
+    if (const char *e = getenv("OCTANE_TUNE_FUSED_Q_MIN")) set_fused_q_min(atol(e));
     if (const char *e = getenv("OCTANE_TUNE_UNIT_W_CAP")) set_unit_w_cap(atoi(e));
     {
         const char *ea = getenv("OCTANE_TUNE_CAP_A"), *eb = getenv("OCTANE_TUNE_CAP_B");
