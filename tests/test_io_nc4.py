@@ -327,3 +327,47 @@ def test_octane_command_line_on_remapped_images(io_demo, capi, tmp_path, proj):
         assert abs(float(d["merc_imager_projection"]["atts"]["lon1"]) + 100.0) < 1e-6
     s = d["optical_flow_settings"]["atts"]
     assert s["K_Iterations"] == "3" and abs(float(s["dt_seconds"]) - 600.0) < 1e-3
+
+
+@pytest.mark.gpu
+def test_octane_command_line_three_channels_finer_and_coarser(io_demo, capi, tmp_path):
+    """-ic21/-ic22 on a grid twice as FINE as channel 1 (blurred and decimated, oct_zoom_out_float) and -ic31/-ic32 on one
+    twice as coarse (oct_zoom_in_float): three planes reach the solver, each calibrated with its own band's range."""
+    nx, ny = 160, 128
+    c1, c2 = _counts(nx, ny, 51)
+    f1, f2 = _counts(2 * nx, 2 * ny, 52)                                 # band 2-like resolution, band 7 constants
+    h1, h2 = _counts(nx // 2, ny // 2, 53)
+    f = [_make_goes(io_demo, tmp_path, "a1", c1, 7.1e8), _make_goes(io_demo, tmp_path, "a2", c2, 7.1e8 + 300.0),
+         _make_goes(io_demo, tmp_path, "b1", f1, 7.1e8, band="7", smul=0.5), _make_goes(io_demo, tmp_path, "b2", f2, 7.1e8 + 300.0, band="7", smul=0.5),
+         _make_goes(io_demo, tmp_path, "c1", h1, 7.1e8, band="14", smul=2.0), _make_goes(io_demo, tmp_path, "c2", h2, 7.1e8 + 300.0, band="14", smul=2.0)]
+    outdir = str(tmp_path) + "/"
+    r = subprocess.run([os.path.join(LIBD, "octane"), "-i1", str(f[0]), "-i2", str(f[1]), "-ic21", str(f[2]), "-ic22", str(f[3]),
+                        "-ic31", str(f[4]), "-ic32", str(f[5]), "-o", outdir, "-pd", "-kiters", "3"], capture_output=True, text=True)
+    assert r.returncode == 0 and "outfile.nc written" in r.stdout, r.stdout + r.stderr
+    out = tmp_path / "outfile.nc"
+    zi, zo = _host_zoom()
+    grids = [(nx, ny, 1.0, 13), (2 * nx, 2 * ny, 0.5, 7), (nx // 2, ny // 2, 2.0, 14)]
+    imgs = []
+    for counts, donav in (((c1, f1, h1), 1), ((c2, f2, h2), 0)):
+        three = np.zeros((3, ny, nx), np.float32)
+        for ch, (cnt, (gx, gy, smul, band)) in enumerate(zip(counts, grids)):
+            mx, mn = capi.bandminmax(band)
+            kw = dict(GOES_KW, xScale=np.float32(5.6e-05) * np.float32(smul), xOffset=-0.031332, yScale=np.float32(-5.6e-05) * np.float32(smul),
+                      yOffset=0.081212, maxin=mx, minin=mn, minx=0, maxx=gx, miny=0, maxy=gy)
+            img = np.ascontiguousarray(capi.navcal(cnt, np.arange(gx, dtype=np.int16), np.arange(gy, dtype=np.int16),
+                                                   capi.NavcalParams(donav=donav, **kw))[0])
+            if ch == 0:
+                three[0] = img
+            elif gx > nx:
+                zo(img, three, gx, gy, nx / gx, 0, ch)
+            else:
+                zi(img, three, gx, gy, nx, ny, ch, 1)
+        imgs.append(three)
+    assert all(imgs[0][c].std() > 1.0 for c in range(3))
+    u, v = capi.flow(imgs[0], imgs[1], capi.FlowParams(kiters=3))
+    assert np.array_equal(_read(io_demo, out, "Upix", "float", tmp_path).reshape(ny, nx), u)
+    assert np.array_equal(_read(io_demo, out, "Vpix", "float", tmp_path).reshape(ny, nx), v)
+    # a third channel without a second one is refused (the reference would write past its buffer)
+    r = subprocess.run([os.path.join(LIBD, "octane"), "-i1", str(f[0]), "-i2", str(f[1]), "-ic31", str(f[4]), "-ic32", str(f[5]), "-o", outdir],
+                       capture_output=True, text=True)
+    assert "needs a second one" in r.stdout
