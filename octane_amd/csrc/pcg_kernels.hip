@@ -1015,7 +1015,10 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
 {
     constexpr int TY = kQTY, TX = kTileX;
     __shared__ __attribute__((aligned(16))) float s_ou[(TY + 4) * kQCols], s_ov[(TY + 4) * kQCols];   // p_{k-1}: rows ty0-2 .. ty0+TY+1
-    __shared__ __attribute__((aligned(16))) float s_nu[(TY + 2) * kQCols], s_nv[(TY + 2) * kQCols];   // p_k:     rows ty0-1 .. ty0+TY
+    // p_k: rows ty0-1 .. ty0+TY, two buffers used alternately -- a workgroup's fast waves may stage and compute the next tile
+    // while its slow ones still read this one's p_k in phase 2, which saves the barrier at the end of a tile
+    constexpr int NSZ = (TY + 2) * kQCols;
+    __shared__ __attribute__((aligned(16))) float s_nu2[2 * NSZ], s_nv2[2 * NSZ];
     __shared__ double s_red[4 * kPartKinds];
     const int tid = threadIdx.x;
     const bool first = (k == 0);
@@ -1077,7 +1080,9 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
     double acc_pq = 0., acc_qz = 0., acc_qmq = 0., acc_rq = 0., acc_qq = 0., acc_rz = 0., acc_rr = 0.;
 
     const ItemRange tr = item_range_walk(ntiles, L.xcd_bands);
-    for (int t = tr.first; t < tr.end; t += tr.step) {
+    int parity = 0;
+    for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1) {
+        float *const s_nu = s_nu2 + parity * NSZ, *const s_nv = s_nv2 + parity * NSZ;
         const int tx0 = (t % tiles_x) * TX, ty0 = y0 + (t / tiles_x) * TY;
         // ---- loads of the thread's two tile groups first (r_{k-1} and the operator; addresses of groups beyond a ragged
         // edge are clamped into the frame, their values never used), so that they are in flight while phase 0 waits for p
@@ -1245,7 +1250,6 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                 }
             }
         }
-        __syncthreads();
     }
     if (!active) return;
     double *own_blk = L.part_own + pout_off;
@@ -1588,7 +1592,7 @@ int pcg_fused_grid_size(int w, int rows, int unit_w, int q_form)
     const long items = (long)((w + kTileX - 1) / kTileX) * ((rows + kTileY * R - 1) / (kTileY * R));
     // never more workgroups than are resident at once (a second wave of a persistent grid runs on a half-empty chip):
     // 128 x 16 tiles need 180 / 163 VGPRs (2 / 3 workgroups per CU), 128 x 8 tiles 135 / 122 (3 / 4)
-    // (the q-recomputing form of the 128 x 16 tile: 199 / 227 VGPRs and 44 KB of LDS, 2 per CU)
+    // (the q-recomputing form of the 128 x 16 tile: 191 / 220 VGPRs and 65 KB of LDS, 2 per CU)
     const bool qform = q_form && R == 2;
     const long cap = 256 * (R == 2 ? ((unit_w && !qform) ? 3 : 2) : (unit_w ? 4 : 3));
     if (items <= cap) return (int)(items < 1 ? 1 : items);
