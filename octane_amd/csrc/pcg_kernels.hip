@@ -1597,7 +1597,9 @@ int pcg_fused_grid_size(int w, int rows, int unit_w, int q_form)
     const long cap = 256 * (R == 2 ? ((unit_w && !qform) ? 3 : 2) : (unit_w ? 4 : 3));
     if (items <= cap) return (int)(items < 1 ? 1 : items);
     const long rounds = (items + cap - 1) / cap;
-    int g = (int)((items + rounds - 1) / rounds);
+    // stored-q forms: as many workgroups as give every one the same number of tiles; the q-recomputing form fills the chip
+    // and lets the last round run on fewer workgroups (measured on a kernel trace: -0.7 % over the two levels that use it)
+    int g = qform ? (int)cap : (int)((items + rounds - 1) / rounds);
     if (grid_multiple() > 1 && g >= 8 * grid_multiple()) g = g / grid_multiple() * grid_multiple();   // XCD bands want a multiple of 8
     return g;
 }
