@@ -288,6 +288,46 @@ def test_full_size_properties_2000(capi):
     assert torch.equal(u, u1) and torch.equal(v, v1)
 
 
+def test_headline_config_5000_three_forms_of_the_pcg_agree(capi):
+    """BASELINE.json's headline run: 5000 x 5000, 8 levels, 2160 PCG iterations.  No oracle at this size
+    in test time; instead the three independent forms of the PCG iteration this library has -- one kernel recomputing q
+    (the default on the two finest levels), one kernel storing q, and the two-pass form with its own kernels -- are run
+    on the same pair and have to agree, the recovered flow has to follow the analytic displacement field, and the
+    iteration count is the fixed kiters * 3 * liters * cgiters."""
+    import torch
+    n = 5000
+    a, b = synth.lattice_scene(n, n, seed=20240615, device="cuda")
+    pl = capi.Plan(n, n, 1, capi.FlowParams(kiters=8))
+    s = torch.cuda.current_stream().cuda_stream
+    res = {}
+    try:
+        for name, knobs in (("q", dict(fused=1, fused_q=1)), ("stored", dict(fused=1, fused_q=0)), ("two_pass", dict(fused=0, fused_q=1))):
+            for key, val in knobs.items():
+                pl.tune(key, val)
+            u = torch.zeros(n, n, device="cuda"); v = torch.zeros(n, n, device="cuda")
+            torch.cuda.synchronize()
+            pl.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert pl.last_iterations() == 8 * 3 * 3 * 30, name
+            assert bool(torch.isfinite(u).all()) and bool(torch.isfinite(v).all()), name
+            res[name] = (u, v)
+    finally:
+        pl.tune("fused", 1); pl.tune("fused_q", 1)
+        pl.close()
+
+    def dist(x, y):
+        num = ((x[0] - y[0]).double() ** 2).sum() + ((x[1] - y[1]).double() ** 2).sum()
+        den = (y[0].double() ** 2).sum() + (y[1].double() ** 2).sum()
+        return float(torch.sqrt(num / den))
+    assert dist(res["q"], res["stored"]) < INVESTIGATE
+    assert dist(res["q"], res["two_pass"]) < INVESTIGATE
+    tu, tv = synth.true_lattice_flow(n, n, xp=torch)
+    m = n // 8
+    eu = (res["q"][0].cpu().double() - tu)[m:-m, m:-m].abs().mean()
+    ev = (res["q"][1].cpu().double() - tv)[m:-m, m:-m].abs().mean()
+    assert eu < 0.05 and ev < 0.05, (eu, ev)
+
+
 def test_full_disk_frame_runs_on_one_gpu(capi):
     """BASELINE.json configs[3] shape: a 10848 x 10848 ABI full-disk pair.  The plan needs ~17 GB of the 288 GB, so
     the frame runs whole on ONE GPU (the reference's managed CSR would need 33 GB).  Properties only: the result is
