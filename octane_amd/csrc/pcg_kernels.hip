@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                         if (x_read) { *(float4 *)xu = ld4_if(at(L.xu, o), L.nt_hints & 1); *(float4 *)xv = ld4_if(at(L.xv, o), L.nt_hints & 1); }
                         if (x_two) {
                             float ou[4], ov[4];
-                            *(float4 *)ou = ld4(at(pin2_u, o)); *(float4 *)ov = ld4(at(pin2_v, o));
+                            *(float4 *)ou = ld4_nt(at(pin2_u, o)); *(float4 *)ov = ld4_nt(at(pin2_v, o));
 #pragma unroll
                             for (int e = 0; e < 4; e++) { xu[e] = alpha2 * ou[e] + xu[e]; xv[e] = alpha2 * ov[e] + xv[e]; }
                         }
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                     }
 #pragma unroll
                     for (int e = 0; e < 4; e++) { ru[e] = nalpha * qu[e] + ru[e]; rv[e] = nalpha * qv[e] + rv[e]; }    // ref .cu:1174
-                    if (own && active) { st4(at(rout_u, o), *(float4 *)ru); st4(at(rout_v, o), *(float4 *)rv); }
+                    if (own && active) { st4_nt(at(rout_u, o), *(float4 *)ru); st4_nt(at(rout_v, o), *(float4 *)rv); }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                     pnu[e] = ok ? direction(ru[e], pu[e], c.a1[e], beta, first) : 0.f;
                     pnv[e] = ok ? direction(rv[e], pv[e], c.a4[e], beta, first) : 0.f;
                 }
-                if (own && active) { st4(at(pout_u, o), *(float4 *)pnu); st4(at(pout_v, o), *(float4 *)pnv); }
+                if (own && active) { st4_nt(at(pout_u, o), *(float4 *)pnu); st4_nt(at(pout_v, o), *(float4 *)pnv); }
             }
             if (gy >= -1) {
                 st4(&s_nu[(gy + 1) * kQCols + kQOff + 4 * gx], *(float4 *)pnu);
