@@ -117,7 +117,7 @@ void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P,
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid);
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int niter_launched);
-void set_fused_q_min(long px);               // tuning: level size from which q is recomputed (default 2^22 pixels)
+void set_fused_q_min(long px);               // tuning: level size from which q is recomputed (default 3 * 2^20 pixels)
 void set_fused_q(int v);                     // tuning: the q-recomputing form of the fused kernel on large levels
 void set_fused_rows(int r);                  // tuning: tile rows of the fused kernel (0 = by level size)
 int  pcg_fused_q_form(int w, int rows, int h);            // 1: a level / band of this size recomputes q (pcg_kernels.hip)

@@ -17,7 +17,7 @@
 //     copies of the owner's without an exchange.  What crosses bands per PCG iteration is READ IN PLACE by the
 //     consuming kernel through peer-mapped pointers, not copied: the per-workgroup partial sums (every band folds all
 //     bands' partials in the same order and so takes the same alpha, beta and stop decision) and a few rows per inner
-//     edge -- fused kernel, bands of >= 2^22 pixels (q recomputed): r on the row beyond the edge, p on the two rows
+//     edge -- fused kernel, bands of >= 3 Mpixel (q recomputed): r on the row beyond the edge, p on the two rows
 //     beyond it, wy of the row above the upper one; fused kernel, smaller bands (q stored; halo rows of r and p kept
 //     current locally): one row of q; two-pass form: one row of r, pass A keeps its own copy of p on the halo rows
 //     (pcg_kernels.hip).  Copied, per linearisation: two rows of u, v per inner edge; per level: the bands of the flow,
