@@ -1,0 +1,67 @@
+"""Randomised parity sweep: HIP path against the oracle on random frame shapes, channel counts and solver parameters
+(first guess and hint term included), with the bar of tests/test_gpu_parity.py (2e-5, or twice the problem's own
+sensitivity to rounding as measured between the oracle's two builds).  A development tool, not part of the test suite:
+   python tools/fuzz_parity.py [cases] [seed]            needs a GPU; prints one line per case and a summary."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from octane_amd import capi, synth  # noqa: E402
+from oracle import oct_oracle as oo  # noqa: E402  (the checker)
+
+
+def rel_l2(u, v, ur, vr):
+    num = np.sum((u.astype(np.float64) - ur) ** 2) + np.sum((v.astype(np.float64) - vr) ** 2)
+    den = np.sum(ur.astype(np.float64) ** 2) + np.sum(vr.astype(np.float64) ** 2)
+    return float(np.sqrt(num / max(den, 1e-300)))
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    oo.build()
+    oo.set_threads(oo.host_cpu_share())
+    worst, bad = 0.0, 0
+    for case in range(ncases):
+        big = case % 10 == 9                       # every tenth case is large enough for the q-recomputing kernel
+        if big:
+            nx, ny, nc = int(rng.randint(1800, 2600)), int(rng.randint(1700, 2100)), 1
+            prm = dict(kiters=int(rng.randint(1, 3)), liters=1, cgiters=int(rng.randint(3, 9)))
+        else:
+            nx, ny, nc = int(rng.randint(40, 700)), int(rng.randint(40, 500)), int(rng.choice([1, 1, 2, 3]))
+            prm = dict(kiters=int(rng.randint(1, 5)), liters=int(rng.randint(1, 4)), cgiters=int(rng.randint(1, 31)),
+                       alpha=float(rng.choice([3.0, 5.0, 8.0])), lambda_=float(rng.choice([0.5, 1.0, 2.0])),
+                       dozim=int(rng.choice([0, 1])))
+        while min(nx, ny) * 0.5 ** (prm["kiters"] - 1) < 16:
+            prm["kiters"] -= 1
+        a, b = synth.lattice_scene(nx, ny, seed=int(rng.randint(1 << 30)), nchan=nc)
+        u0 = v0 = None
+        if not big and rng.rand() < 0.4:
+            prm["lambdac"] = float(rng.choice([0.0, 0.2, 0.5]))
+            u0 = (1.5 * rng.randn(ny, nx)).astype(np.float32)
+            v0 = (1.5 * rng.randn(ny, nx)).astype(np.float32)
+        P = oo.FlowParams(**prm)
+        g = oo.REF_GRID_THREADS
+        uo, vo, its_o = oo.flow(a, b, P, u0=u0, v0=v0, flavour="omp", dot_threads=g)
+        uf, vf, _ = oo.flow(a, b, P, u0=u0, v0=v0, flavour="fma", dot_threads=g)
+        floor = rel_l2(uf, vf, uo, vo)
+        pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm))
+        ug, vg = pl.run_host(a, b, u0, v0)
+        its_g = pl.last_iterations()
+        pl.close()
+        d = rel_l2(ug, vg, uo, vo)
+        bar = max(2e-5, 2.0 * floor)
+        ok = np.isfinite(ug).all() and d < bar and its_g == its_o
+        worst = max(worst, d / bar)
+        bad += 0 if ok else 1
+        print(f"{'ok ' if ok else 'BAD'} {nx}x{ny}x{nc} {prm} guess={u0 is not None}: {d:.2e} (floor {floor:.1e}, bar {bar:.1e}) its {its_g}/{its_o}", flush=True)
+    print(f"{ncases} cases, {bad} bad, worst distance / bar = {worst:.2f}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
