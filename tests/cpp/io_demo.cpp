@@ -5,6 +5,7 @@
 //   io_demo --make-proj out.nc polar|merc nx ny rad.bin t xs xo ys yo lon lat1 R    a re-mapped image (float Rad)
 //   io_demo --make-cth out.nc nx ny cth.bin                    cloud-top heights as CLAVR-x names them
 //   io_demo --make-fg out.nc nx ny uv.bin                     a first-guess file: UFG, VFG (float32 from uv.bin)
+//   io_demo --write-out out.nc GOES|POLAR|MERC nx ny nchan    runs oct_filewrite on a synthetic, fully populated GOESVar (no GPU)
 //   io_demo --dump file.nc                                    one line per variable: name|shape|att=value;...
 //   io_demo --read file.nc var type out.bin                   whole variable as short|int|float|double
 #include <cstdio>
@@ -14,8 +15,11 @@
 #include <vector>
 
 #include "nc4lite.hpp"
+#include "../../include/octane_host.hpp"
 
 using nc4lite::Type;
+
+int oct_filewrite(std::string, std::string, GOESVar &, OFFlags);
 
 int main(int argc, char **argv)
 {
@@ -119,6 +123,35 @@ int main(int argc, char **argv)
             w.put_var("UFG", uv.data()); w.put_var("VFG", uv.data() + (size_t)nx * ny);
             w.close();
             return 0;
+        }
+        if (argc == 7 && !strcmp(argv[1], "--write-out")) {
+            const std::string ftype = argv[3];
+            const int nx = atoi(argv[4]), ny = atoi(argv[5]), nc = atoi(argv[6]);
+            const size_t n = (size_t)nx * ny;
+            OFFlags args;
+            octane_default_flags(args);
+            args.ftype = ftype; args.oftype = 1; args.pixuv = 1; args.dosrsal = 1; args.outrad = true; args.putinterp = 0;
+            args.doc2 = nc >= 2; args.doc3 = nc >= 3;
+            GOESVar g;
+            g.nav.nx = nx; g.nav.ny = ny;
+            g.nav.xScale = 2000.f; g.nav.xOffset = -1000.f; g.nav.yScale = -2000.f; g.nav.yOffset = 3000.f;
+            g.nav.lat1 = 70.f; g.nav.lon0 = -45.f; g.nav.lon1 = -100.f; g.nav.R = 6371228.f; g.nav.gipVal = 7.f;
+            g.nav.radScale = 0.5f; g.nav.radOffset = -1.f; g.nav.g2xOffset = -1000.f; g.nav.g2yOffset = 3000.f;
+            g.nav.pph = 35786023.f; g.nav.req = 6378137.f; g.nav.rpol = 6356752.5f; g.nav.inverse_flattening = 298.25f; g.nav.lat0 = 0.f; g.nav.lpo = -75.f;
+            g.nav.fk1 = 1.f; g.nav.fk2 = 2.f; g.nav.bc1 = 3.f; g.nav.bc2 = 4.f; g.nav.kap1 = 5.f;
+            std::vector<short> x(nx), y(ny), sv(n), sv2(n);
+            std::vector<float> fu(n), fv(n), img(n * nc);
+            for (int i = 0; i < nx; i++) x[i] = (short)i;
+            for (int j = 0; j < ny; j++) y[j] = (short)j;
+            for (size_t i = 0; i < n; i++) { fu[i] = 0.25f * (float)i; fv[i] = -0.5f * (float)i; sv[i] = (short)(i % 1000); sv2[i] = (short)(-(long)(i % 500)); }
+            for (size_t i = 0; i < n * nc; i++) img[i] = (float)(i % 251);
+            g.x = x.data(); g.y = y.data(); g.t = 7.1e8; g.tUnits = "seconds since 2000-01-01 12:00:00"; g.dT = 300.f;
+            g.uPix = fu.data(); g.vPix = fv.data(); g.uVal = sv.data(); g.vVal = sv2.data(); g.uVal2 = sv.data(); g.vVal2 = sv2.data();
+            g.dataSVal = sv.data();
+            g.data.setdims(nx, ny, nc); g.data.data = img.data();
+            const int rc = oct_filewrite(argv[2], ftype, g, args);
+            g.data.data = nullptr;          // the vectors own the memory
+            return rc;
         }
         if (argc == 3 && !strcmp(argv[1], "--dump")) {
             fputs(nc4lite::describe(argv[2]).c_str(), stdout);

@@ -371,3 +371,53 @@ def test_octane_command_line_three_channels_finer_and_coarser(io_demo, capi, tmp
     r = subprocess.run([os.path.join(LIBD, "octane"), "-i1", str(f[0]), "-i2", str(f[1]), "-ic31", str(f[4]), "-ic32", str(f[5]), "-o", outdir],
                        capture_output=True, text=True)
     assert "needs a second one" in r.stdout
+
+
+@pytest.mark.parametrize("ftype,nchan", [("GOES", 1), ("POLAR", 3), ("MERC", 1)])
+def test_writers_emit_the_references_variables_without_a_gpu(io_demo, tmp_path, ftype, nchan):
+    """oct_filewrite on a synthetic, fully populated GOESVar: variable names, types, shapes, attributes and values of
+    outfile.nc / outfile_polar.nc / outfile_merc.nc as ref src/oct_filewrite.cc defines them (-pd -srsal set, so that
+    Upix / Vpix and their long_name exist)."""
+    nx, ny = 40, 24
+    out = tmp_path / "o.nc"
+    subprocess.check_call([io_demo, "--write-out", str(out), ftype, str(nx), str(ny), str(nchan)])
+    d = _dump(io_demo, out)
+    n = nx * ny
+    idx = np.arange(n)
+    fu = (0.25 * idx).astype(np.float32); fv = (-0.5 * idx).astype(np.float32)
+    sv = (idx % 1000).astype(np.int16); sv2 = (-(idx % 500)).astype(np.int16)
+    img = (np.arange(n * nchan) % 251).astype(np.float32)
+    assert d["x"]["type"] == "i2" and d["y"]["type"] == "i2" and d["t"]["type"] == "f8"
+    assert float(d["x"]["atts"]["scale_factor"]) == 2000.0 and float(d["y"]["atts"]["add_offset"]) == 3000.0
+    assert d["t"]["atts"]["units"] == "seconds since 2000-01-01 12:00:00" and d["t"]["atts"]["standard_name"] == "time"
+    s = d["optical_flow_settings"]["atts"]
+    assert float(s["alpha"]) == 5.0 and s["K_Iterations"] == "4" and abs(float(s["dt_seconds"]) - 300.0) < 1e-4
+    assert np.array_equal(_read(io_demo, out, "Upix", "float", tmp_path), fu)
+    assert np.array_equal(_read(io_demo, out, "Vpix", "float", tmp_path), fv)
+    if ftype == "GOES":
+        for name, want in (("U", sv), ("V", sv2), ("U_raw", sv), ("V_raw", sv2), ("Rad", sv)):
+            assert d[name]["type"] == "i2" and d[name]["shape"] == f"{ny}x{nx}"
+            assert np.array_equal(_read(io_demo, out, name, "short", tmp_path), want), name
+        assert d["U"]["atts"]["units"] == "x-pixels" and abs(float(d["U"]["atts"]["scale_factor"]) - 0.01) < 1e-9
+        assert d["goes_imager_projection"]["atts"]["grid_mapping_name"] == "geostationary"
+        assert "Image2_xOffset" in s
+    elif ftype == "POLAR":
+        assert d["U"]["type"] == "f8" and d["U"]["atts"]["grid_mapping"] == "polar_orthonormal" and d["U"]["atts"]["units"] == "x-pixels"
+        assert np.array_equal(_read(io_demo, out, "U", "double", tmp_path), fu.astype(np.float64))      # the pixel displacements
+        assert np.array_equal(_read(io_demo, out, "V", "double", tmp_path), fv.astype(np.float64))
+        for c, name in enumerate(("Rad", "Rad2", "Rad3")):
+            assert d[name]["type"] == "f4" and d[name]["atts"]["long_name"] == name
+            assert np.array_equal(_read(io_demo, out, name, "float", tmp_path), img[c * n:(c + 1) * n]), name
+        p = d["polar_imager_projection"]["atts"]
+        assert p["grid_mapping_name"] == "polar" and float(p["lat1"]) == 70.0 and float(p["lon0"]) == -45.0
+        assert d["Upix"]["atts"]["long_name"] == "Upix"
+        assert _read(io_demo, out, "polar_imager_projection", "int", tmp_path)[0] == 7
+        assert s["key"].startswith("1 = Modified Sun")
+    else:
+        assert d["U"]["type"] == "f8" and d["U"]["atts"]["grid_mapping"] == "Mercator Sphere"
+        assert abs(float(d["U"]["atts"]["scale_factor"]) - 0.01) < 1e-9
+        assert np.array_equal(_read(io_demo, out, "U", "double", tmp_path), sv.astype(np.float64))      # winds x 100
+        assert np.array_equal(_read(io_demo, out, "V", "double", tmp_path), sv2.astype(np.float64))
+        assert np.array_equal(_read(io_demo, out, "Rad", "float", tmp_path), img[:n]) and "Rad2" not in d
+        p = d["merc_imager_projection"]["atts"]
+        assert p["grid_mapping_name"] == "Mercator" and float(p["lon1"]) == -100.0 and abs(float(p["R"]) - 6371228.0) < 1.0
