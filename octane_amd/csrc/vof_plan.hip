@@ -861,9 +861,11 @@ extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const 
     // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues, 4 by default: 147 / 161 / 145 Mpix/s with 2 / 3 / 4
     // lanes at 2000^2 (a fourth lane shares a queue with another one and the two serialise).  With 8 queues -- what
     // this library asks for when it is loaded before the runtime initialises, see octane_runtime_defaults -- it is
-    // 166 / 171 / 160 with 3 / 4 / 6 lanes.  Larger frames are bandwidth-bound and get one lane.
+    // 166 / 171 / 160 with 3 / 4 / 6 lanes.  Larger frames spend less of their time on latency-bound levels, but two lanes
+    // still pay: 5000^2 168 -> 185 Mpix/s (190 with three; tools/lanes_sweep.py).  Beyond 64 Mpixel one lane.
     const char *hwq = getenv("GPU_MAX_HW_QUEUES");
-    int lanes = ((long)nx * ny <= (8L << 20)) ? ((hwq && atoi(hwq) >= 8) ? 4 : 3) : 1;
+    const long px = (long)nx * ny;
+    int lanes = px <= (8L << 20) ? ((hwq && atoi(hwq) >= 8) ? 4 : 3) : (px <= (64L << 20) ? 2 : 1);
     if (const char *e = getenv("OCTANE_TUNE_BATCH_LANES")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
     const int nworkers = ndevices * lanes;
     std::vector<int> rcs(nworkers, OCTANE_OK);
