@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Fused PCG iteration WITHOUT a stored q (the large levels of a plain plan).
+// Fused PCG iteration WITHOUT a stored q (levels and row bands of 3 Mpixel and more).
 //
 // q_{k-1} = A p_{k-1} is written by one launch only to be read once by the next (r_k = r_{k-1} - alpha q_{k-1}).  p_{k-1}
 // is stored anyway, so the next launch can form q_{k-1} again -- same inputs, same operations, same bits -- and the 16
@@ -969,6 +969,9 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
 //   phase 1   per group of the tile and its ring: q_{k-1} (stencil on that LDS tile), r_k, z_k, p_k -> second LDS tile;
 //             tile groups also update x and store r_k, p_k
 //   phase 2   tile groups: q_k (stencil on the second LDS tile) and the seven partial sums; q_k is NOT stored
+// The second LDS tile has two buffers used alternately, so a tile costs two barriers, not three.  r_k and p_k leave with
+// streaming stores (nothing of a launch this size is still cached when the next one reads it); the file is built with
+// LLVM's max-ilp scheduling (Makefile).  What else was tried on this kernel, and what it did: DESIGN.md 8.
 // Everything else (scalars from the previous launch's sums, double-buffered r / partials, triple-buffered p, deferred x)
 // is k_pcg_fused's.  In row bands (BANDED) the two rows beyond a band edge are read from the neighbour's planes in place.
 // ---------------------------------------------------------------------------------------------------------------------
