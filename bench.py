@@ -327,6 +327,10 @@ def main():
                 # one whole PCG iteration on SURVEY 8(d)'s accounting (116 B/px: pass A with seven coefficient planes + pass B).
                 # This implementation moves 64 (fused kernel, five planes, x every second launch, q formed twice instead of stored;
                 # 80 with OCTANE_TUNE_FUSED_Q=0) -- the figure above counts those, the stricter one.
+                # the same launch priced with the bytes rocprofv3 counted on the L2's fabric side (profiles/traffic.json;
+                # Infinity-Cache hits included): what "rocprof achieved GB/s against the roofline" reads
+                "rocprof_traffic_gbs": round(traffic / (dms * 1e-3) / 1e9, 1) if traffic else None,
+                "rocprof_traffic_frac": round(traffic / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "pcg_iteration_gbs_at_116B_per_pixel": round(iter_gbs, 1),
                 "frac_at_survey_bytes": round(survey_bpp * n * n / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "assemble_ms": round(pr.assemble_ms / max(1, pr.assemble_launches), 4),
