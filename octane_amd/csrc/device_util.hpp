@@ -122,6 +122,16 @@ __device__ __forceinline__ ItemRange item_range_walk(int nitems, int mode)
         r.base = 0; r.first = (int)blockIdx.x * per; r.end = min(nitems, r.first + per); r.step = 1;
         return r;
     }
+    if ((mode == 3 || mode == 4) && (gridDim.x & 63) == 0) {
+        // Runs of 4 (mode 3) or 8 (mode 4) consecutive items -- horizontally adjacent tiles -- on ONE XCD (blockIdx % 8),
+        // within the same compact front of gridDim.x items as mode 0: the lines a tile's left / right halo shares with
+        // its neighbours are then in the same L2 at the same time.
+        const int run = mode == 3 ? 4 : 8;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        ItemRange r;
+        r.base = 0; r.first = ((j / run) * 8 + x) * run + (j % run); r.end = nitems; r.step = gridDim.x;
+        return r;
+    }
     return item_range(nitems, mode == 1);
 }
 
