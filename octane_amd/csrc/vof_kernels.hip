@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const double al1 = P.al1, alpha = P.alpha, loa = P.loa;
     const float lambdac = P.lambdac;
+    const bool quad_only = (al1 == 1.0), robust_only = (al1 == 0.0);
     double acc_rr = 0., acc_rz = 0.;
 
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -244,11 +245,18 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
                  + sq(vn - vc) + sq((float)(0.25 * (double)((vne - vnw) + (ve - vw))));
         float Us = sq(uc - us) + sq((float)(0.25 * (double)((use - usw) + (ue - uw))))
                  + sq(vc - vs) + sq((float)(0.25 * (double)((vse - vsw) + (ve - vw))));
-        float ps1 = psi_smooth(Uw), ps2 = psi_smooth(Us), ps3 = psi_smooth(Ue), ps4 = psi_smooth(Un);
-        float pstot = ps1 + ps2 + ps3 + ps4;
+        // The GNC blend al1 * (quadratic terms) + (1 - al1) * (robust terms) runs with al1 = 1, 0.5, 0.  A factor that is
+        // exactly 0 makes its term +-0, which changes nothing it is added to (only, possibly, the sign of an exact zero):
+        // the robust terms -- four psi'_s, two psi'_d, seven fp64 divisions and six square roots -- are skipped at al1 == 1,
+        // the quadratic ones -- five fp64 divisions by alpha -- at al1 == 0.  Uniform branches.
+        float ps1 = 0.f, ps2 = 0.f, ps3 = 0.f, ps4 = 0.f, pstot = 0.f, snu = 0.f, snv = 0.f;
+        if (!quad_only) {
+            ps1 = psi_smooth(Uw); ps2 = psi_smooth(Us); ps3 = psi_smooth(Ue); ps4 = psi_smooth(Un);
+            pstot = ps1 + ps2 + ps3 + ps4;
+            snu = ps1 * uw + ps2 * us + ps3 * ue + ps4 * un;
+            snv = ps1 * vw + ps2 * vs + ps3 * ve + ps4 * vn;
+        }
         const float pstotq = 4.f;
-        float snu = ps1 * uw + ps2 * us + ps3 * ue + ps4 * un;
-        float snv = ps1 * vw + ps2 * vs + ps3 * ve + ps4 * vn;
         float snuq = uw + us + ue + un;
         float snvq = vw + vs + ve + vn;
 
@@ -264,10 +272,11 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
         if (x0 == w - 1) x0 = w - 2;
         if (y0 == h - 1) y0 = h - 2;
         const float fx1 = (float)x0, fx2 = (float)(x0 + 1), fy1 = (float)y0, fy2 = (float)(y0 + 1);
-        const float p1 = (fx2 - xwp) / (fx2 - fx1);
-        const float p2 = (xwp - fx1) / (fx2 - fx1);
-        const float p3 = ((fy2 - ywp) / (fy2 - fy1));
-        const float p4 = ((ywp - fy1) / (fy2 - fy1));
+        // ref .cu:60-63 (oct_binterp_cu) divides these by (fx2 - fx1) and (fy2 - fy1): exactly 1.0f for every cell, and x / 1.0f is x
+        const float p1 = fx2 - xwp;
+        const float p2 = xwp - fx1;
+        const float p3 = fy2 - ywp;
+        const float p4 = ywp - fy1;
         const size_t c1 = (size_t)y0 * pitch + x0, c3 = c1 + pitch;
 
         float t1 = 0, t2 = 0, t4 = 0, t5 = 0, t6 = 0, e1 = 0;
@@ -312,26 +321,46 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
             t6 += naIt * Iy;
             g6 += -(nbIxt * Ixy + ncIyt * Iyy);
         }
-        float pd = (float)((double)psi_data(e1) / alpha);
-        float pd2 = (float)(loa * (double)psi_data(e2));
-        float a1 = (float)((al1) * ((double)t1 / alpha + loa * (double)g1 + (double)lambdac + (double)pstotq)
-                           + (1 - al1) * (double)(pd * t1 + pd2 * g1 + lambdac + pstot));
-        float a2 = (float)((al1) * ((double)t2 / alpha + loa * (double)g2s)
-                           + (1 - al1) * (double)(pd * t2 + pd2 * g2s));
-        float a4 = (float)((al1) * ((double)t4 / alpha + loa * (double)g4 + (double)lambdac + (double)pstotq)
-                           + (1 - al1) * (double)(pd * t4 + pd2 * g4 + lambdac + pstot));
-        float a7 = (float)(-1 * (al1 + (1 - al1) * (double)ps3));   // east
-        float a8 = (float)(-1 * (al1 + (1 - al1) * (double)ps4));   // north
-
         float hint_u = 0.f, hint_v = 0.f;
         if (lambdac != 0.f) {   // 0*(finite) == 0 exactly, so the reads can be skipped
             hint_u = lambdac * (uc - L.ut[rc + ii]);
             hint_v = lambdac * (vc - L.vt[rc + ii]);
         }
-        float bu = (float)(al1 * ((double)t5 / alpha + loa * (double)g5 - (double)hint_u + (double)snuq - (double)(pstotq * uc))
-                           + (1. - al1) * (double)(pd * t5 + pd2 * g5 - hint_u + snu - pstot * uc));
-        float bv = (float)(al1 * ((double)t6 / alpha + loa * (double)g6 - (double)hint_v + (double)snvq - (double)(pstotq * vc))
-                           + (1 - al1) * (double)(pd * t6 + pd2 * g6 - hint_v + snv - pstot * vc));
+        float pd = 0.f, pd2 = 0.f;
+        if (!quad_only) {
+            pd = (float)((double)psi_data(e1) / alpha);
+            pd2 = (float)(loa * (double)psi_data(e2));
+        }
+        double qa1 = 0., qa2 = 0., qa4 = 0., qbu = 0., qbv = 0.;          // the quadratic terms
+        if (!robust_only) {
+            qa1 = (double)t1 / alpha + loa * (double)g1 + (double)lambdac + (double)pstotq;
+            qa2 = (double)t2 / alpha + loa * (double)g2s;
+            qa4 = (double)t4 / alpha + loa * (double)g4 + (double)lambdac + (double)pstotq;
+            qbu = (double)t5 / alpha + loa * (double)g5 - (double)hint_u + (double)snuq - (double)(pstotq * uc);
+            qbv = (double)t6 / alpha + loa * (double)g6 - (double)hint_v + (double)snvq - (double)(pstotq * vc);
+        }
+        float a1, a2, a4, a7, a8, bu, bv;
+        if (quad_only) {                    // 1 * q + 0 * r
+            a1 = (float)qa1; a2 = (float)qa2; a4 = (float)qa4;
+            a7 = -1.f; a8 = -1.f;           // (float)(-1 * (1 + 0 * psi)), east and north
+            bu = (float)qbu; bv = (float)qbv;
+        } else if (robust_only) {           // 0 * q + 1 * r
+            a1 = pd * t1 + pd2 * g1 + lambdac + pstot;
+            a2 = pd * t2 + pd2 * g2s;
+            a4 = pd * t4 + pd2 * g4 + lambdac + pstot;
+            a7 = (float)(-1 * (double)ps3);
+            a8 = (float)(-1 * (double)ps4);
+            bu = pd * t5 + pd2 * g5 - hint_u + snu - pstot * uc;
+            bv = pd * t6 + pd2 * g6 - hint_v + snv - pstot * vc;
+        } else {
+            a1 = (float)((al1) * qa1 + (1 - al1) * (double)(pd * t1 + pd2 * g1 + lambdac + pstot));
+            a2 = (float)((al1) * qa2 + (1 - al1) * (double)(pd * t2 + pd2 * g2s));
+            a4 = (float)((al1) * qa4 + (1 - al1) * (double)(pd * t4 + pd2 * g4 + lambdac + pstot));
+            a7 = (float)(-1 * (al1 + (1 - al1) * (double)ps3));   // east
+            a8 = (float)(-1 * (al1 + (1 - al1) * (double)ps4));   // north
+            bu = (float)(al1 * qbu + (1. - al1) * (double)(pd * t5 + pd2 * g5 - hint_u + snu - pstot * uc));
+            bv = (float)(al1 * qbv + (1 - al1) * (double)(pd * t6 + pd2 * g6 - hint_v + snv - pstot * vc));
+        }
         const size_t o = rc + ii;
         L.a1[o] = a1; L.a2[o] = a2; L.a4[o] = a4;
         if (!(L.lean && L.unit_w)) { L.wx[o] = a7; L.wy[o] = a8; }     // exactly -1 in the first GNC step: nobody reads them then
