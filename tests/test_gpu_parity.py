@@ -181,6 +181,29 @@ def test_first_assembly_is_bit_exact(capi, oracle):
         assert np.array_equal(g[gi], o[oi]), nm
 
 
+def test_assembly_of_every_gnc_step_is_bit_exact(capi, oracle):
+    """With cgiters = 0 no solve changes the flow, so the three assemblies of a level (al1 = 1, 0.5, 0: quadratic terms
+    only, the blend, robust terms only -- three code paths in k_assemble) all see the first guess and can be compared
+    with the oracle bit for bit.  A non-zero first guess and a hint term make the warp and every term non-trivial."""
+    nx, ny = 150, 97
+    a, b = synth.lattice_scene(nx, ny, seed=19)
+    tu, tv = synth.true_lattice_flow(nx, ny)
+    u0 = (0.8 * tu).astype(np.float32); v0 = (0.8 * tv).astype(np.float32)
+    prm = dict(kiters=1, liters=1, cgiters=0, lambdac=0.3)
+    tr_o, tr_g = {}, {}
+    oracle.flow(a, b, oracle.FlowParams(**prm), u0=u0, v0=v0, trace=tr_o)
+    pl = capi.Plan(nx, ny, 1, capi.FlowParams(**prm))
+    pl.set_trace(tr_g)
+    pl.run_host(a, b, u0, v0)
+    pl.close()
+    for gnc in range(3):
+        g = tr_g[("coef7", 0, gnc, 0)]
+        o = tr_o[("coef", 0, gnc, 0)]
+        for gi, oi, nm in zip(range(7), (0, 1, 2, 5, 6, 7, 8), ("a1", "a2", "a4", "a7", "a8", "bu", "bv")):
+            assert np.array_equal(g[gi], o[oi]), (gnc, nm, int((g[gi] != o[oi]).sum()))
+        assert np.abs(g[5]).max() > 0 and np.isfinite(g).all()
+
+
 def test_runs_are_bitwise_reproducible(capi):
     """Two-stage fixed-order reductions: no float atomics, so repeated runs agree exactly
     (the CUDA reference does not: SURVEY.md 2.2, jVecXVec)."""
