@@ -39,6 +39,57 @@ FUSED_Q_BYTES_PER_PIXEL_GNC0 = 56
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def pair_lanes(args, capi, shard, synth, torch, dist, world, rank, dev, n, prm):
+    """The pair workload with several pairs in flight per GPU (--lanes L): one pair's latency-bound coarse levels run under
+    another's bandwidth-bound fine levels.  Not the headline configuration (that is one pair at a time); a step is one
+    pair per lane."""
+    import threading
+    lanes = args.lanes
+    pairs = [synth.lattice_scene(n, n, seed=20240613 + 2 + rank + 31 * ln, device=dev) for ln in range(lanes)]
+    plans = [capi.Plan(n, n, 1, prm) for _ in range(lanes)]
+    outs = [(torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)) for _ in range(lanes)]
+
+    def lane_work(ln, count):
+        a, b = pairs[ln]
+        u, v = outs[ln]
+        for _ in range(count):
+            plans[ln].solve_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr(), 0, 0, capi.STREAM_OWN)
+        plans[ln].wait()
+
+    def run(count):
+        th = [threading.Thread(target=lane_work, args=(ln, count)) for ln in range(lanes)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(max(1, args.warmup))
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"metric": "Mpix/s (full pyramid) at %dx%d, %d pairs in flight per GPU" % (n, n, lanes),
+                          "value": round(shard.whole_job_mpix(world * lanes * n * n, args.steps, elapsed), 3), "unit": "Mpix/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"{lanes} concurrent {n}x{n} pairs per GPU, kiters={args.kiters} liters={args.liters} "
+                                                 f"cgiters={args.cgiters}; a step is one pair per lane (not the headline configuration)",
+                                     "sharding": "independent pairs, no data-path collective"},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    for pl in plans:
+        pl.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev):
     """BASELINE.json configs[4]: 64 independent 2000x2000 pairs (kiters=6) over the ranks, pair b on rank b % world;
     each GPU runs four lanes (four plans, each on its private stream, one host thread each) so one pair's
@@ -214,6 +265,8 @@ def main():
                          "configs[3], one --size frame as row bands: --bands bands driven by a single process, or -- "
                          "under torchrun -- one band per rank")
     ap.add_argument("--bands", type=int, default=4, help="row bands of the tiled workload")
+    ap.add_argument("--lanes", type=int, default=1, help="pair workload only: this many pairs in flight per GPU, each on its own plan, "
+                    "stream and host thread (a step is then one pair per lane); 1 = the headline configuration")
     ap.add_argument("--cpu-sample", type=int, default=3072, help="edge of the CPU-baseline sample pair")
     args = ap.parse_args()
     if args.size is None:
@@ -249,6 +302,8 @@ def main():
         return batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev)
     n = args.size
     prm = capi.FlowParams(kiters=args.kiters, liters=args.liters, cgiters=args.cgiters, device=local)
+    if args.lanes > 1:
+        return pair_lanes(args, capi, shard, synth, torch, dist, world, rank, dev, n, prm)
     a, b = synth.lattice_scene(n, n, seed=20240613 + 2 + rank, device=dev)
     u = torch.zeros(n, n, device=dev)
     v = torch.zeros(n, n, device=dev)
