@@ -69,6 +69,10 @@ def main():
         # the reference's dot product depends on its launch geometry (oracle/vof_oracle.c, dotf): a second, finer geometry
         # is as valid an answer as the first, and on large, heavily truncated solves the two can be further apart than
         # the bar -- the HIP path (fp64 sums) has to match one of them
+        us = vs = None
+        if nx * ny <= 100_000:                      # small frames: the one-thread schedule the survey's answers were recorded with
+            us, vs, _ = oo.flow(a, b, P, u0=u0, v0=v0, flavour="omp")
+            floor = max(floor, rel_l2(us, vs, uo, vo))
         u2 = v2 = None
         if nx * ny > 1_000_000:
             u2, v2, _ = oo.flow(a, b, P, u0=u0, v0=v0, flavour="omp", dot_threads=8 * g)
@@ -80,6 +84,8 @@ def main():
         d = rel_l2(ug, vg, uo, vo)
         if u2 is not None:
             d = min(d, rel_l2(ug, vg, u2, v2))
+        if us is not None:
+            d = min(d, rel_l2(ug, vg, us, vs))
         bar = max(2e-5, 2.0 * floor)
         ok = np.isfinite(ug).all() and d < bar and its_g == its_o
         worst = max(worst, d / bar)
