@@ -104,6 +104,16 @@ def test_level_above_four_megapixels_matches_oracle(capi, oracle):
     _check(capi, oracle, a, b, dict(kiters=1, liters=1, cgiters=7))
 
 
+def test_large_level_with_two_channels_first_guess_and_hint_term(capi, oracle):
+    """The q-recomputing kernel under everything the assembly can feed it: two channels, a first guess that is not zero
+    and the hint term (lambdac), on a level of 3.6 Mpixel with ragged tiles."""
+    nx, ny = 2090, 1730
+    a, b = synth.lattice_scene(nx, ny, seed=57, nchan=2)
+    tu, tv = synth.true_lattice_flow(nx, ny)
+    u0 = (0.7 * tu).astype(np.float32); v0 = (0.7 * tv).astype(np.float32)
+    _check(capi, oracle, a, b, dict(kiters=1, liters=1, cgiters=6, lambdac=0.3), u0=u0, v0=v0)
+
+
 def test_first_guess_and_hint_term(capi, oracle):
     """lambdac != 0 (only reachable with -firstguess): the hint term and its pyramid."""
     nx, ny = 120, 88
