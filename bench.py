@@ -9,7 +9,15 @@ scene.  With N ranks each rank solves its own independent pair on its own GPU (t
 over pairs: no collective in the data path; weak scaling); value = N * pixels / max-over-ranks
 time.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (python -m torch.distributed.run,
+fresh child processes, before this process has touched the GPU) and exits with their code; under torchrun (the
+driver's launch) the ranks come from the environment and --gpus has to agree with WORLD_SIZE.
+
 The JSON line also carries
+  value_with_transfers -- SURVEY 8d's primary metric: one oct_variational_optical_flow-shaped call on HOST buffers
+                   (H2D + all levels + D2H through octane_vof_run), pageable and pinned; never `value`;
+  placement_trials_ms -- [min, median, max] ms per PCG iteration over the candidate arenas the plan timed when it was
+                   created: the headline is a best-of-n-placements figure (DESIGN.md 8);
   roofline      -- dominant kernel (the fused PCG iteration at the finest level): algorithmic bytes per launch
                    (80 B/pixel, 72 in the first GNC step; DESIGN.md) / its mean duration from HIP events on the launch stream;
   cpu_baseline  -- the CPU oracle ("port", OpenMP over the host cores) timed on a bounded sample (rank 0, N=1 only).
@@ -37,6 +45,14 @@ FUSED_BYTES_PER_PIXEL_GNC0 = 72        # first GNC step: wx == wy == -1, not rea
 FUSED_Q_BYTES_PER_PIXEL = 64           # k_pcg_fused_q (levels of >= 3 * 2^20 pixels): q = A p is formed again, neither written nor read
 FUSED_Q_BYTES_PER_PIXEL_GNC0 = 56
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+TILED_PARITY_BAR = 2e-5            # banded vs plain solve of the same frame: two groupings of the same fp64 partial sums
+
+
+def flow_distance(torch, got, want):
+    """relative L2 distance of two flow fields held on a device"""
+    num = ((got[0] - want[0]).double() ** 2).sum() + ((got[1] - want[1]).double() ** 2).sum()
+    den = (want[0].double() ** 2).sum() + (want[1].double() ** 2).sum()
+    return float(torch.sqrt(num / den))
 
 
 def pair_lanes(args, capi, shard, synth, torch, dist, world, rank, dev, n, prm):
@@ -172,9 +188,23 @@ def tiled(args, capi, synth, torch):
     z = torch.zeros(n, n, device=dev)
     prm = capi.FlowParams(kiters=args.kiters, liters=args.liters, cgiters=args.cgiters)
     torch.cuda.synchronize()
+    # the plain plan's answer on band 0's device first: the banded solve is checked against it before anything is timed
+    pu, pv = torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)
+    pl = capi.Plan(n, n, 1, capi.FlowParams(kiters=args.kiters, liters=args.liters, cgiters=args.cgiters, device=devices[0]))
+    pl.run_device(a.data_ptr(), b.data_ptr(), pu.data_ptr(), pv.data_ptr())
+    torch.cuda.synchronize()
+    plain_its = pl.last_iterations()
+    pl.close()
     tp = capi.TiledPlan(n, n, 1, prm, nbands=args.bands, devices=devices)
     tp.load_device(a.data_ptr(), b.data_ptr(), z.data_ptr(), z.data_ptr())     # the pair resident on every band's device
-    for _ in range(args.warmup):
+    tp.solve()
+    ou, ov = torch.empty(n, n, device=dev), torch.empty(n, n, device=dev)
+    tp.fetch_device(ou.data_ptr(), ov.data_ptr())
+    torch.cuda.synchronize()
+    parity = flow_distance(torch, (ou, ov), (pu, pv))
+    parity_its = tp.last_iterations()
+    del ou, ov
+    for _ in range(max(0, args.warmup - 1)):
         tp.solve()
     tp.wait()
     t0 = time.perf_counter()
@@ -195,9 +225,13 @@ def tiled(args, capi, synth, torch):
                                   "two event-ordered phase boundaries, partial sums and one residual row per inner edge read in "
                                   "place from the neighbouring band",
                       "device_bytes_per_band": tp.device_bytes},
+           "parity_vs_plain": {"rel_l2": parity, "bar": TILED_PARITY_BAR, "iterations_plain": plain_its, "iterations_banded": parity_its,
+                               "ok": bool(parity <= TILED_PARITY_BAR and plain_its == parity_its)},
            "roofline": None, "cpu_baseline": None}
     tp.close()
     print(json.dumps(out), flush=True)
+    if not out["parity_vs_plain"]["ok"]:
+        raise SystemExit(3)
 
 
 def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
@@ -216,14 +250,30 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         return out
 
     torch.cuda.synchronize()
-    mp = capi.MpPlan(n, n, 1, prm, rank, world, "/octane_bench_%s" % os.environ.get("MASTER_PORT", "0"), all_gather)
+    parity = plain_its = None
+    if rank == 0:    # the plain plan's answer on rank 0's device: the banded solve is checked against it before anything is timed
+        pu, pv = torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)
+        pl = capi.Plan(n, n, 1, prm)
+        pl.run_device(a.data_ptr(), b.data_ptr(), pu.data_ptr(), pv.data_ptr())
+        torch.cuda.synchronize()
+        plain_its = pl.last_iterations()
+        pl.close()
+    dist.barrier()
+    nonce = [os.urandom(6).hex() if rank == 0 else None]       # a name no earlier (crashed) run can have left behind
+    dist.broadcast_object_list(nonce, src=0)
+    mp = capi.MpPlan(n, n, 1, prm, rank, world, "/octane_bench_%s" % nonce[0], all_gather)
+    mp.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr())
+    torch.cuda.synchronize()
+    if rank == 0:
+        parity = flow_distance(torch, (u, v), (pu, pv))
+        del pu, pv
 
     def barrier():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(0, args.warmup - 1)):
         mp.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr())
     barrier()
     t0 = time.perf_counter()
@@ -242,16 +292,61 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
                                       f"one row band per rank, {world} ranks",
                           "sharding": f"row bands of the {mp.banded_levels} finest level(s), coarser levels replicated; HIP IPC peer reads "
                                       "of partial sums and edge rows, phase barrier in shared memory; no collective on the data path"},
+               "parity_vs_plain": {"rel_l2": parity, "bar": TILED_PARITY_BAR, "iterations_plain": plain_its, "iterations_banded": iters,
+                                   "ok": bool(parity <= TILED_PARITY_BAR and plain_its == iters)},
                "roofline": None, "cpu_baseline": None}
         print(json.dumps(out), flush=True)
+        ok = out["parity_vs_plain"]["ok"]
+    else:
+        ok = True
     mp.close()
     dist.barrier()
     dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(ngpus):
+    """--gpus N without a launcher: start N fresh ranks (one per GPU) and exit with their code.  Nothing in this process
+    has touched the GPU yet (torch.cuda.device_count() does not initialise it), and the ranks are child processes, not
+    an exec of this one."""
+    import subprocess
+    import torch
+    visible = torch.cuda.device_count()
+    one_device = os.environ.get("OCTANE_BENCH_ONE_DEVICE") == "1"       # rehearsal: all ranks share GPU 0
+    if visible < ngpus and not one_device:
+        print(f"bench.py: --gpus {ngpus} but only {visible} GPU(s) visible (set OCTANE_BENCH_ONE_DEVICE=1 with "
+              f"OCTANE_BENCH_BACKEND=gloo to rehearse the N-rank control flow on one GPU)", file=sys.stderr)
+        raise SystemExit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def run_name(n, kiters, liters, cgiters):
+    """Which of SURVEY 8d's named runs a parameter set is (they differ in work per pixel by 2.8x; never substitute silently)."""
+    if (kiters, liters, cgiters) == (8, 3, 30):
+        return "SURVEY 8d run R1" + (" = BASELINE.json configs[2]" if n == 5000 else "")
+    if (kiters, liters, cgiters) == (8, 10, 10):
+        return "SURVEY 8d run R2 (300 PCG iterations per level, 240 warps; API-only, cgiters is not a CLI flag)"
+    if (kiters, liters, cgiters) == (10, 10, 30):
+        return "SURVEY 8d run R3 (the metric string's '300 warps': kiters * 3 * liters = 300)"
+    if (n, kiters, liters, cgiters) == (2000, 6, 3, 30):
+        return "BASELINE.json configs[1]"
+    return "not one of SURVEY 8d's named runs"
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs = ranks (one process per GPU).  N > 1 without a launcher "
+                    "starts the N ranks itself; under torchrun it has to equal WORLD_SIZE.  Default: WORLD_SIZE, else 1")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=None, help="frame edge: 5000 (pair), 10848 (tiled) unless given")
@@ -259,9 +354,10 @@ def main():
     ap.add_argument("--liters", type=int, default=3)
     ap.add_argument("--cgiters", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-transfers", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--workload", default="pair", choices=["pair", "batch64", "tiled"],
                     help="pair (default): one --size pair per GPU; batch64: BASELINE.json configs[4], 64 pairs of "
-                         "2000x2000 (kiters=6) shared by all ranks, two concurrent lanes per GPU; tiled: BASELINE.json "
+                         "2000x2000 (kiters=6) shared by all ranks, four concurrent lanes per GPU (three on 4 hardware queues); tiled: BASELINE.json "
                          "configs[3], one --size frame as row bands: --bands bands driven by a single process, or -- "
                          "under torchrun -- one band per rank")
     ap.add_argument("--bands", type=int, default=4, help="row bands of the tiled workload")
@@ -271,6 +367,16 @@ def main():
     args = ap.parse_args()
     if args.size is None:
         args.size = 10848 if args.workload == "tiled" else 5000
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus is not None and args.gpus > 1:
+            self_launch(args.gpus)                      # does not return
+        args.gpus = 1
+    else:
+        if args.gpus is not None and args.gpus != int(env_world):
+            print(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={env_world}", file=sys.stderr)
+            raise SystemExit(2)
+        args.gpus = int(env_world)
 
     import torch
     import torch.distributed as dist
@@ -289,8 +395,11 @@ def main():
             shard.init_from_env("nccl", device_id=torch.device("cuda", local))
         else:
             shard.init_from_env(backend)
-    if capi.lib().octane_device_count() < 1:
+    ndev = capi.lib().octane_device_count()
+    if ndev < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if local >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but {ndev} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -308,6 +417,8 @@ def main():
     u = torch.zeros(n, n, device=dev)
     v = torch.zeros(n, n, device=dev)
     plan = capi.Plan(n, n, 1, prm)
+    tr = sorted(t for t in plan.placement_trials() if t > 0)
+    trials_ms = {"n": len(tr), "min": round(tr[0], 4), "median": round(tr[len(tr) // 2], 4), "max": round(tr[-1], 4)} if tr else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -364,19 +475,21 @@ def main():
             iter_ms = a_ms + b_ms
         # HBM-side traffic of that kernel from the PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be
         # collected inside this run; tools/profile_round.sh + tools/summarize_rocprof.py produce the file)
-        traffic = None
+        traffic = traffic_source = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             tk = "k_pcg_fused" if fused else dom          # the summariser files every fused instance under one name
             if tj.get(tk, {}).get("size") == n and tj[tk].get("kernel", dom) == dom:
                 traffic = tj[tk]["read_bytes"] + tj[tk]["write_bytes"]
+                traffic_source = "profiles/traffic.json @ %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this " \
+                                 "kernel; NOT measured in this run)" % tj.get("commit", tj[tk].get("commit", "unknown commit"))
         except (OSError, ValueError):
             pass
         achieved = bpp * n * n / (dms * 1e-3) / 1e9
         iter_gbs = 116 * n * n / (iter_ms * 1e-3) / 1e9
         survey_bpp = 116 if fused else (60 if dom == "k_pcg_pass_a" else 56)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(dms, 4), "bytes_per_launch": int(round(bpp * n * n)),
                 "pcg_iteration_ms": round(iter_ms, 4),
                 # one whole PCG iteration on SURVEY 8(d)'s accounting (116 B/px: pass A with seven coefficient planes + pass B).
@@ -391,12 +504,37 @@ def main():
                 "assemble_ms": round(pr.assemble_ms / max(1, pr.assemble_launches), 4),
                 "setup_ms_all_levels": round(pr.setup_ms, 3), "profiled_step_ms": round(pr.total_ms, 2)}
 
+    # SURVEY 8d's primary metric: the whole call on HOST buffers (H2D + all levels + D2H), as the C++ shim of
+    # oct_variational_optical_flow costs per pair -- pageable memory (what the reference's caller has) and pinned memory.
+    transfers = None
+    if rank == 0 and world == 1 and not args.no_transfers:
+        import numpy as np
+        ha, hb = a.cpu().numpy(), b.cpu().numpy()
+        transfers = {}
+        for kind in ("pageable", "pinned"):
+            if kind == "pinned":
+                ta, tb = torch.from_numpy(ha).pin_memory(), torch.from_numpy(hb).pin_memory()
+                tu, tv = torch.zeros(n, n).pin_memory(), torch.zeros(n, n).pin_memory()
+                xa, xb, xu, xv = ta.numpy(), tb.numpy(), tu.numpy(), tv.numpy()
+            else:
+                xa, xb, xu, xv = ha, hb, np.zeros((n, n), np.float32), np.zeros((n, n), np.float32)
+            best = None
+            for rep in range(3):           # the first call creates the cached plan; the best of the next two counts
+                xu[:] = 0; xv[:] = 0
+                t1 = time.perf_counter()
+                capi.flow_inplace(xa, xb, xu, xv, prm)
+                dt = time.perf_counter() - t1
+                if rep > 0:
+                    best = dt if best is None else min(best, dt)
+            transfers[kind] = {"ms": round(best * 1e3, 2), "mpix_s": round(n * n / best / 1e6, 2)}
+        capi.release_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oct_oracle as oo     # the checker, timed as the CPU baseline ("port")
         m = args.cpu_sample
         ca, cb = synth.lattice_scene(m, m, seed=20240613 + 2)
-        ck = 4
+        ck = min(args.kiters, 4)
         t1 = time.perf_counter()
         # OpenMP build of the oracle (bit-identical to the scalar one) under the reference's launch-geometry
         # dot-product schedule, on all the host cores this process may use
@@ -405,12 +543,15 @@ def main():
         _, _, cits = oo.flow(ca, cb, oo.FlowParams(kiters=ck, liters=args.liters, cgiters=args.cgiters),
                              flavour="omp", dot_threads=oo.REF_GRID_THREADS)
         ct = time.perf_counter() - t1
-        # same work per pixel-iteration as the GPU workload; scale Mpix/s by iterations per pyramid
-        cpu_mpix = m * m / ct / 1e6 * (ck / args.kiters)
+        # same work per level pixel as the GPU workload; work grows with the sum of the level sizes, sum_k 0.25^k, which
+        # is 1.328 N0 at 4 levels and 1.333 N0 at 8: the sample's fewer levels are worth 0.4 %, not a factor
+        lev_sum = lambda k: sum(0.25 ** i for i in range(k))
+        scale = lev_sum(ck) / lev_sum(args.kiters)
+        cpu_mpix = m * m / ct / 1e6 * scale
         cpu = {"value": round(cpu_mpix, 5), "unit": "Mpix/s", "cores": cores, "kind": "port",
                "sample": f"{m}x{m} lattice pair, kiters={ck} liters={args.liters} cgiters={args.cgiters} "
-                         f"({cits} PCG iterations) in {ct:.1f} s on {cores} host cores (OpenMP); Mpix/s scaled by {ck}/{args.kiters} "
-                         f"to the workload's levels"}
+                         f"({cits} PCG iterations) in {ct:.1f} s on {cores} host cores (OpenMP); Mpix/s scaled by {scale:.4f} "
+                         f"(level-pixel sums of {ck} vs {args.kiters} levels)"}
 
     if rank == 0:
         out = {"metric": "Mpix/s (full pyramid) at %dx%d" % (n, n), "value": round(value, 3), "unit": "Mpix/s",
@@ -418,9 +559,14 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan=1 "
-                                      f"alpha=5 lambda=1" + (" (BASELINE.json configs[2], SURVEY 8d run R1), " if (n, args.kiters, args.liters, args.cgiters) == (5000, 8, 3, 30) else ", ") + 
+                                      f"alpha=5 lambda=1 ({run_name(n, args.kiters, args.liters, args.cgiters)}), "
                                       f"{iters} PCG iterations per pyramid (expected {expect}), one pair per GPU",
                           "sharding": "independent pairs, no data-path collective"},
+               # the whole call on host buffers (H2D + all levels + D2H): SURVEY 8d's primary metric; `value` above is the
+               # device-resident figure the bench contract asks for
+               "value_with_transfers": transfers,
+               # the plan kept the fastest of these candidate arenas (ms per finest-level PCG iteration): best-of-n placement
+               "placement_trials_ms": trials_ms,
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

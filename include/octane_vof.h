@@ -70,6 +70,11 @@ typedef struct octane_vof_plan octane_vof_plan;
 int octane_vof_plan_create(octane_vof_plan **plan, int nx, int ny, int nchan, const octane_vof_params *p);
 int octane_vof_plan_destroy(octane_vof_plan *plan);
 size_t octane_vof_plan_device_bytes(const octane_vof_plan *plan);
+/* Plans of 4 Mpixel and more allocate up to eight candidate arenas, time a few PCG iterations on each and keep the
+ * fastest (where an arena lands in physical memory is worth up to 11 %).  Returns how many candidates were timed and
+ * copies up to `cap` of their times (ms per PCG iteration at the finest level) into ms: a throughput measured on such
+ * a plan is a "best of n placements" figure and should be reported with this spread.  No reference counterpart. */
+int octane_vof_plan_placement_trials(const octane_vof_plan *plan, double *ms, int cap);
 
 #define OCTANE_MEM_HOST   0
 #define OCTANE_MEM_DEVICE 1

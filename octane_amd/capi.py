@@ -21,7 +21,7 @@ NAV_GEOS, NAV_POLAR, NAV_MERC = 0, 1, 2
 # every symbol include/octane_vof.h declares
 EXPORTS = (
     "octane_vof_default_params", "octane_vof_run", "octane_vof_release_cache", "octane_vof_plan_create", "octane_vof_plan_destroy",
-    "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_solve", "octane_vof_plan_wait", "octane_vof_plan_last_iterations",
+    "octane_vof_plan_device_bytes", "octane_vof_plan_placement_trials", "octane_vof_plan_run", "octane_vof_plan_solve", "octane_vof_plan_wait", "octane_vof_plan_last_iterations",
     "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_probe", "octane_vof_tune",
     "octane_vof_batch_run",
     "octane_vof_tiled_create", "octane_vof_tiled_destroy", "octane_vof_tiled_load", "octane_vof_tiled_solve",
@@ -128,6 +128,8 @@ def lib() -> C.CDLL:
     L.octane_vof_plan_destroy.argtypes = [vp]
     L.octane_vof_plan_device_bytes.argtypes = [vp]
     L.octane_vof_plan_device_bytes.restype = C.c_size_t
+    L.octane_vof_plan_placement_trials.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
+    L.octane_vof_plan_placement_trials.restype = C.c_int
     L.octane_vof_plan_run.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
     L.octane_vof_plan_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
     L.octane_vof_plan_wait.argtypes = [vp]
@@ -240,6 +242,12 @@ class Plan:
     @property
     def device_bytes(self) -> int:
         return lib().octane_vof_plan_device_bytes(self._h)
+
+    def placement_trials(self):
+        """ms per finest-level PCG iteration of every candidate arena timed at creation ([] when none were)."""
+        buf = (C.c_double * 8)()
+        n = lib().octane_vof_plan_placement_trials(self._h, buf, 8)
+        return [buf[i] for i in range(min(n, 8))]
 
     def run_host(self, img1, img2, u0=None, v0=None):
         """Host numpy buffers in, (u, v) numpy out.  img: [nchan, ny, nx] or [ny, nx]."""
@@ -475,6 +483,22 @@ def flow(img1, img2, params: FlowParams | None = None, u0=None, v0=None):
     if rc != OK:
         raise OctaneError(rc, "octane_vof_run")
     return u, v
+
+
+def flow_inplace(img1, img2, u, v, params: FlowParams | None = None) -> None:
+    """octane_vof_run on the caller's own buffers, exactly as the C++ shim calls it: u / v (C-contiguous float32 [ny, nx])
+    hold the first guess on entry and the flow on return; nothing is copied or allocated on the host side."""
+    a, b = img1, img2
+    for x in (a, b, u, v):
+        if not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.flags["C_CONTIGUOUS"]):
+            raise ValueError("flow_inplace needs C-contiguous float32 arrays")
+    if a.ndim == 2:
+        a, b = a[None], b[None]
+    nc, ny, nx = a.shape
+    p = (params or FlowParams()).c()
+    rc = lib().octane_vof_run(_ptr(a), _ptr(b), nx, ny, nc, _ptr(u), _ptr(v), C.byref(p))
+    if rc != OK:
+        raise OctaneError(rc, "octane_vof_run")
 
 
 def release_cache() -> None:

@@ -393,6 +393,8 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
             for (int t = 0; t < ncand; t++) fprintf(stderr, " %.4f@%p", ms[t], (void *)cand[t]);
             fprintf(stderr, " -> candidate %d\n", best);
         }
+        pl->ntrials = ncand;
+        for (int t = 0; t < ncand; t++) pl->trial_ms[t] = ms[t];
         for (int t = 0; t < ncand; t++)
             if (t != best) (void)hipFree(cand[t]);
         pl->arena = cand[best];
@@ -416,6 +418,14 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
 }
 
 extern "C" size_t octane_vof_plan_device_bytes(const octane_vof_plan *pl) { return pl ? pl->arena_bytes : 0; }
+
+extern "C" int octane_vof_plan_placement_trials(const octane_vof_plan *pl, double *ms, int cap)
+{
+    if (!pl) return 0;
+    for (int t = 0; t < pl->ntrials && t < cap; t++)
+        if (ms) ms[t] = pl->trial_ms[t];
+    return pl->ntrials;
+}
 
 extern "C" int octane_vof_plan_set_trace(octane_vof_plan *pl, octane_vof_trace_fn fn, void *user)
 {

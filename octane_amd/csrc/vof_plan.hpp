@@ -60,6 +60,8 @@ struct octane_vof_plan {
     hipGraphExec_t graph_exec = nullptr;
     int graph_cur = 0;
     int nt_hints = 15;   // x, q, mu/mv in pass B and a2 in pass A are single-use: streaming loads/stores
+    int ntrials = 0;     // placement trials made when the plan was created, and what each candidate arena measured
+    double trial_ms[8] = {0};
 };
 
 

@@ -11,54 +11,80 @@ from octane_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-BAR = 1e-4          # north_star tolerance
-INVESTIGATE = 2e-5  # expect ~3e-6
+BAR = 1e-4          # north_star tolerance: asserted for EVERY case that is not on the allow-list below
+INVESTIGATE = 2e-5  # expect ~3e-6; everything not allow-listed has to stay below this
+
+# Cases whose distance to the primary oracle may exceed INVESTIGATE, each with the reason and the numbers measured when
+# the entry was made.  An entry sets the case's own bar (never "whatever the floor happens to be today"), and _check
+# verifies that the entry is still justified: the oracle's own spread on that case (FMA-contracted vs strict build of the
+# same source, and the reference's other valid dot-product schedules) has to exceed INVESTIGATE / 2, otherwise the entry
+# is stale and the test fails.  Nothing else may be further than INVESTIGATE (hence BAR) from the oracle.
+ALLOW = {
+    # alpha = 12, lambda = 0.25 on a 90 x 70 frame: the truncated solve amplifies single roundings -- the oracle's strict
+    # and FMA builds are 1.8e-4 apart, the GPU 1.1e-4 from the strict one
+    "lat_90x70_a12_l025": dict(bar=4e-4, why="oracle strict vs FMA build 1.8e-4 apart"),
+}
 
 
-def _check(capi, oracle, a, b, prm_kwargs, u0=None, v0=None, bar=INVESTIGATE):
-    """GPU vs strict oracle.
-
-    The oracle offers two valid schedules of the reference's dot product (oracle/vof_oracle.c, dotf): the CUDA
-    launch geometry (what a GPU run of the reference adds up) and the one-thread running sum (what the survey
-    recorded; only meaningful on small frames, it drifts by 1e-3 beyond ~0.3 Mpixel).  The GPU has to match
-    one of them.  The bar is 2e-5 unless the problem itself is more sensitive than that to rounding: the
-    distance between the oracle's two builds (FMA-contracted vs not, same source) measures that sensitivity,
-    and the GPU may not be further away than twice that.  (alpha=12, lambda=0.25 on a 90x70 frame is such a
-    case: a 1e-7 change in a dot product moves the flow by 1.5e-4.)"""
+def _check(capi, oracle, a, b, prm_kwargs, u0=None, v0=None, case=None):
+    """GPU vs the strict oracle under the reference's launch geometry (the PRIMARY oracle: what a GPU run of the
+    reference adds up, oracle/vof_oracle.c dotf).  Asserts d < INVESTIGATE (2e-5 < BAR = 1e-4) unless `case` is on the
+    ALLOW list, whose entry then gives the bar.  The oracle's other valid variants (FMA-contracted build, one-thread
+    running sums on small frames, 8x finer launch geometry on large ones) are computed and PRINTED as information: they
+    measure how sensitive the problem itself is to rounding, they do not move the bar.  Every number goes to stdout so
+    that `pytest -rP` logs carry them."""
     g = oracle.REF_GRID_THREADS
     P = oracle.FlowParams(**prm_kwargs)
     uo, vo, its_o = oracle.flow(a, b, P, u0=u0, v0=v0, dot_threads=g)
     uf, vf, _ = oracle.flow(a, b, P, u0=u0, v0=v0, flavour="fma", dot_threads=g)
     nc, ny, nx = (1,) + a.shape if a.ndim == 2 else a.shape
-    floor = rel_l2(uf, vf, uo, vo)
-    us = vs = None
-    if nx * ny <= 100_000:       # the reference's own spread also includes its two dot-product schedules
+    spread = {"fma": rel_l2(uf, vf, uo, vo)}
+    others = {}
+    if nx * ny <= 100_000:       # the reference's one-thread schedule (what the survey recorded)
         us, vs, _ = oracle.flow(a, b, P, u0=u0, v0=v0)
-        floor = max(floor, rel_l2(us, vs, uo, vo))
-    u8 = v8 = None
-    if nx * ny > 3_000_000:      # ... and, on large frames, its launch geometry: 1.7e-4 apart on a 4.4 Mpixel solve truncated
-        u8, v8, _ = oracle.flow(a, b, P, u0=u0, v0=v0, flavour="omp", dot_threads=8 * g)     # at cgiters = 3 (DESIGN 4)
-        floor = max(floor, rel_l2(u8, v8, uo, vo))
-    bar = max(bar, 2.0 * floor)
+        spread["serial"] = rel_l2(us, vs, uo, vo); others["serial"] = (us, vs)
+    if nx * ny > 3_000_000:      # a finer launch geometry (1.7e-4 apart on a 4.4 Mpixel solve truncated at cgiters = 3, DESIGN 4)
+        u8, v8, _ = oracle.flow(a, b, P, u0=u0, v0=v0, flavour="omp", dot_threads=8 * g)
+        spread["grid_x8"] = rel_l2(u8, v8, uo, vo); others["grid_x8"] = (u8, v8)
+    floor = max(spread.values())
     pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm_kwargs))
     ug, vg = pl.run_host(a, b, u0, v0)
     its_g = pl.last_iterations()
     pl.close()
     assert np.isfinite(ug).all() and np.isfinite(vg).all()
     d = rel_l2(ug, vg, uo, vo)
-    if us is not None:
-        d = min(d, rel_l2(ug, vg, us, vs))
-    if u8 is not None:
-        d = min(d, rel_l2(ug, vg, u8, v8))
-    assert d < bar, f"relative L2 {d:.3e} vs oracle (bar {bar:.1e})"
+    info = {k: rel_l2(ug, vg, *o) for k, o in others.items()}
+    allow = ALLOW.get(case)
+    bar = allow["bar"] if allow else INVESTIGATE
+    print(f"PARITY case={case or '-'} {nx}x{ny}x{nc} {prm_kwargs}: d_primary={d:.3e} bar={bar:.1e} "
+          f"(north-star {BAR:.0e}{', ALLOW-LISTED: ' + allow['why'] if allow else ''}) "
+          f"oracle_spread={ {k: f'{x:.2e}' for k, x in spread.items()} } "
+          f"d_other={ {k: f'{x:.2e}' for k, x in info.items()} } iterations oracle/gpu={its_o}/{its_g}")
+    if allow:
+        assert floor > INVESTIGATE / 2, f"allow-list entry {case!r} is stale: the oracle's own spread is only {floor:.2e}"
+    else:
+        assert bar <= BAR
+    assert d < bar, f"relative L2 {d:.3e} vs the primary oracle (bar {bar:.1e}; oracle spread {floor:.2e})"
     return d, its_o, its_g
 
 
 @pytest.mark.parametrize("n,shift", [(64, (1.5, -0.75)), (128, (2.0, 1.0))])
 def test_s1_scene_matches_oracle(capi, oracle, n, shift):
     a, b = synth.gaussian_scene(n, shift)
-    d, io, ig = _check(capi, oracle, a, b, {})
+    d, io, ig = _check(capi, oracle, a, b, {}, case=f"s1_{n}")
     assert io == ig
+
+
+def test_config0_s1_512_matches_oracle(capi, oracle):
+    """BASELINE.json configs[0]: the 512 x 512 translating-Gaussian pair (S1 of SURVEY 8d: shift (3, -2), alpha = 5,
+    lambda = 1, the command line's defaults kiters 4, liters 3, cgiters 30 -> 1080 PCG iterations), in-out u / v with a
+    zero first guess as ref .cu:1213 takes them.  ~6 s of oracle time per build."""
+    a, b = synth.gaussian_scene(512, (3.0, -2.0))
+    z = np.zeros((512, 512), np.float32)
+    d, io, ig = _check(capi, oracle, a, b, dict(alpha=5.0, lambda_=1.0), u0=z, v0=z.copy(), case="config0_s1_512")
+    assert io == ig == 4 * 3 * 3 * 30
+    ug, vg = capi.flow(a, b, capi.FlowParams(alpha=5.0, lambda_=1.0))
+    assert abs(synth.interior_mean(ug) - 3.0004) < 2e-3 and abs(synth.interior_mean(vg) + 2.0010) < 2e-3   # BASELINE.md 2
 
 
 @pytest.mark.parametrize("nx,ny,nc,prm", [
@@ -74,7 +100,9 @@ def test_s1_scene_matches_oracle(capi, oracle, n, shift):
 ])
 def test_lattice_scene_matches_oracle(capi, oracle, nx, ny, nc, prm):
     a, b = synth.lattice_scene(nx, ny, seed=nx * 7 + ny, nchan=nc)
-    _check(capi, oracle, a, b, prm)
+    case = "lat_90x70_a12_l025" if prm.get("alpha") == 12.0 else f"lat_{nx}x{ny}x{nc}"
+    d, io, ig = _check(capi, oracle, a, b, prm, case=case)
+    assert io == ig
 
 
 def test_multi_tile_persistent_loops_match_oracle(capi, oracle):
@@ -82,7 +110,7 @@ def test_multi_tile_persistent_loops_match_oracle(capi, oracle):
     1024 tiles): the regime BASELINE's sizes run in.  Caught an in-place halo race once."""
     nx, ny = 1300, 1040
     a, b = synth.lattice_scene(nx, ny, seed=77)
-    _check(capi, oracle, a, b, dict(kiters=2, liters=1, cgiters=15))
+    _check(capi, oracle, a, b, dict(kiters=2, liters=1, cgiters=15), case="multi_tile_1300x1040")
 
 
 def test_one_thread_schedule_of_the_oracle_also_agrees_on_small_frames(capi, oracle):
@@ -101,7 +129,7 @@ def test_level_above_four_megapixels_matches_oracle(capi, oracle):
     deferred x update (first launch, odd, even without and with a stored x)."""
     nx, ny = 2300, 1900
     a, b = synth.lattice_scene(nx, ny, seed=55)
-    _check(capi, oracle, a, b, dict(kiters=1, liters=1, cgiters=7))
+    _check(capi, oracle, a, b, dict(kiters=1, liters=1, cgiters=7), case="q_2300x1900")
 
 
 def test_large_level_with_two_channels_first_guess_and_hint_term(capi, oracle):
@@ -111,7 +139,7 @@ def test_large_level_with_two_channels_first_guess_and_hint_term(capi, oracle):
     a, b = synth.lattice_scene(nx, ny, seed=57, nchan=2)
     tu, tv = synth.true_lattice_flow(nx, ny)
     u0 = (0.7 * tu).astype(np.float32); v0 = (0.7 * tv).astype(np.float32)
-    _check(capi, oracle, a, b, dict(kiters=1, liters=1, cgiters=6, lambdac=0.3), u0=u0, v0=v0)
+    _check(capi, oracle, a, b, dict(kiters=1, liters=1, cgiters=6, lambdac=0.3), u0=u0, v0=v0, case="q_2090x1730_nc2_hint")
 
 
 def test_first_guess_and_hint_term(capi, oracle):
@@ -121,7 +149,7 @@ def test_first_guess_and_hint_term(capi, oracle):
     tu, tv = synth.true_lattice_flow(nx, ny)
     u0 = (tu + 0.3).astype(np.float32)
     v0 = (tv - 0.2).astype(np.float32)
-    _check(capi, oracle, a, b, dict(kiters=3, lambdac=0.5), u0, v0)
+    _check(capi, oracle, a, b, dict(kiters=3, lambdac=0.5), u0, v0, case="hint_120x88")
 
 
 def test_early_exit_of_the_pcg_loop(capi, oracle, golden_flow):
@@ -132,7 +160,7 @@ def test_early_exit_of_the_pcg_loop(capi, oracle, golden_flow):
     u0 = np.full(a.shape[1:], 2.0, np.float32)
     v0 = np.full(a.shape[1:], -1.0, np.float32)
     prm = dict(kiters=2, dozim=0, lambdac=0.5, alpha=8.0, lambda_=0.5)
-    d, io, ig = _check(capi, oracle, a, b, prm, u0, v0)
+    d, io, ig = _check(capi, oracle, a, b, prm, u0, v0, case="early_exit_60x44")
     assert io == int(golden_flow[name + "_its"]) and io < 2 * 3 * 3 * 30
     assert ig == io
 
@@ -282,6 +310,39 @@ def test_batch_entry_equals_single_runs(capi):
     for (a, b), (u, v) in zip(pairs, outs):
         us, vs = capi.flow(a, b, prm)
         assert np.array_equal(u, us) and np.array_equal(v, vs)
+
+
+def test_config4_batch_of_64_pairs_2000(capi):
+    """BASELINE.json configs[4]: a batch of 64 independent 2000 x 2000 pairs (kiters 6, the command line's liters 3 and
+    cgiters 30) through octane_vof_batch_run with its default lanes.  Every pair has to come back bit-equal to a
+    single-plan run of the same pair with the fixed 6 * 3 * 3 * 30 = 1620 iterations: lanes share a GPU, never a result."""
+    import torch
+    n, npairs = 2000, 64
+    prm = capi.FlowParams(kiters=6)
+    pairs = []
+    for s in range(npairs):
+        a, b = synth.lattice_scene(n, n, seed=20240617 + s, device="cuda")
+        pairs.append((a.cpu().numpy(), b.cpu().numpy()))
+    torch.cuda.synchronize()
+    outs = capi.batch_flow(pairs, prm, devices=[0])
+    assert len(outs) == npairs
+    pl = capi.Plan(n, n, 1, prm)
+    nbad, worst = 0, 0.0
+    for k, ((a, b), (u, v)) in enumerate(zip(pairs, outs)):
+        us, vs = pl.run_host(a, b)
+        assert pl.last_iterations() == 6 * 3 * 3 * 30, k
+        assert np.isfinite(u).all() and np.isfinite(v).all(), k
+        same = np.array_equal(u, us) and np.array_equal(v, vs)
+        nbad += 0 if same else 1
+        worst = max(worst, rel_l2(u, v, us, vs))
+    pl.close()
+    tu, tv = synth.true_lattice_flow(n, n)
+    m = n // 8
+    eu = np.abs(outs[-1][0].astype(np.float64) - tu)[m:-m, m:-m].mean(); ev = np.abs(outs[-1][1].astype(np.float64) - tv)[m:-m, m:-m].mean()
+    print(f"PARITY case=config4_batch64 64 x {n}x{n}: pairs differing from their single-plan run {nbad}/64, worst relL2 {worst:.3e}; "
+          f"mean |flow - truth| of the last pair {eu:.4f}, {ev:.4f} px")
+    assert nbad == 0, f"{nbad} of 64 pairs differ from their single-plan runs (worst relative L2 {worst:.3e})"
+    assert eu < 0.05 and ev < 0.05
 
 
 def test_device_pointer_entry_equals_host_entry(capi):

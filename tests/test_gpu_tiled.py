@@ -175,6 +175,52 @@ def test_full_disk_quarter_scale_four_bands(capi):
     assert rel_l2(ut, vt, up, vp) < ORDER_BAR
 
 
+def test_config3_full_disk_10848_four_bands_equals_plain_plan(capi):
+    """BASELINE.json configs[3] at full size and full work: a 10848 x 10848 full-disk pair, SURVEY 8d's R1 parameters
+    (kiters 8, liters 3, cgiters 30 -> 2160 PCG iterations), split four ways through octane_vof_tiled_* (virtual bands
+    on the one device a test box has: same kernels, same band bookkeeping, same exchange protocol as four devices),
+    against the plain plan on the same inputs.  u / v are in-out with a zero first guess (ref .cu:1213).  The banded
+    solve is the same global PCG with another grouping of the fp64 partial sums: expected bit-identical, asserted
+    <= 2e-5 relative L2 with equal iteration counts."""
+    import torch
+    n = 10848
+    dev = torch.device("cuda:0")
+    a, b = synth.lattice_scene(n, n, seed=20240613 + 3, device=dev)
+    z = torch.zeros(n, n, device=dev)
+    ou, ov = torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)
+    prm = capi.FlowParams(kiters=8, liters=3, cgiters=30)
+    torch.cuda.synchronize()
+    pl = capi.Plan(n, n, 1, prm)
+    pl.run_device(a.data_ptr(), b.data_ptr(), ou.data_ptr(), ov.data_ptr())
+    torch.cuda.synchronize()
+    up, vp, ip = ou.clone(), ov.clone(), pl.last_iterations()
+    pl.close()
+    assert ip == 8 * 3 * 3 * 30
+    tp = capi.TiledPlan(n, n, 1, prm, nbands=4, devices=[0, 0, 0, 0])
+    nbanded = tp.banded_levels
+    assert nbanded == 2                                   # 10848^2 and 5424^2 are above the default 12 Mpixel threshold
+    tp.load_device(a.data_ptr(), b.data_ptr(), z.data_ptr(), z.data_ptr())
+    tp.solve()
+    tp.fetch_device(ou.data_ptr(), ov.data_ptr())
+    torch.cuda.synchronize()
+    its = tp.last_iterations()
+    tp.close()
+    assert bool(torch.isfinite(ou).all()) and bool(torch.isfinite(ov).all())
+    num = ((ou - up).double() ** 2).sum() + ((ov - vp).double() ** 2).sum()
+    den = (up.double() ** 2).sum() + (vp.double() ** 2).sum()
+    d = float(torch.sqrt(num / den))
+    ndiff = int((ou != up).sum() + (ov != vp).sum())
+    tu, tv = synth.true_lattice_flow(n, n, xp=torch)
+    m = n // 8
+    eu = float((ou[m:-m:16, m:-m:16].double().cpu() - tu[m:-m:16, m:-m:16]).abs().mean())
+    ev = float((ov[m:-m:16, m:-m:16].double().cpu() - tv[m:-m:16, m:-m:16]).abs().mean())
+    print(f"PARITY case=config3_full_disk_4_bands {n}x{n}: banded vs plain relL2 {d:.3e} ({ndiff} values differ), "
+          f"iterations plain/banded {ip}/{its}, banded levels {nbanded}, mean |flow - truth| {eu:.4f}, {ev:.4f} px")
+    assert its == ip
+    assert d <= ORDER_BAR
+    assert eu < 0.05 and ev < 0.05
+
+
 @pytest.mark.parametrize("nbands", [2, 3])
 def test_bands_above_four_megapixels_recompute_q(capi, oracle, nbands):
     """Bands of 3 * 2^20 pixels and more run the q-recomputing fused kernel: nothing is stored on halo rows, a band reads r on
