@@ -315,11 +315,9 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     }
     // plane pointers for an arena starting at `base`
     auto carve = [&](float *base) {
+        // planes sit at the same OFFSETS in every arena (row bands address a neighbour's plane as "my pointer moved by the
+        // distance between the arena bases", BandNet::peer), so nothing here may depend on the absolute address
         float *cur = base;
-        if (align_f) {   // start the first plane on the same alignment
-            uintptr_t a = (uintptr_t)cur, al = align_f * 4 > (4u << 20) ? (4u << 20) : align_f * 4;
-            cur = (float *)((a + al - 1) / al * al);
-        }
         // multi-channel fields are addressed as base + c * plane0, so their planes stay plane0 apart
         auto take = [&](size_t n) { float *r = cur; cur += (n - 1) * pl->plane0 + stride; return r; };
         pl->img1p = take(nc); pl->img2p = take(nc); pl->uh = take(1); pl->vh = take(1);

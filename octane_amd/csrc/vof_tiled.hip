@@ -129,13 +129,19 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
     for (int a = 0; a < nbands; a++)
         for (int b = 0; b < nbands; b++)
             if (t->dev[a] != t->dev[b]) {
+                // the PCG kernels read the other bands' partials and edge rows in place: without peer access there is no
+                // solve, so both "cannot" and "could not be enabled" are errors (only "already enabled" is fine)
                 int can = 0;
-                if (hipSetDevice(t->dev[a]) == hipSuccess && hipDeviceCanAccessPeer(&can, t->dev[a], t->dev[b]) == hipSuccess && can)
-                    (void)hipDeviceEnablePeerAccess(t->dev[b], 0);
+                hipError_t pe = hipSetDevice(t->dev[a]);
+                if (pe == hipSuccess) pe = hipDeviceCanAccessPeer(&can, t->dev[a], t->dev[b]);
+                if (pe == hipSuccess && can) {
+                    pe = hipDeviceEnablePeerAccess(t->dev[b], 0);
+                    if (pe == hipErrorPeerAccessAlreadyEnabled) pe = hipSuccess;
+                }
                 (void)hipGetLastError();
-                if (!can) {      // the PCG kernels read the other bands' partials and edge rows in place
-                    set_last_error("octane_vof_tiled_create: devices " + std::to_string(t->dev[a]) + " and " +
-                                   std::to_string(t->dev[b]) + " cannot access each other's memory");
+                if (pe != hipSuccess || !can) {
+                    set_last_error("octane_vof_tiled_create: device " + std::to_string(t->dev[a]) + " cannot access the memory of device " +
+                                   std::to_string(t->dev[b]) + (pe != hipSuccess ? std::string(": ") + hipGetErrorString(pe) : std::string(" (no peer path)")));
                     delete t;
                     return OCTANE_E_INVALID;
                 }
@@ -222,8 +228,10 @@ extern "C" size_t octane_vof_tiled_device_bytes(const octane_vof_tiled *t)
 struct SpinBarrier {
     std::atomic<int> arrived{0};
     std::atomic<int> generation{0};
-    // returns false when `timeout_s` (0 = none) passed without everybody arriving
-    bool wait(int n, double timeout_s = 0.)
+    // returns false when `timeout_s` (0 = none) passed without everybody arriving, or when *abort became non-zero while
+    // waiting.  A wait that gives up leaves its arrival counted: the barrier is not to be used again afterwards (the
+    // process form marks itself dead and stops synchronising, ProcNet::sync).
+    bool wait(int n, double timeout_s = 0., const std::atomic<int> *abort = nullptr)
     {
         const int gen = generation.load(std::memory_order_acquire);
         if (arrived.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
@@ -236,9 +244,12 @@ struct SpinBarrier {
         while (generation.load(std::memory_order_acquire) == gen) {
             if (++spins > 4096) {
                 std::this_thread::yield();
-                if (timeout_s > 0. && (spins & 1023) == 0) {
-                    if (spins == 5120) t0 = std::chrono::steady_clock::now();
-                    else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+                if ((spins & 1023) == 0) {
+                    if (abort && abort->load(std::memory_order_acquire) != 0) return false;
+                    if (timeout_s > 0.) {
+                        if (spins == 5120) t0 = std::chrono::steady_clock::now();
+                        else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+                    }
                 }
             }
         }
@@ -570,7 +581,11 @@ extern "C" int octane_vof_tiled_run(octane_vof_tiled *t, const float *img1, cons
 // barrier that lives in a POSIX shared-memory object.  That costs a host round trip per boundary (two per PCG iteration)
 // where the in-process form costs an event wait, and in exchange needs nothing but shared memory between the ranks: no
 // collective library on the data path (RCCL stays what the launcher uses for rendezvous and timing).
-// The barrier gives up after 120 s so that a rank that died cannot leave the others spinning.
+// The barrier gives up after 120 s (OCTANE_MP_TIMEOUT_S) so that a rank that died cannot leave the others spinning: the
+// rank that times out marks the group DEAD in the shared object; from then on no rank of the group waits for or issues
+// anything more, octane_vof_mp_run returns an error on every rank still alive, and the group cannot be used again (the
+// launcher is expected to exit non-zero and start fresh ranks).  A rank that merely FAILED (a HIP error, bad inputs) is
+// different: it keeps walking the protocol so that the others see the flag and return at once, and the group stays usable.
 // =====================================================================================================================
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -579,8 +594,10 @@ extern "C" int octane_vof_tiled_run(octane_vof_tiled *t, const float *img1, cons
 
 struct MpShared {                 // lives in the shared-memory object; zero-filled at creation by rank 0
     SpinBarrier bar;
-    std::atomic<int> failed;      // first failing rank + 1
+    std::atomic<int> failed;      // first failing rank + 1 (cleared by rank 0 for the next call)
     std::atomic<int> ready;       // rank 0 sets it once the object is initialised
+    std::atomic<int> dead;        // a rank timed out at a phase boundary: the barrier state is undefined, nobody synchronises again
+    std::atomic<unsigned long long> nonce;   // of rank 0's IPC handle: tells this run's object from one a crashed run left behind
 };
 
 struct octane_vof_mp {
@@ -592,6 +609,8 @@ struct octane_vof_mp {
     char *arena[kMaxBands] = {nullptr};
     double *parts_all[kMaxBands] = {nullptr};
     bool connected = false;
+    bool dead = false;             // a phase boundary timed out: every further call fails at once
+    double timeout_s = 120.;
     std::vector<std::vector<BandRows>> rows;
     std::string shm_name;
     MpShared *shm = nullptr;
@@ -612,7 +631,8 @@ struct ProcNet : BandNet {
         for (int b = 0; b < nb; b++) { arena[b] = m->arena[b]; parts[b] = m->parts_all[b]; }
     }
     octane_vof_plan *plan(int) override { return m->pl; }
-    bool failed() override { return m->shm->failed.load(std::memory_order_relaxed) != 0; }
+    bool dead() const { return m->shm->dead.load(std::memory_order_acquire) != 0; }
+    bool failed() override { return m->shm->failed.load(std::memory_order_relaxed) != 0 || dead(); }
     void fail(int b, int code, const std::string &msg) override
     {
         if (rc == OCTANE_OK) { rc = code; error = msg; }
@@ -622,8 +642,14 @@ struct ProcNet : BandNet {
     void sync(int b) override
     {
         BandNet &N = *this;
+        if (dead()) return;                         // the walk goes on (nothing is issued: failed()), but nobody waits any more
         BAND_HIP(hipStreamSynchronize(m->pl->own_stream));
-        if (!m->shm->bar.wait(nb, 120.)) fail(b, OCTANE_E_HIP, "timed out waiting for the other ranks at a phase boundary");
+        if (!m->shm->bar.wait(nb, m->timeout_s, &m->shm->dead)) {
+            const bool first = !dead();
+            m->shm->dead.store(1, std::memory_order_release);
+            fail(b, OCTANE_E_HIP, first ? "timed out waiting for the other ranks at a phase boundary"
+                                        : "another rank timed out at a phase boundary");
+        }
     }
     hipError_t copy(int, void *dst, int, const void *src, size_t bytes) override
     {
@@ -642,7 +668,8 @@ extern "C" int octane_vof_mp_destroy(octane_vof_mp *m)
         if (m->parts_all[b]) (void)hipIpcCloseMemHandle(m->parts_all[b]);
     }
     if (m->shm) {
-        if (m->connected) (void)m->shm->bar.wait(m->world, 20.);      // nobody unmaps what another rank may still read
+        // nobody unmaps what another rank may still read (a dead group has stopped reading)
+        if (m->connected && !m->dead && m->shm->dead.load() == 0) (void)m->shm->bar.wait(m->world, 20., &m->shm->dead);
         munmap(m->shm, sizeof(MpShared));
         if (m->rank == 0) shm_unlink(m->shm_name.c_str());
     }
@@ -685,49 +712,43 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
         for (int b = 0; b < world; b++) { r[b].y0 = edges[b]; r[b].y1 = edges[b + 1]; }
         m->rows[k] = r;
     }
-    // the shared-memory object: rank 0 creates and initialises it, the others wait for it to appear
-    int fd = -1;
+    if (const char *e = getenv("OCTANE_MP_TIMEOUT_S")) { const double v = atof(e); if (v > 0.) m->timeout_s = v; }
+    // The shared-memory object.  Rank 0 creates and initialises it HERE (removing whatever an earlier, crashed run left
+    // under the name); the other ranks open it in octane_vof_mp_connect, i.e. after the host program's all-gather of the
+    // handles, which rank 0 only joins after this function has returned -- so they can only ever see this run's object --
+    // and they check the nonce rank 0 derived from its own IPC handle against the all-gathered handle.
     if (rank == 0) {
         shm_unlink(shm_name);
-        fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd >= 0 && ftruncate(fd, sizeof(MpShared)) != 0) { close(fd); fd = -1; }
-    } else {
-        for (int tries = 0; tries < 6000 && fd < 0; tries++) {     // up to 60 s
-            fd = shm_open(shm_name, O_RDWR, 0600);
-            if (fd >= 0) {
-                struct stat st;
-                if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(MpShared)) { close(fd); fd = -1; }
-            }
-            if (fd < 0) usleep(10000);
-        }
-    }
-    if (fd < 0) {
-        set_last_error(std::string("octane_vof_mp_create: cannot open shared memory object ") + shm_name);
-        octane_vof_mp_destroy(m);
-        return OCTANE_E_INVALID;
-    }
-    void *mem = mmap(nullptr, sizeof(MpShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (mem == MAP_FAILED) {
-        set_last_error("octane_vof_mp_create: mmap of the shared memory object failed");
-        octane_vof_mp_destroy(m);
-        return OCTANE_E_INVALID;
-    }
-    m->shm = static_cast<MpShared *>(mem);
-    if (rank == 0) {
-        new (m->shm) MpShared();
-        m->shm->failed.store(0);
-        m->shm->ready.store(1, std::memory_order_release);
-    } else {
-        for (int tries = 0; tries < 6000 && m->shm->ready.load(std::memory_order_acquire) != 1; tries++) usleep(10000);
-        if (m->shm->ready.load(std::memory_order_acquire) != 1) {
-            set_last_error("octane_vof_mp_create: rank 0 never initialised the shared memory object");
+        const int fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, sizeof(MpShared)) != 0) {
+            if (fd >= 0) close(fd);
+            set_last_error(std::string("octane_vof_mp_create: cannot create shared memory object ") + shm_name);
             octane_vof_mp_destroy(m);
             return OCTANE_E_INVALID;
         }
+        void *mem = mmap(nullptr, sizeof(MpShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (mem == MAP_FAILED) {
+            set_last_error("octane_vof_mp_create: mmap of the shared memory object failed");
+            octane_vof_mp_destroy(m);
+            return OCTANE_E_INVALID;
+        }
+        m->shm = static_cast<MpShared *>(mem);
+        new (m->shm) MpShared();
+        m->shm->failed.store(0);
+        m->shm->dead.store(0);
+        m->shm->nonce.store(0);
     }
     *out = m;
     return OCTANE_OK;
+}
+
+static unsigned long long handle_nonce(const MpHandles &h)     // FNV-1a of rank 0's handles, never 0
+{
+    unsigned long long x = 1469598103934665603ull;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(&h);
+    for (size_t i = 0; i < sizeof h; i++) { x ^= p[i]; x *= 1099511628211ull; }
+    return x ? x : 1;
 }
 
 extern "C" int octane_vof_mp_handles(octane_vof_mp *m, void *buf)
@@ -735,9 +756,14 @@ extern "C" int octane_vof_mp_handles(octane_vof_mp *m, void *buf)
     if (!m || !buf) return OCTANE_E_INVALID;
     TILED_TRY(hipSetDevice(m->device));
     MpHandles h;
+    std::memset(&h, 0, sizeof h);
     TILED_TRY(hipIpcGetMemHandle(&h.arena, m->pl->arena));
     TILED_TRY(hipIpcGetMemHandle(&h.parts, m->parts));
     std::memcpy(buf, &h, sizeof h);
+    if (m->rank == 0) {                          // the object is ready for the others once the nonce is in place
+        m->shm->nonce.store(handle_nonce(h), std::memory_order_release);
+        m->shm->ready.store(1, std::memory_order_release);
+    }
     return OCTANE_OK;
 }
 
@@ -746,6 +772,27 @@ extern "C" int octane_vof_mp_connect(octane_vof_mp *m, const void *all_handles)
     if (!m || !all_handles || m->connected) { set_last_error("octane_vof_mp_connect: invalid argument"); return OCTANE_E_INVALID; }
     TILED_TRY(hipSetDevice(m->device));
     const MpHandles *h = static_cast<const MpHandles *>(all_handles);
+    if (m->rank != 0) {       // rank 0's object exists by now (see octane_vof_mp_create); a few retries cover slow filesystems only
+        int fd = -1;
+        for (int tries = 0; tries < 500 && fd < 0; tries++) {
+            fd = shm_open(m->shm_name.c_str(), O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat st;
+                if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(MpShared)) { close(fd); fd = -1; }
+            }
+            if (fd < 0) usleep(10000);
+        }
+        if (fd < 0) { set_last_error("octane_vof_mp_connect: cannot open shared memory object " + m->shm_name); return OCTANE_E_INVALID; }
+        void *mem = mmap(nullptr, sizeof(MpShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (mem == MAP_FAILED) { set_last_error("octane_vof_mp_connect: mmap of the shared memory object failed"); return OCTANE_E_INVALID; }
+        m->shm = static_cast<MpShared *>(mem);
+        if (m->shm->ready.load(std::memory_order_acquire) != 1 || m->shm->nonce.load(std::memory_order_acquire) != handle_nonce(h[0])) {
+            set_last_error("octane_vof_mp_connect: shared memory object " + m->shm_name + " is not this run's (stale object of a crashed run?)");
+            munmap(m->shm, sizeof(MpShared)); m->shm = nullptr;
+            return OCTANE_E_INVALID;
+        }
+    }
     for (int b = 0; b < m->world; b++) {
         if (b == m->rank) continue;
         void *pa = nullptr, *pp = nullptr;
@@ -755,7 +802,11 @@ extern "C" int octane_vof_mp_connect(octane_vof_mp *m, const void *all_handles)
         m->parts_all[b] = static_cast<double *>(pp);
     }
     m->connected = true;
-    if (!m->shm->bar.wait(m->world, 120.)) { set_last_error("octane_vof_mp_connect: the other ranks did not arrive"); return OCTANE_E_HIP; }
+    if (!m->shm->bar.wait(m->world, m->timeout_s, &m->shm->dead)) {
+        m->shm->dead.store(1); m->dead = true;
+        set_last_error("octane_vof_mp_connect: the other ranks did not arrive");
+        return OCTANE_E_HIP;
+    }
     return OCTANE_OK;
 }
 
@@ -779,6 +830,11 @@ extern "C" int octane_vof_mp_run(octane_vof_mp *m, const float *img1, const floa
         set_last_error("octane_vof_mp_run: invalid argument (or octane_vof_mp_connect not called)");
         return OCTANE_E_INVALID;
     }
+    if (m->dead || m->shm->dead.load(std::memory_order_acquire) != 0) {
+        m->dead = true;
+        set_last_error("octane_vof_mp_run: this group of ranks timed out at a phase boundary earlier and cannot be used again; start fresh ranks");
+        return OCTANE_E_HIP;
+    }
     TILED_TRY(hipSetDevice(m->device));
     octane_vof_plan *pl = m->pl;
     ProcNet N(m);
@@ -793,7 +849,12 @@ extern "C" int octane_vof_mp_run(octane_vof_mp *m, const float *img1, const floa
     m->last_cur = N.cur[m->rank];
     if (N.failed()) {
         set_last_error("octane_vof_mp_run (rank " + std::to_string(m->rank) + "): " + (N.error.empty() ? std::string("another rank failed") : N.error));
-        m->shm->bar.wait(m->world, 20.);          // everybody has seen the flag before rank 0 clears it for the next call
+        if (N.dead()) {                           // a rank is gone: no more synchronisation of any kind, the group is finished
+            m->dead = true;
+            (void)hipStreamSynchronize(pl->own_stream);
+            return N.rc != OCTANE_OK ? N.rc : OCTANE_E_HIP;
+        }
+        m->shm->bar.wait(m->world, 20., &m->shm->dead);   // everybody has seen the flag before rank 0 clears it for the next call
         if (m->rank == 0) m->shm->failed.store(0);
         return N.rc != OCTANE_OK ? N.rc : OCTANE_E_HIP;
     }

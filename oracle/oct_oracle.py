@@ -48,13 +48,11 @@ class _Trace(C.Structure):
 
 def build(force: bool = False) -> None:
     """Compile the oracle (and, when /root/reference is present, oracle/_ref)."""
-    need = force or not all(os.path.exists(os.path.join(_HERE, n))
-                            for n in ("liboct_oracle.so", "liboct_oracle_fma.so", "liboct_oracle_omp.so"))
-    if need:
-        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    # make decides what is out of date (a changed vof_oracle.c must not be shadowed by an older .so)
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + ["all"])
     ref = os.environ.get("OCT_REFERENCE", "/root/reference")
-    if os.path.isdir(os.path.join(ref, "src")) and (force or not os.path.exists(ref_helpers_path())):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "ref", f"REF={ref}"])
+    if os.path.isdir(os.path.join(ref, "src")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + ["ref", f"REF={ref}"])
 
 
 def ref_helpers_path() -> str:
@@ -83,6 +81,11 @@ def lib(flavour: str = "strict") -> C.CDLL:
     L.oct_oracle_gauss_taps.argtypes = [C.c_float, C.c_int, _F]
     L.oct_oracle_blur_rows.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
     L.oct_oracle_blur_cols.argtypes = [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.oct_oracle_clamp_coord.restype = C.c_float
+    L.oct_oracle_clamp_coord.argtypes = [C.c_float, C.c_int, C.POINTER(C.c_int)]
+    L.oct_oracle_bilinear.restype = C.c_float
+    L.oct_oracle_bilinear.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.oct_oracle_bicubic.restype = C.c_float
     L.oct_oracle_bicubic.argtypes = [_F, C.c_float, C.c_float, C.c_int, C.c_int]
     L.oct_oracle_decimate.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, C.c_float]

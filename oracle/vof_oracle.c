@@ -76,6 +76,49 @@ static float clamp_coord(float x, int n, int *hit)
 
 static float sqf(float x) { return x * x; } /* ref .cu:43-47 jsq */
 
+/* ref .cu:727-747: the warped sampling position (ii + u, jj + v), clamped into the level, and the cell it falls into
+ * (the last cell is xi-2 .. xi-1: a position on the last pixel samples that cell's far edge). */
+typedef struct warp_cell { float xw, yw; int x0, y0, hitx, hity; } warp_cell;
+static warp_cell warp_position(float px, float py, int xi, int yi)
+{
+    warp_cell w;
+    w.xw = clamp_coord(px, xi, &w.hitx);
+    w.yw = clamp_coord(py, yi, &w.hity);
+    w.x0 = (int)w.xw; w.y0 = (int)w.yw;
+    if (w.x0 == xi - 1) w.x0 = xi - 2;
+    if (w.y0 == yi - 1) w.y0 = yi - 2;
+    return w;
+}
+/* ref .cu:56-64 oct_binterp_coefs_cu: the four bilinear weights of a position inside the unit cell at (x0, y0), in float */
+static void bilinear_weights(float xw, float yw, int x0, int y0, float p[4])
+{
+    float fx1 = (float)x0, fx2 = (float)(x0 + 1), fy1 = (float)y0, fy2 = (float)(y0 + 1);
+    p[0] = (fx2 - xw) / (fx2 - fx1);
+    p[1] = (xw - fx1) / (fx2 - fx1);
+    p[2] = ((fy2 - yw) / (fy2 - fy1));
+    p[3] = ((yw - fy1) / (fy2 - fy1));
+}
+/* ref .cu:63 / :70 oct_coef_binterp_cu: the weights applied to the cell's four corner values, in the reference's order */
+static float bilinear_apply(const float p[4], float f11, float f21, float f12, float f22)
+{
+    return p[2] * ((p[0]) * f11 + (p[1]) * f21) + p[3] * ((p[0]) * f12 + (p[1]) * f22);
+}
+
+/* Test hooks for the pins against the reference's own plain-C++ code (include/oct_bc.h, src/oct_binterp.cc): exactly the
+ * functions the assembly below uses. */
+float oct_oracle_clamp_coord(float x, int n, int *hit) { return clamp_coord(x, n, hit); }
+float oct_oracle_bilinear(float px, float py, int xi, int yi, float f11, float f21, float f12, float f22,
+                          float *p4, int *cell_xy, int *hit_xy)
+{
+    warp_cell w = warp_position(px, py, xi, yi);
+    float p[4];
+    bilinear_weights(w.xw, w.yw, w.x0, w.y0, p);
+    if (p4) { p4[0] = p[0]; p4[1] = p[1]; p4[2] = p[2]; p4[3] = p[3]; }
+    if (cell_xy) { cell_xy[0] = w.x0; cell_xy[1] = w.y0; }
+    if (hit_xy) { hit_xy[0] = w.hitx; hit_xy[1] = w.hity; }
+    return bilinear_apply(p, f11, f21, f12, f22);
+}
+
 /* ref .cu:49-54 zoom_size (factor is a float promoted to double at the call) */
 void oct_oracle_level_dims(int nx, int ny, float factor, int *lx, int *ly)
 {
@@ -327,25 +370,17 @@ void oct_oracle_assemble(const oct_oracle_level *L, const float *u, const float 
         /* ref .cu:727-747 warped sampling position */
         float t1 = 0, t2 = 0, t4 = 0, t5 = 0, t6 = 0, e1 = 0;
         float g1 = 0, g2s = 0, g4 = 0, g5 = 0, g6 = 0, e2 = 0;
-        int hitx, hity;
-        float xw = clamp_coord((float)(ii + uc), xi, &hitx);
-        float yw = clamp_coord((float)(jj + vc), yi, &hity);
-        int x0 = (int)xw, y0 = (int)yw;
-        if (x0 == xi - 1) x0 = xi - 2;
-        if (y0 == yi - 1) y0 = yi - 2;
+        const warp_cell wc = warp_position((float)(ii + uc), (float)(jj + vc), xi, yi);
+        const int hitx = wc.hitx, hity = wc.hity, x0 = wc.x0, y0 = wc.y0;
         long rowbase = (long)xi * y0;
+        float pw[4];                             /* ref .cu:56-71 bilinear weights, once per pixel */
+        bilinear_weights(wc.xw, wc.yw, x0, y0, pw);
 
         for (int c = 0; c < nc; c++) {
             long cb = npix * c;
             long here = ii + (long)xi * jj + cb;
             long c1 = x0 + rowbase + cb, c2 = c1 + 1, c3 = c1 + xi, c4 = c3 + 1;
-            /* ref .cu:56-71 bilinear weights */
-            float fx1 = (float)x0, fx2 = (float)(x0 + 1), fy1 = (float)y0, fy2 = (float)(y0 + 1);
-            float p1 = (fx2 - xw) / (fx2 - fx1);
-            float p2 = (xw - fx1) / (fx2 - fx1);
-            float p3 = ((fy2 - yw) / (fy2 - fy1));
-            float p4 = ((yw - fy1) / (fy2 - fy1));
-#define BIL(F) (p3 * ((p1) * (F)[c1] + (p2) * (F)[c2]) + p4 * ((p1) * (F)[c3] + (p2) * (F)[c4]))
+#define BIL(F) bilinear_apply(pw, (F)[c1], (F)[c2], (F)[c3], (F)[c4])
             float w2 = BIL(L->img2);
             float Ix = BIL(L->gx2);
             float Iy = BIL(L->gy2);

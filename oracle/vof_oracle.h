@@ -42,6 +42,9 @@ float oct_oracle_bicubic(const float *src, float uu, float vv, int nx, int ny);
 void  oct_oracle_decimate(const float *blurred, float *out, int nx, int ny, int nc, float factor);
 void  oct_oracle_gradient(const float *f, float *gx, float *gy, int xi, int yi, int nc);
 void  oct_oracle_upsample_flow(const float *coarse, float *fine, int nx, int ny, int nxx, int nyy, float sf);
+float oct_oracle_clamp_coord(float x, int n, int *hit);                       /* ref .cu:26-41 */
+float oct_oracle_bilinear(float px, float py, int xi, int yi, float f11, float f21, float f12, float f22,
+                          float *p4, int *cell_xy, int *hit_xy);             /* ref .cu:56-71, 727-747 */
 long  oct_oracle_nnz_before(long n, int ii, int jj, int xi, int yi);
 void  oct_oracle_assemble(const oct_oracle_level *L, const float *u, const float *v,
                           const float *ut, const float *vt, double al1, double alpha,

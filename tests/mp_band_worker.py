@@ -33,6 +33,31 @@ def main():
         prm = capi.FlowParams(kiters=kit, liters=lit, cgiters=cg, lambdac=0.4, device=0)
     mp = capi.MpPlan(nx, ny, 1, prm, rank, world, f"/octane_test_{os.environ['MASTER_PORT']}", all_gather, min_band_pixels=minpix)
     banded = mp.banded_levels
+    if len(sys.argv) > 7 and sys.argv[7] == "loop":
+        # dead-peer drill: solve again and again until the library reports that the group is dead (the test kills another
+        # rank meanwhile); the survivor must get an error -- not hang --, a second call must fail at once, close must return
+        import time
+        print("MP_LOOP_RUNNING", flush=True)
+        t_err = None
+        try:
+            for _ in range(100000):
+                t_call = time.perf_counter()
+                mp.run_host(a, b, u0, v0)
+        except capi.OctaneError as e:
+            t_err = time.perf_counter() - t_call
+            msg = str(e)
+        t2 = time.perf_counter()
+        second_failed = False
+        try:
+            mp.run_host(a, b, u0, v0)
+        except capi.OctaneError:
+            second_failed = True
+        t2 = time.perf_counter() - t2
+        t3 = time.perf_counter()
+        mp.close()
+        t3 = time.perf_counter() - t3
+        print(f"MP_DEAD_RESULT error_after={t_err:.2f}s second_call_failed={second_failed} in {t2:.3f}s close={t3:.3f}s msg={msg!r}", flush=True)
+        os._exit(0 if (t_err is not None and second_failed and t2 < 1.0 and t3 < 5.0) else 1)     # no gloo teardown with a dead peer
     for rep in range(2):                                   # twice: the protocol must be re-enterable
         u, v = mp.run_host(a, b, u0, v0)
     ok = True

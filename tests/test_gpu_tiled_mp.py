@@ -44,3 +44,38 @@ def test_one_band_per_process_matches_plain_plan(world, args):
     line = [l for l in outs[0].splitlines() if l.startswith("MP_RESULT")]
     assert line and "ok=True" in line[0], outs[0]
     assert "banded=0" not in line[0]
+
+
+def test_a_dead_rank_does_not_leave_the_survivor_spinning():
+    """a rank that dies mid-run.  Two ranks solve in a loop; rank 1 is killed (its exact PID) while they run.
+    Rank 0 must come back from octane_vof_mp_run with an error within the barrier's time-out (4 s here, 120 s by default)
+    -- one time-out, not one per remaining phase boundary --, every later call must fail at once, and close must return."""
+    import time
+    world, port = 2, _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OCTANE_MP_TIMEOUT_S="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_band_worker.py"), "640", "576", "2", "3", "30", "1", "loop"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    try:
+        line = ""
+        t0 = time.time()
+        while "MP_LOOP_RUNNING" not in line and time.time() - t0 < 240:      # the first torch import of a fresh box is slow
+            line = procs[0].stdout.readline()
+            if not line and procs[0].poll() is not None:
+                break
+        assert "MP_LOOP_RUNNING" in line, line
+        time.sleep(2.0)                      # both ranks are inside octane_vof_mp_run now
+        procs[1].kill()
+        t_kill = time.time()
+        out0 = procs[0].communicate(timeout=60)[0]
+        waited = time.time() - t_kill
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res = [l for l in out0.splitlines() if l.startswith("MP_DEAD_RESULT")]
+    print(out0)
+    assert res and procs[0].returncode == 0, out0
+    assert waited < 25.0, f"the survivor needed {waited:.1f} s after the kill (time-out 4 s)"

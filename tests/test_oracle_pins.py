@@ -118,3 +118,79 @@ def test_live_reference_helper_agrees_with_committed_goldens(oracle, golden_ref)
     ny, nx = img.shape
     for (u, v), want in list(zip(golden_ref["bic_pts"], golden_ref["bic_vals"]))[:50]:
         assert f(img, float(u), float(v), nx, ny, 1) == want
+
+
+# ---- the warp's bilinear weights and the clamp, against the reference's own plain-C++ code -----------------------------------
+@pytest.fixture(scope="module")
+def golden_bil():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_binterp_bc.npz"))
+
+
+def test_clamp_matches_reference_oct_bc(oracle, golden_bil):
+    """ref include/oct_bc.h:1-20 (oct_bc<T>, compiled from the reference into oracle/_ref; goldens by
+    tests/golden/make_ref_binterp_goldens.py) is the CPU twin of the device clamp oct_bc_cu (.cu:26-41): clamp -- not
+    reflect -- to [0, n-1] and report whether it clamped.  The oracle's clamp_coord must agree bit for bit, flag included."""
+    L = oracle.lib()
+    hit = C.c_int()
+    xs, ns = golden_bil["bc_x"], golden_bil["bc_n"]
+    got = np.array([(L.oct_oracle_clamp_coord(float(x), int(n), C.byref(hit)), hit.value) for x, n in zip(xs, ns)])
+    assert np.array_equal(got[:, 0].astype(np.float32), golden_bil["bc_float"])
+    assert np.array_equal(got[:, 1].astype(np.int32), golden_bil["bc_float_hit"])
+    # the double and int instantiations say the same thing (the quirk is in the comparison x >= nx, not in the type)
+    assert np.array_equal(got[:, 0], golden_bil["bc_double"])
+    assert np.array_equal(got[:, 1].astype(np.int32), golden_bil["bc_double_hit"])
+    gi = np.array([(L.oct_oracle_clamp_coord(float(x), int(n), C.byref(hit)), hit.value) for x, n in zip(golden_bil["bc_xi"], golden_bil["bc_ni"])])
+    assert np.array_equal(gi[:, 0].astype(np.int32), golden_bil["bc_int"]) and np.array_equal(gi[:, 1].astype(np.int32), golden_bil["bc_int_hit"])
+    assert golden_bil["bc_float_hit"].sum() > 20 and (golden_bil["bc_float_hit"] == 0).sum() > 100     # both branches exercised
+
+
+def test_bilinear_warp_matches_reference_oct_binterp(oracle, golden_bil):
+    """ref src/oct_binterp.cc:24-41 (oct_binterp_coefs, oct_coef_binterp; double) is the CPU twin of the device warp's
+    oct_binterp_coefs_cu / oct_coef_binterp_cu (.cu:56-71; float).  On float-representable positions the double weights are
+    exact, so the oracle's float weights must equal them to float rounding -- bit for bit wherever Sterbenz' lemma makes
+    the float subtraction exact (cells >= 1) -- and the interpolated value must be the double one within float rounding of
+    a four-term sum.  Cell selection (last cell capped at n-2, .cu:738-745) is checked against the generator's rule."""
+    L = oracle.lib()
+    nx, ny = int(golden_bil["bil_nx"]), int(golden_bil["bil_ny"])
+    p4 = (C.c_float * 4)(); cell = (C.c_int * 2)(); hit = (C.c_int * 2)()
+    px, py, f = golden_bil["bil_px"], golden_bil["bil_py"], golden_bil["bil_f"]
+    want_p, want_v, want_v2 = golden_bil["bil_p"], golden_bil["bil_val"], golden_bil["bil_val_reused"]
+    nexact = 0
+    for k in range(len(px)):
+        v = L.oct_oracle_bilinear(float(px[k]), float(py[k]), nx, ny, *(float(t) for t in f[k]), p4, cell, hit)
+        assert (cell[0], cell[1]) == (int(golden_bil["bil_x0"][k]), int(golden_bil["bil_y0"][k])), k
+        assert (hit[0], hit[1]) == (0, 0), k
+        p = np.array(list(p4), np.float64)
+        np.testing.assert_allclose(p, want_p[k], rtol=0, atol=6e-8, err_msg=str(k))      # float subtraction near 1 - tiny
+        if cell[0] >= 1 and cell[1] >= 1:
+            assert np.array_equal(p.astype(np.float32), want_p[k].astype(np.float32)), k
+            nexact += 1
+        assert abs(p[0] + p[1] - 1.0) < 2e-7 and abs(p[2] + p[3] - 1.0) < 2e-7
+        assert abs(v - want_v[k]) <= 4 * np.spacing(np.float32(255.0)), (k, v, want_v[k])
+        v2 = L.oct_oracle_bilinear(float(px[k]), float(py[k]), nx, ny, *(float(t) for t in f[k, ::-1]), None, None, None)
+        assert abs(v2 - want_v2[k]) <= 4 * np.spacing(np.float32(255.0)), k
+    assert nexact > 500
+    # beyond the level the position is clamped and flagged (the assembly then zeroes the derivatives, .cu:768-779)
+    v = L.oct_oracle_bilinear(-2.5, float(ny) + 3.0, nx, ny, 1.0, 2.0, 3.0, 4.0, p4, cell, hit)
+    assert (hit[0], hit[1]) == (1, 1) and (cell[0], cell[1]) == (0, ny - 2) and v == 3.0
+
+
+def test_reference_binterp_and_bc_goldens_are_current(oracle, golden_bil):
+    """Where the reference is present (this container, not the GPU box): the committed goldens are what its code returns now."""
+    path = oracle.ref_helpers_path()
+    if not os.path.exists(path) or not os.path.isdir("/root/reference/src"):
+        pytest.skip("no reference build here")
+    R = C.CDLL(path)
+    R.oct_ref_bc_float.restype = C.c_float
+    R.oct_ref_bc_float.argtypes = [C.c_float, C.c_int, C.POINTER(C.c_int)]
+    R.oct_ref_binterp_coefs.restype = C.c_double
+    R.oct_ref_binterp_coefs.argtypes = [C.c_double] * 10 + [C.POINTER(C.c_double)]
+    hit = C.c_int()
+    got = np.array([R.oct_ref_bc_float(float(x), int(n), C.byref(hit)) for x, n in zip(golden_bil["bc_x"], golden_bil["bc_n"])], np.float32)
+    assert np.array_equal(got, golden_bil["bc_float"])
+    buf = (C.c_double * 4)()
+    for k in (0, 5, 100, 599):
+        x0, y0 = float(golden_bil["bil_x0"][k]), float(golden_bil["bil_y0"][k])
+        v = R.oct_ref_binterp_coefs(float(golden_bil["bil_px"][k]), float(golden_bil["bil_py"][k]), x0, x0 + 1, y0, y0 + 1,
+                                    *(float(t) for t in golden_bil["bil_f"][k]), buf)
+        assert v == golden_bil["bil_val"][k]
