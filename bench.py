@@ -45,6 +45,7 @@ FUSED_BYTES_PER_PIXEL_GNC0 = 72        # first GNC step: wx == wy == -1, not rea
 FUSED_Q_BYTES_PER_PIXEL = 64           # k_pcg_fused_q (levels of >= 3 * 2^20 pixels): q = A p is formed again, neither written nor read
 FUSED_Q_BYTES_PER_PIXEL_GNC0 = 56
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+TILED_SEED = 20240615              # (with 20240616 the 85 x 85 coarsest level of a 10848^2 / 8-level pyramid runs away at R1's iteration counts)
 TILED_PARITY_BAR = 2e-5            # banded vs plain solve of the same frame: two groupings of the same fp64 partial sums
 
 
@@ -184,7 +185,7 @@ def tiled(args, capi, synth, torch):
     devices = [b % ndev for b in range(args.bands)]
     dev = torch.device("cuda", devices[0])
     torch.cuda.set_device(dev)
-    a, b = synth.lattice_scene(n, n, seed=20240613 + 3, device=dev)
+    a, b = synth.lattice_scene(n, n, seed=TILED_SEED, device=dev)
     z = torch.zeros(n, n, device=dev)
     prm = capi.FlowParams(kiters=args.kiters, liters=args.liters, cgiters=args.cgiters)
     torch.cuda.synchronize()
@@ -239,7 +240,7 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
     (octane_vof_mp_*: HIP IPC mappings of the other ranks' arenas, phase barrier in shared memory; torch.distributed only
     for rendezvous, the handle all-gather and the timing).  Every rank holds the whole pair on its own device."""
     n = args.size
-    a, b = synth.lattice_scene(n, n, seed=20240613 + 3, device=dev)          # same seed on every rank: the same frame
+    a, b = synth.lattice_scene(n, n, seed=TILED_SEED, device=dev)          # same seed on every rank: the same frame
     u = torch.zeros(n, n, device=dev)
     v = torch.zeros(n, n, device=dev)
     prm = capi.FlowParams(kiters=args.kiters, liters=args.liters, cgiters=args.cgiters, device=local)
