@@ -27,6 +27,47 @@ __device__ __forceinline__ double block_sum_256(double v, double *scratch)
     return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
 }
 
+// N sums over a workgroup of NT threads (NT / 64 waves) with one pair of barriers; every thread gets all totals.
+// scratch: (NT / 64) * N doubles.
+template <int N, int NT>
+__device__ __forceinline__ void block_sum_multi(const double (&v)[N], double *scratch, double (&out)[N])
+{
+    constexpr int NW = NT / 64;
+    double w[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) w[j] = wave_sum(v[j]);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                       // scratch may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < N; j++) scratch[j * NW + wave] = w[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double t = scratch[j * NW];
+#pragma unroll
+        for (int i = 1; i < NW; i++) t += scratch[j * NW + i];
+        out[j] = t;
+    }
+}
+template <int N, int NT>
+__device__ __forceinline__ void fold_band_partials_multi(const double *const *blocks, int first_off, int kind_stride, int n,
+                                                         int nbands, double *scratch /* >= (NT / 64) * N */, double (&out)[N])
+{
+    double v[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = 0.;
+    for (int b = 0; b < nbands; b++) {
+        const double *__restrict__ part = blocks[b] + first_off;
+        for (int i = threadIdx.x; i < n; i += NT) {
+#pragma unroll
+            for (int j = 0; j < N; j++) v[j] += part[(size_t)j * kind_stride + i];
+        }
+    }
+    block_sum_multi<N, NT>(v, scratch, out);
+}
+
 // N sums over the workgroup with one pair of barriers; every thread gets all totals.  scratch: 4 * N doubles.
 template <int N>
 __device__ __forceinline__ void block_sum_multi_256(const double (&v)[N], double *scratch, double (&out)[N])
@@ -134,6 +175,48 @@ __device__ __forceinline__ ItemRange item_range_walk(int nitems, int mode)
     }
     return item_range(nitems, mode == 1);
 }
+
+// Tile walk "slabs" (mode >= 5; 2-D tiles of a row-major frame, persistent grid whose size is a multiple of 8).
+// The tile rows are grouped into super-rows of S tile rows; inside a super-row the tiles are ranked column by column and
+// the ranks are cut into 8 equal shares: XCD x (workgroups with blockIdx % 8 == x -- how the hardware deals workgroups
+// over the XCDs today; placement only ever affects speed) owns share x, a vertical slab of ~tiles_x / 8 columns, in EVERY
+// super-row.  A tile's left / right AND upper / lower neighbours are then worked on by the same XCD at about the same
+// time, so the ring lines neighbouring tiles share can be hits in that XCD's L2 instead of second fetches through the
+// fabric, while all XCDs still advance through the frame together: one compact front, as with the plain round-robin walk.
+// Shares differ by at most one tile per super-row.  Workgroup (x, j) takes elements j, j + G/8, j + 2G/8, ... of XCD x's
+// sequence (super-row after super-row, rank order inside).
+struct SlabWalk {
+    int tiles_x, tiles_y, S, nfull, rows_last;      // nfull full super-rows, then one of rows_last tile rows (may be 0)
+    int x, per, idx;                                // this workgroup: XCD, workgroups per XCD, current sequence element
+    int lo_full, cnt_full, lo_last, cnt_last;       // XCD x's rank range in a full / in the last super-row
+};
+__device__ __forceinline__ SlabWalk slab_walk_begin(int tiles_x, int tiles_y, int S)
+{
+    SlabWalk w;
+    w.tiles_x = tiles_x; w.tiles_y = tiles_y; w.S = S;
+    w.nfull = tiles_y / S; w.rows_last = tiles_y - w.nfull * S;
+    w.x = blockIdx.x & 7; w.per = gridDim.x >> 3; w.idx = blockIdx.x >> 3;
+    const int nf = tiles_x * S, nl = tiles_x * w.rows_last;
+    w.lo_full = (int)((long)w.x * nf / 8); w.cnt_full = (int)((long)(w.x + 1) * nf / 8) - w.lo_full;
+    w.lo_last = (int)((long)w.x * nl / 8); w.cnt_last = (int)((long)(w.x + 1) * nl / 8) - w.lo_last;
+    return w;
+}
+// current tile as (column, row), or false when this workgroup's walk is over; slab_walk_next advances
+__device__ __forceinline__ bool slab_walk_tile(const SlabWalk &w, int &tc, int &tr)
+{
+    const int in_full = w.nfull * w.cnt_full;
+    if (w.idx < in_full) {
+        const int s = w.idx / w.cnt_full, rank = w.lo_full + (w.idx - s * w.cnt_full);
+        tc = rank / w.S; tr = s * w.S + (rank - tc * w.S);
+        return true;
+    }
+    const int off = w.idx - in_full;
+    if (off >= w.cnt_last) return false;
+    const int rank = w.lo_last + off;
+    tc = rank / w.rows_last; tr = w.nfull * w.S + (rank - tc * w.rows_last);
+    return true;
+}
+__device__ __forceinline__ void slab_walk_next(SlabWalk &w) { w.idx += w.per; }
 
 // Jacobi preconditioner entry exactly as the reference forms it: M = 1./M in double, stored
 // as float (ref .cu:141-149).

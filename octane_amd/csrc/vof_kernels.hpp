@@ -102,6 +102,7 @@ void launch_gradient(hipStream_t s, const float *f, float *gx, float *gy, int w,
 void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpitch,
                      float *fine, int fw, int fh, int fpitch, float sf);
 void set_max_blocks(int n);
+int  pcg_fused_q_stamps(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol, unsigned long long *out16);   // diagnostic
 void set_grid_multiple(int m);           // tuning knob (<= kMaxParts)
 int  grid_multiple();
 int  balanced_grid(long work_items);   // persistent grid: every block gets the same number of items (+-1)
@@ -124,6 +125,25 @@ int  pcg_fused_q_form(int w, int rows, int h);            // 1: a level / band o
 int  pcg_fused_grid_size(int w, int rows, int unit_w, int q_form);   // fused one-kernel-per-iteration PCG
 void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 void launch_flow_update_fused(hipStream_t s, const LevelPtrs &L, int niter_launched, int nparts);
+// ---- whole solve of a mid-size level in one launch, the level resident on chip (pcg_persist.hip) ----
+constexpr int kMidMaxG = 256;        // workgroups of the persistent solve: one per CU
+struct MidGeom { int gx, gy, bh, P, G; };      // sub-domain grid, rows per sub-domain, 8-row slots per thread, workgroups
+struct MidArgs {
+    int gx, gy, bh, G;
+    int k0, k1, kcap;                // this launch runs iterations [k0, k1) of a solve capped at kcap
+    int nparts_asm;                  // partial sums the assembly wrote (r.z, r.r of the right-hand side)
+    int full_state;                  // stepped form: the complete state is stored to / loaded from the level's planes
+    float tol;
+    unsigned long long *ctr;         // grid barrier counter, zeroed ahead of every launch
+    unsigned int *abort_word;        // raised when a barrier timed out
+    double *parts;                   // [2][kPartKinds][kMidMaxG] partial sums by iteration parity
+    float *edges;                    // [G][2][4 sides][6 arrays][128] edge pixels by iteration parity
+};
+int  pcg_mid_config(int w, int h, int ncu, int force_p, MidGeom *g);
+void pcg_mid_configure();
+size_t pcg_mid_workspace_bytes();
+hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom &g, void *workspace, int k0, int k1, int kcap,
+                                int nparts_asm, float tol);
 bool pcg_small_applicable(int w, int h);
 void pcg_small_configure();
 void launch_pcg_solve_small(hipStream_t s, const LevelPtrs &L, int maxit, float tol);   // whole solve + flow update, one workgroup

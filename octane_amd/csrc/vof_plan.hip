@@ -85,6 +85,8 @@ extern "C" int octane_vof_plan_destroy(octane_vof_plan *pl)
     if (pl->d_alpha) (void)hipFree(pl->d_alpha);
     if (pl->d_iters) (void)hipFree(pl->d_iters);
     if (pl->h_iters) (void)hipHostFree(pl->h_iters);
+    if (pl->d_mid) (void)hipFree(pl->d_mid);
+    if (pl->h_mid_abort) (void)hipHostFree(pl->h_mid_abort);
     if (pl->own_stream) (void)hipStreamDestroy(pl->own_stream);
     delete pl;
     return OCTANE_OK;
@@ -253,12 +255,21 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_FUSED_ROWS")) set_fused_rows(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_FUSED_Q")) set_fused_q(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_FUSED_Q_MIN")) set_fused_q_min(atol(e));
+    if (const char *e = getenv("OCTANE_TUNE_PERSIST")) pl->use_persist = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_PERSIST_STEP")) pl->persist_step = atoi(e);
+    if (const char *e = getenv("OCTANE_TUNE_PERSIST_P")) pl->persist_p = atoi(e);
+    if (const char *e = getenv("OCTANE_TUNE_PERSIST_MAX")) pl->persist_max_pixels = atol(e);
+    {
+        hipDeviceProp_t prop;
+        pl->ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }
     if (const char *e = getenv("OCTANE_TUNE_UNIT_W_CAP")) set_unit_w_cap(atoi(e));
     {
         const char *ea = getenv("OCTANE_TUNE_CAP_A"), *eb = getenv("OCTANE_TUNE_CAP_B");
         if (ea || eb) set_pass_caps(ea ? atoi(ea) : 768, eb ? atoi(eb) : 1024);
     }
     pcg_small_configure();
+    pcg_mid_configure();
     set_grid_multiple(pl->xcd_bands == 1 ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
 
@@ -349,6 +360,10 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         if (hipMalloc((void **)&pl->d_iters, sizeof(long long)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         if (hipHostMalloc((void **)&pl->h_iters, sizeof(long long)) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
         *pl->h_iters = 0;
+        if (hipMalloc(&pl->d_mid, pcg_mid_workspace_bytes()) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        if (hipMemset(pl->d_mid, 0, pcg_mid_workspace_bytes()) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipHostMalloc((void **)&pl->h_mid_abort, 16) != hipSuccess) { rc = OCTANE_E_NOMEM; break; }
+        *pl->h_mid_abort = 0;
         if (hipMemset(pl->d_parts, 0, 2 * kPartBlock * sizeof(double)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMemset(pl->d_state, 0, 2 * sizeof(PcgState)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipStreamCreateWithFlags(&pl->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = OCTANE_E_HIP; break; }
@@ -530,6 +545,28 @@ int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur
     return OCTANE_OK;
 }
 
+// Launches of the persistent solve need ALL their workgroups resident at once (they meet at grid barriers).  Two such
+// launches running side by side on one device -- the lanes of a batch, virtual row bands sharing a GPU -- could each hold
+// CUs the other is waiting for, so within this process they are serialised among themselves per device: every launch waits
+// for the event the previous one recorded (on whatever stream that was) and records the next.  Everything else overlaps as
+// before.  (Another PROCESS on the same GPU is not covered: the kernel's barriers are bounded and abort the solve.)
+static std::mutex g_persist_mu;
+static hipEvent_t g_persist_ev[64] = {nullptr};
+static int persist_launch(octane_vof_plan *pl, hipStream_t s, const LevelPtrs &L, const MidGeom &mg, int k0, int k1, int kcap, int nparts_asm)
+{
+    std::lock_guard<std::mutex> g(g_persist_mu);
+    const int d = pl->device & 63;
+    if (!g_persist_ev[d]) {
+        if (hipEventCreateWithFlags(&g_persist_ev[d], hipEventDisableTiming) != hipSuccess) { g_last_error = "persistent solve: hipEventCreate failed"; return OCTANE_E_HIP; }
+    } else if (hipStreamWaitEvent(s, g_persist_ev[d], 0) != hipSuccess) {
+        g_last_error = "persistent solve: hipStreamWaitEvent failed"; return OCTANE_E_HIP;
+    }
+    hipError_t e = launch_pcg_solve_mid(s, L, mg, pl->d_mid, k0, k1, kcap, nparts_asm, pl->tol);
+    if (e == hipSuccess) e = hipEventRecord(g_persist_ev[d], s);
+    if (e != hipSuccess) { g_last_error = std::string("persistent solve: ") + hipGetErrorString(e); return OCTANE_E_HIP; }
+    return OCTANE_OK;
+}
+
 int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur, const LevelCtx &c, bool pf)
 {
     const octane_vof_params &prm = pl->prm;
@@ -544,6 +581,10 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
     const int g_a_unit = pcg_grid_size_unit_w(li.w, li.h);
     const int g_b = pcg_b_grid_size(li.w, li.h);
     const bool small = pl->use_small && pcg_small_applicable(li.w, li.h);
+    // mid-size levels: the whole solve in one persistent launch, the level resident on chip (pcg_persist.hip)
+    MidGeom mg;
+    const bool mid = !small && pl->use_persist && pl->use_fused && !pl->use_graph && pl->d_mid && (long)li.w * li.h <= pl->persist_max_pixels &&
+                     pcg_mid_config(li.w, li.h, pl->ncu, pl->persist_p, &mg) == 1;
 
     for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
         AssembleParams ap;
@@ -572,6 +613,16 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
             }
             if (small) {       // coarsest levels: the whole solve and the flow update in one workgroup
                 launch_pcg_solve_small(s, L, prm.cgiters, pl->tol);
+            } else if (mid) {  // the whole solve and the flow update in one launch of one workgroup per sub-domain
+                const int step = pl->persist_step > 0 ? pl->persist_step : (prm.cgiters > 0 ? prm.cgiters : 1);
+                for (int k0 = 0; k0 < prm.cgiters || k0 == 0; k0 += step) {
+                    const int k1 = k0 + step < prm.cgiters ? k0 + step : prm.cgiters;
+                    e = ev_begin(pl, s, EV_PASS_A, pf);
+                    const int rc = persist_launch(pl, s, L, mg, k0, k1, prm.cgiters, g_asm);
+                    ev_end(e, s);
+                    if (rc) return rc;
+                    if (k1 >= prm.cgiters) break;
+                }
             } else if (pl->use_fused) {
                 for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182, one kernel per iteration
                     e = ev_begin(pl, s, EV_PASS_A, pf);
@@ -654,6 +705,7 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(pl->h_iters, pl->d_iters, sizeof(long long), hipMemcpyDeviceToHost, s));
+    if (pl->d_mid) HIP_TRY(hipMemcpyAsync(pl->h_mid_abort, static_cast<char *>(pl->d_mid) + 8, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     if (prof) {
         (void)hipEventRecord(pl->ev_t1, s);
         HIP_TRY(hipEventSynchronize(pl->ev_t1));
@@ -686,17 +738,30 @@ extern "C" int octane_vof_plan_get_profile(octane_vof_plan *pl, octane_vof_profi
     return OCTANE_OK;
 }
 
+// A persistent solve gives up when its workgroups cannot all become resident (its grid barrier is bounded): the flow of that
+// run is not valid.  Reported by every call that has synchronised with the run; the word is cleared so that the plan stays usable.
+static int persist_check(octane_vof_plan *pl)
+{
+    if (!pl->h_mid_abort || *pl->h_mid_abort == 0) return OCTANE_OK;
+    *pl->h_mid_abort = 0;
+    (void)hipMemset(static_cast<char *>(pl->d_mid) + 8, 0, 4);
+    g_last_error = "a persistent PCG solve could not get all its workgroups resident within 0.25 s (another process with the same kind of "
+                   "kernel on this GPU?): the result of this run is not valid; OCTANE_TUNE_PERSIST=0 selects one launch per iteration";
+    return OCTANE_E_HIP;
+}
+
 extern "C" int octane_vof_plan_wait(octane_vof_plan *pl)
 {
     if (!pl) return OCTANE_E_INVALID;
     HIP_TRY(hipSetDevice(pl->device));
     HIP_TRY(hipStreamSynchronize(pl->own_stream));
-    return OCTANE_OK;
+    return persist_check(pl);
 }
 
 extern "C" long long octane_vof_plan_last_iterations(octane_vof_plan *pl)
 {
     if (!pl) return -1;
+    if (pl->h_mid_abort && *pl->h_mid_abort != 0) return -2;       // the run's persistent solve aborted: see octane_vof_plan_wait
     return *pl->h_iters;
 }
 
@@ -795,6 +860,7 @@ extern "C" int octane_vof_plan_solve(octane_vof_plan *pl, const float *img1, con
         HIP_TRY(hipMemcpy2DAsync(u, dense_row, pl->U[cur], pitched_row, dense_row, ny, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpy2DAsync(v, dense_row, pl->V[cur], pitched_row, dense_row, ny, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (int rc = persist_check(pl)) return rc;
     } else {
         launch_copy2d(s, pl->U[cur], p0, u, nx, nx, ny);
         launch_copy2d(s, pl->V[cur], p0, v, nx, nx, ny);
@@ -1272,6 +1338,38 @@ extern "C" int octane_vof_plan_probe(octane_vof_plan *pl, int level, int iterati
     return OCTANE_OK;
 }
 
+// Diagnostic: where the waves of one launch of the q-recomputing PCG kernel spend their time at pyramid level `level` (shader
+// clock cycles summed over all waves, per seam of a tile: pcg_kernels.hip, g_q_stamps).  even != 0 times a launch that also
+// updates x.  The planes are clobbered, values are irrelevant (stop test held open).
+extern "C" int octane_vof_plan_probe_stamps(octane_vof_plan *pl, int level, int even, int unit_w, unsigned long long *out16)
+{
+    if (!pl || level < 0 || level >= (int)pl->lev.size() || !out16) return OCTANE_E_INVALID;
+    HIP_TRY(hipSetDevice(pl->device));
+    const LevelInfo &li = pl->lev[level];
+    LevelPtrs L;
+    fill_level_ptrs(pl, li, 0, pl->img1p, pl->img2p, pl->uh, pl->vh, L);
+    L.q_form = pcg_fused_q_form(li.w, li.h, li.h);
+    if (!L.q_form) { g_last_error = "octane_vof_plan_probe_stamps: the level does not run the q-recomputing kernel"; return OCTANE_E_INVALID; }
+    L.unit_w = unit_w ? 1 : 0;
+    const int g_f = pcg_fused_grid_size(li.w, li.h, L.unit_w, L.q_form);
+    std::vector<double> ones(2 * (size_t)kPartBlock, 0.0);
+    for (int half = 0; half < 2; half++) {
+        double *blk = ones.data() + (size_t)half * kPartBlock;
+        blk[kPartRz] = 4.0; blk[kPartRr] = 4.0; blk[kPartPq] = 1.0; blk[kPartQz] = 1.0; blk[kPartQmq] = 1.0; blk[kPartRq] = 1.0; blk[kPartQq] = 1.0;
+    }
+    PcgState st[2];
+    st[0].rz = 1.f; st[0].stopped = 0; st[0].iters = 0; st[0].pad = 0;
+    st[1] = st[0];
+    hipStream_t s = pl->own_stream;
+    int rc = 0;
+    for (int rep = 0; rep < 3 && rc == 0; rep++) {
+        HIP_TRY(hipMemcpyAsync(pl->d_parts, ones.data(), 2 * (size_t)kPartBlock * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(pl->d_state, st, sizeof(st), hipMemcpyHostToDevice, s));
+        rc = pcg_fused_q_stamps(s, L, even ? 4 : 5, 1, g_f, 0.f, out16);
+    }
+    return rc == 0 ? OCTANE_OK : OCTANE_E_HIP;
+}
+
 // Developer knob setter (the same knobs the OCTANE_TUNE_* environment variables set at plan creation).
 extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
 {
@@ -1288,6 +1386,9 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "unit_w") pl->use_unit_w = value != 0;
     else if (k == "fused") pl->use_fused = value != 0;
     else if (k == "fused_q") set_fused_q(value);
+    else if (k == "persist") pl->use_persist = value != 0;
+    else if (k == "persist_step") pl->persist_step = value;
+    else if (k == "persist_p") pl->persist_p = value;
     else if (k == "fused_rows") set_fused_rows(value);
     else return OCTANE_E_INVALID;
     return OCTANE_OK;

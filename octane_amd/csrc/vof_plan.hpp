@@ -60,6 +60,14 @@ struct octane_vof_plan {
     hipGraphExec_t graph_exec = nullptr;
     int graph_cur = 0;
     int nt_hints = 15;   // x, q, mu/mv in pass B and a2 in pass A are single-use: streaming loads/stores
+    // Mid-size levels (above what one workgroup holds, up to ~1.9 Mpixel): the whole solve in ONE persistent launch with the
+    // level resident on chip (pcg_persist.hip).  persist_step > 0 runs that many iterations per launch with the state in the
+    // level's planes instead (the per-launch form the persistent one is checked against); persist_p forces the slot count.
+    int use_persist = 1, persist_step = 0, persist_p = 0;
+    long persist_max_pixels = 2L << 20;
+    int ncu = 0;                   // compute units of the device
+    void *d_mid = nullptr;         // workspace of the persistent solve (barrier counter, abort word, partial sums, edge pixels)
+    unsigned *h_mid_abort = nullptr;   // pinned copy of the abort word, refreshed at the end of every run
     int ntrials = 0;     // placement trials made when the plan was created, and what each candidate arena measured
     double trial_ms[8] = {0};
 };
