@@ -121,6 +121,14 @@ int octane_vof_plan_get_profile(octane_vof_plan *plan, octane_vof_profile *out);
  * defer_x, small, unit_w, fused, fused_q, fused_rows}.  Results agree for every setting to the last bits of the PCG
  * scalars (the grouping of the fp64 partial sums follows the grid); only speed changes. */
 int octane_vof_tune(octane_vof_plan *plan, const char *key, int value);
+/* Diagnostic: where the waves of one launch of the q-recomputing PCG kernel spend their time at pyramid level `level`: shader
+ * clock cycles summed over all waves, per seam of a tile (out16[0..6]), tiles walked ([7]), prologue ([8]), epilogue ([9]).
+ * even != 0 stamps a launch that also updates x.  The planes are clobbered.  No reference counterpart. */
+int octane_vof_plan_probe_stamps(octane_vof_plan *plan, int level, int even, int unit_w, unsigned long long *out16);
+/* Self-test of the persistent PCG kernel's three-instruction reciprocal (hardware estimate + one fused Newton step) against the
+ * IEEE division on every positive normal float whose reciprocal is normal: out3 = {patterns compared, mismatches, one
+ * mismatching bit pattern}.  No reference counterpart (the reference divides, ref .cu:141-149). */
+int octane_selftest_rcp(int device, unsigned long long *out3);
 /* Diagnostic: time `iterations` (>= 2) PCG iterations of pyramid level `level` (0 = coarsest) in isolation, on
  * whatever the plan's planes hold (the stop test is held open, values are irrelevant, the planes are clobbered).
  * With the one-kernel iteration (the default) its time comes back in *pass_a_ms and *pass_b_ms is 0. */

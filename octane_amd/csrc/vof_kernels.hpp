@@ -134,16 +134,17 @@ struct MidArgs {
     int nparts_asm;                  // partial sums the assembly wrote (r.z, r.r of the right-hand side)
     int full_state;                  // stepped form: the complete state is stored to / loaded from the level's planes
     float tol;
-    unsigned long long *ctr;         // grid barrier counter, zeroed ahead of every launch
-    unsigned int *abort_word;        // raised when a barrier timed out
-    double *parts;                   // [2][kPartKinds][kMidMaxG] partial sums by iteration parity
-    float *edges;                    // [G][2][4 sides][6 arrays][128] edge pixels by iteration parity
+    unsigned tag0;                   // granule tags of this solve are tag0 + iteration + 1
+    unsigned int *abort_word;        // raised when a wait timed out
+    unsigned long long *parts;       // [2 parities][14 = 7 sums x low / high half][kMidMaxG] granules
+    unsigned long long *edges;       // [G][2 parities][4 sides][6 arrays][128] granules
 };
 int  pcg_mid_config(int w, int h, int ncu, int force_p, MidGeom *g);
 void pcg_mid_configure();
 size_t pcg_mid_workspace_bytes();
-hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom &g, void *workspace, int k0, int k1, int kcap,
+hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom &g, void *workspace, unsigned seq, int k0, int k1, int kcap,
                                 int nparts_asm, float tol);
+int  pcg_selftest_rcp(hipStream_t s, unsigned long long *host3);
 bool pcg_small_applicable(int w, int h);
 void pcg_small_configure();
 void launch_pcg_solve_small(hipStream_t s, const LevelPtrs &L, int maxit, float tol);   // whole solve + flow update, one workgroup

@@ -552,7 +552,7 @@ int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur
 // before.  (Another PROCESS on the same GPU is not covered: the kernel's barriers are bounded and abort the solve.)
 static std::mutex g_persist_mu;
 static hipEvent_t g_persist_ev[64] = {nullptr};
-static int persist_launch(octane_vof_plan *pl, hipStream_t s, const LevelPtrs &L, const MidGeom &mg, int k0, int k1, int kcap, int nparts_asm)
+static int persist_launch(octane_vof_plan *pl, hipStream_t s, const LevelPtrs &L, const MidGeom &mg, unsigned seq, int k0, int k1, int kcap, int nparts_asm)
 {
     std::lock_guard<std::mutex> g(g_persist_mu);
     const int d = pl->device & 63;
@@ -561,7 +561,7 @@ static int persist_launch(octane_vof_plan *pl, hipStream_t s, const LevelPtrs &L
     } else if (hipStreamWaitEvent(s, g_persist_ev[d], 0) != hipSuccess) {
         g_last_error = "persistent solve: hipStreamWaitEvent failed"; return OCTANE_E_HIP;
     }
-    hipError_t e = launch_pcg_solve_mid(s, L, mg, pl->d_mid, k0, k1, kcap, nparts_asm, pl->tol);
+    hipError_t e = launch_pcg_solve_mid(s, L, mg, pl->d_mid, seq, k0, k1, kcap, nparts_asm, pl->tol);
     if (e == hipSuccess) e = hipEventRecord(g_persist_ev[d], s);
     if (e != hipSuccess) { g_last_error = std::string("persistent solve: ") + hipGetErrorString(e); return OCTANE_E_HIP; }
     return OCTANE_OK;
@@ -615,10 +615,11 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
                 launch_pcg_solve_small(s, L, prm.cgiters, pl->tol);
             } else if (mid) {  // the whole solve and the flow update in one launch of one workgroup per sub-domain
                 const int step = pl->persist_step > 0 ? pl->persist_step : (prm.cgiters > 0 ? prm.cgiters : 1);
+                const unsigned seq = pl->mid_seq++;            // one tag range per solve, shared by the launches of the stepped form
                 for (int k0 = 0; k0 < prm.cgiters || k0 == 0; k0 += step) {
                     const int k1 = k0 + step < prm.cgiters ? k0 + step : prm.cgiters;
                     e = ev_begin(pl, s, EV_PASS_A, pf);
-                    const int rc = persist_launch(pl, s, L, mg, k0, k1, prm.cgiters, g_asm);
+                    const int rc = persist_launch(pl, s, L, mg, seq, k0, k1, prm.cgiters, g_asm);
                     ev_end(e, s);
                     if (rc) return rc;
                     if (k1 >= prm.cgiters) break;
@@ -1368,6 +1369,15 @@ extern "C" int octane_vof_plan_probe_stamps(octane_vof_plan *pl, int level, int 
         rc = pcg_fused_q_stamps(s, L, even ? 4 : 5, 1, g_f, 0.f, out16);
     }
     return rc == 0 ? OCTANE_OK : OCTANE_E_HIP;
+}
+
+// Self-test: the three-instruction reciprocal of pcg_persist.hip against the IEEE division on every positive normal float whose
+// reciprocal is normal.  out3 = {patterns compared, mismatches, a mismatching bit pattern}.
+extern "C" int octane_selftest_rcp(int device, unsigned long long *out3)
+{
+    if (!out3) return OCTANE_E_INVALID;
+    HIP_TRY(hipSetDevice(device));
+    return pcg_selftest_rcp(nullptr, out3) == 0 ? OCTANE_OK : OCTANE_E_HIP;
 }
 
 // Developer knob setter (the same knobs the OCTANE_TUNE_* environment variables set at plan creation).

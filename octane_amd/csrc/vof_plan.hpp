@@ -66,7 +66,8 @@ struct octane_vof_plan {
     int use_persist = 1, persist_step = 0, persist_p = 0;
     long persist_max_pixels = 2L << 20;
     int ncu = 0;                   // compute units of the device
-    void *d_mid = nullptr;         // workspace of the persistent solve (barrier counter, abort word, partial sums, edge pixels)
+    void *d_mid = nullptr;         // workspace of the persistent solve (abort word, granules of partial sums and edge pixels)
+    unsigned mid_seq = 1;          // solves issued on that workspace: part of the granules' tags
     unsigned *h_mid_abort = nullptr;   // pinned copy of the abort word, refreshed at the end of every run
     int ntrials = 0;     // placement trials made when the plan was created, and what each candidate arena measured
     double trial_ms[8] = {0};

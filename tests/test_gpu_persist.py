@@ -99,3 +99,16 @@ def test_identical_images_persistent(capi):
     a, _ = synth.lattice_scene(400, 300, seed=3)
     u, v, its = _run(capi, a, a, dict(kiters=1))
     assert its == 0 and not u.any() and not v.any()
+
+
+def test_three_instruction_reciprocal_equals_the_division_everywhere(capi):
+    """pcg_persist.hip forms 1 / diagonal as v_rcp_f32 + one fused Newton step.  It has to be the correctly rounded quotient --
+    what `1.0f / x` gives -- for every x it can meet: checked on ALL positive normal floats whose reciprocal is normal."""
+    import ctypes as C
+    out = (C.c_ulonglong * 3)()
+    L = capi.lib()
+    L.octane_selftest_rcp.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+    assert L.octane_selftest_rcp(0, out) == 0
+    print(f"PERSIST reciprocal self-test: {out[0]} patterns, {out[1]} mismatches" + (f" (e.g. 0x{out[2]:08x})" if out[1] else ""))
+    assert out[0] == 0x7E000000 - 0x01000000
+    assert out[1] == 0
