@@ -49,6 +49,29 @@ TILED_SEED = 20240615              # (with 20240616 the 85 x 85 coarsest level o
 TILED_PARITY_BAR = 2e-5            # banded vs plain solve of the same frame: two groupings of the same fp64 partial sums
 
 
+def device_state(torch, dev):
+    """What this box's memory system delivers right now: boxes of this pool come in a fast and a slow state (the same binary's
+    finest-level PCG launch takes 0.33 or 0.42 ms), so every record carries a plain 1 GiB device copy timed in the same process."""
+    import time as _t
+    prop = torch.cuda.get_device_properties(dev)
+    n = 1 << 28                                       # 1 GiB of floats read + 1 GiB written per copy
+    a = torch.empty(n, dtype=torch.float32, device=dev); b = torch.empty_like(a)
+    a.fill_(1.0)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize(dev)
+    t0 = _t.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    torch.cuda.synchronize(dev)
+    dt = (_t.perf_counter() - t0) / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return {"name": prop.name, "compute_units": prop.multi_processor_count, "copy_1gib_gbs": round(2 * n * 4 / dt / 1e9, 1),
+            "note": "torch device-to-device copy of 1 GiB (read + write), a yardstick for the box's memory state, not a roofline"}
+
+
 def flow_distance(torch, got, want):
     """relative L2 distance of two flow fields held on a device"""
     num = ((got[0] - want[0]).double() ** 2).sum() + ((got[1] - want[1]).double() ** 2).sum()
@@ -568,6 +591,7 @@ def main():
                "value_with_transfers": transfers,
                # the plan kept the fastest of these candidate arenas (ms per finest-level PCG iteration): best-of-n placement
                "placement_trials_ms": trials_ms,
+               "device": device_state(torch, dev) if rank == 0 else None,
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
