@@ -259,6 +259,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_STEP")) pl->persist_step = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_P")) pl->persist_p = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_MAX")) pl->persist_max_pixels = atol(e);
+    if (const char *e = getenv("OCTANE_TUNE_PERSIST_MAXG")) pl->persist_max_g = atoi(e);
     {
         hipDeviceProp_t prop;
         pl->ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
@@ -584,7 +585,7 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
     // mid-size levels: the whole solve in one persistent launch, the level resident on chip (pcg_persist.hip)
     MidGeom mg;
     const bool mid = !small && pl->use_persist && pl->use_fused && !pl->use_graph && pl->d_mid && (long)li.w * li.h <= pl->persist_max_pixels &&
-                     pcg_mid_config(li.w, li.h, pl->ncu, pl->persist_p, &mg) == 1;
+                     pcg_mid_config(li.w, li.h, pl->ncu < pl->persist_max_g ? pl->ncu : pl->persist_max_g, pl->persist_p, &mg) == 1;
 
     for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
         AssembleParams ap;
@@ -956,6 +957,10 @@ extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const 
             const int first = d + ndevices * lane, step = ndevices * lanes;
             if (first >= npairs) return;
             int rc = octane_vof_plan_create(&pl, nx, ny, nchan, &prm);
+            // Lanes fill one another's latency-bound levels already; a persistent solve holds its CUs for a whole solve and such
+            // launches are serialised per device, so beside other lanes only the tiny levels keep it (64 x 2000^2: 145 Mpix/s with a
+            // cap of 16 workgroups, 143 without the persistent solve, 130 with a cap of 130, 136 uncapped)
+            if (rc == OCTANE_OK && lanes > 1 && !getenv("OCTANE_TUNE_PERSIST_MAXG")) pl->persist_max_g = 16;
             for (int b = first; rc == OCTANE_OK && b < npairs; b += step)
                 rc = octane_vof_plan_run(pl, img1[b], img2[b], u[b], v[b], OCTANE_MEM_HOST, nullptr);
             if (rc != OCTANE_OK) errs[wk] = g_last_error;
@@ -1399,6 +1404,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "persist") pl->use_persist = value != 0;
     else if (k == "persist_step") pl->persist_step = value;
     else if (k == "persist_p") pl->persist_p = value;
+    else if (k == "persist_max_g") pl->persist_max_g = value;
     else if (k == "fused_rows") set_fused_rows(value);
     else return OCTANE_E_INVALID;
     return OCTANE_OK;

@@ -64,6 +64,7 @@ struct octane_vof_plan {
     // level resident on chip (pcg_persist.hip).  persist_step > 0 runs that many iterations per launch with the state in the
     // level's planes instead (the per-launch form the persistent one is checked against); persist_p forces the slot count.
     int use_persist = 1, persist_step = 0, persist_p = 0;
+    int persist_max_g = 1 << 20;   // cap on the workgroups (= CUs held for a whole solve) of one persistent launch: lanes of a batch lower it
     long persist_max_pixels = 2L << 20;
     int ncu = 0;                   // compute units of the device
     void *d_mid = nullptr;         // workspace of the persistent solve (abort word, granules of partial sums and edge pixels)
