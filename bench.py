@@ -418,6 +418,9 @@ def main():
     backend = os.environ.get("OCTANE_BENCH_BACKEND", "nccl")
     if os.environ.get("OCTANE_BENCH_ONE_DEVICE") == "1":
         local = 0
+        # ranks of a rehearsal share one GPU: their persistent PCG solves (one workgroup per CU, all resident at once) cannot be
+        # serialised across processes, so each rank may only hold its share of the CUs
+        os.environ.setdefault("OCTANE_TUNE_PERSIST_MAXG", str(max(1, 256 // max(1, world))))
     if world > 1:   # one process per GPU over RCCL; only the barrier and the max-over-ranks time use it
         if backend == "nccl":
             shard.init_from_env("nccl", device_id=torch.device("cuda", local))

@@ -598,6 +598,7 @@ struct MpShared {                 // lives in the shared-memory object; zero-fil
     std::atomic<int> ready;       // rank 0 sets it once the object is initialised
     std::atomic<int> dead;        // a rank timed out at a phase boundary: the barrier state is undefined, nobody synchronises again
     std::atomic<unsigned long long> nonce;   // of rank 0's IPC handle: tells this run's object from one a crashed run left behind
+    std::atomic<unsigned long long> devid[kMaxBands];   // a hash of each rank's PCI bus id: ranks sharing a GPU share its CUs
 };
 
 struct octane_vof_mp {
@@ -738,6 +739,7 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
         m->shm->failed.store(0);
         m->shm->dead.store(0);
         m->shm->nonce.store(0);
+        for (int b = 0; b < kMaxBands; b++) m->shm->devid[b].store(0);
     }
     *out = m;
     return OCTANE_OK;
@@ -802,10 +804,28 @@ extern "C" int octane_vof_mp_connect(octane_vof_mp *m, const void *all_handles)
         m->parts_all[b] = static_cast<double *>(pp);
     }
     m->connected = true;
+    {   // which GPU this rank drives, for the others to see
+        char bus[64] = {0};
+        (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, m->device);
+        unsigned long long hsh = 1469598103934665603ull;
+        for (const char *c = bus; *c; c++) { hsh ^= (unsigned char)*c; hsh *= 1099511628211ull; }
+        m->shm->devid[m->rank].store(hsh ? hsh : 1, std::memory_order_release);
+    }
     if (!m->shm->bar.wait(m->world, m->timeout_s, &m->shm->dead)) {
         m->shm->dead.store(1); m->dead = true;
         set_last_error("octane_vof_mp_connect: the other ranks did not arrive");
         return OCTANE_E_HIP;
+    }
+    {   // Ranks that share a GPU (a rehearsal on a one-GPU box) share its CUs: their persistent PCG solves of the replicated
+        // levels run at the same time and cannot be serialised across processes, so each may only hold its share of the CUs --
+        // otherwise two of them could wait for each other's workgroups to become resident (pcg_persist.hip).
+        int sharing = 0;
+        const unsigned long long mine = m->shm->devid[m->rank].load(std::memory_order_acquire);
+        for (int b = 0; b < m->world; b++) sharing += (m->shm->devid[b].load(std::memory_order_acquire) == mine);
+        if (sharing > 1) {
+            const int cap = m->pl->ncu / sharing;
+            if (cap < m->pl->persist_max_g) m->pl->persist_max_g = cap;
+        }
     }
     return OCTANE_OK;
 }
