@@ -132,43 +132,18 @@ int pcg_selftest_rcp(hipStream_t s, unsigned long long *host3)
     return rc;
 }
 
-// q = A p of one pixel from the LDS tile (same operations, in the same order, as every other form of A p in this library) and
-// the five sums that carry q.  INTERIOR: the sub-domain touches no border of the level, so no neighbour is missing and no weight
-// is a merged border weight.
-template <bool UNITW, bool INTERIOR>
-__device__ __forceinline__ void mid_stencil(const float *s_pu, const float *s_pv, int li, int x, int y, int w, int h, float a1, float a2, float a4,
-                                            float wS, float wW, float wE, float wN, float &pcu, float &pcv, float &sumu, float &sumv)
-{
-    sumu = 0.f; sumv = 0.f;
-    if (INTERIOR) {
-        const float ws = UNITW ? -1.f : wS, ww = UNITW ? -1.f : wW, we = UNITW ? -1.f : wE, wn = UNITW ? -1.f : wN;
-        sumu += ws * s_pu[li - kMidLP]; sumv += ws * s_pv[li - kMidLP];
-        sumu += ww * s_pu[li - 1]; sumv += ww * s_pv[li - 1];
-        pcu = s_pu[li]; pcv = s_pv[li];
-        sumu += a1 * pcu; sumv += a2 * pcu;
-        sumu += a2 * pcv; sumv += a4 * pcv;
-        sumu += we * s_pu[li + 1]; sumv += we * s_pv[li + 1];
-        sumu += wn * s_pu[li + kMidLP]; sumv += wn * s_pv[li + kMidLP];
-    } else {
-        if (y > 0) { const float ws = UNITW ? ((y == h - 1) ? -2.f : -1.f) : wS; sumu += ws * s_pu[li - kMidLP]; sumv += ws * s_pv[li - kMidLP]; }
-        if (x > 0) { const float ww = UNITW ? ((x == w - 1) ? -2.f : -1.f) : wW; sumu += ww * s_pu[li - 1]; sumv += ww * s_pv[li - 1]; }
-        pcu = s_pu[li]; pcv = s_pv[li];
-        sumu += a1 * pcu; sumv += a2 * pcu;
-        sumu += a2 * pcv; sumv += a4 * pcv;
-        if (x < w - 1) { const float we = UNITW ? ((x == 0) ? -2.f : -1.f) : wE; sumu += we * s_pu[li + 1]; sumv += we * s_pv[li + 1]; }
-        if (y < h - 1) { const float wn = UNITW ? ((y == 0) ? -2.f : -1.f) : wN; sumu += wn * s_pu[li + kMidLP]; sumv += wn * s_pv[li + kMidLP]; }
-    }
-}
+typedef float v2f __attribute__((ext_vector_type(2)));     // (u, v) of one pixel: one packed instruction per pair of operations
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 
 template <int P, bool UNITW>
 __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     constexpr int ROWS = P * kMidRG;                       // rows a sub-domain can hold
-    float *s_pu = s_mem, *s_pv = s_pu + (ROWS + 2) * kMidLP;
-    float *s_xu = s_pv + (ROWS + 2) * kMidLP, *s_xv = s_xu + ROWS * kMidW;
-    float *s_edge = s_xv + ROWS * kMidW;                   // r_u, r_v, q_u, q_v of the first / last row [0..7] and of the west / east column [8..15]: 16 x 128
-    float *s_acc = s_edge + 16 * kMidEdge;                 // every thread's seven partial sums, [kind][thread]
+    v2f *s_p = reinterpret_cast<v2f *>(s_mem);             // p tile with its one-pixel ring: (ROWS + 2) x 66 pixels of (u, v)
+    v2f *s_x = s_p + (ROWS + 2) * kMidLP;                  // x: ROWS x 64
+    v2f *s_edge = s_x + ROWS * kMidW;                      // r and q of the edge pixels: [side 0..3][r, q][128]
+    float *s_acc = reinterpret_cast<float *>(s_edge + 4 * 2 * kMidEdge);   // every thread's seven partial sums, [kind][thread]
     double *s_tot = reinterpret_cast<double *>(s_acc + kPartKinds * kMidT);   // the seven folded sums of the previous iteration (+ scratch)
     int *s_flag = reinterpret_cast<int *>(s_tot + 32);     // raised by a lane whose wait was abandoned
 
@@ -177,7 +152,8 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
     const int wg = blockIdx.x, bx = wg % A.gx, by = wg / A.gx;
     const int x0 = bx * kMidW, y0 = by * A.bh;
     const int sw = min(kMidW, w - x0), sh = min(A.bh, h - y0);
-    const bool interior = x0 > 0 && x0 + sw < w && y0 > 0 && y0 + sh < h;     // no pixel of the sub-domain lies on the level's border
+    // a sub-domain that touches no border of the level and fills all 64 x ROWS pixel slots needs no predicate and no border weight
+    const bool fast = x0 > 0 && x0 + sw < w && y0 > 0 && y0 + sh < h && sw == kMidW && sh == ROWS;
 
     // The solve's scalars between the launches of the stepped form, double-buffered by the parity of the first iteration (a
     // one-iteration launch has no barrier, so workgroup 0 may write the new state before another workgroup has read the old)
@@ -188,10 +164,12 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         return;
     }
 
-    // ---- the sub-domain's state: operator, r (p, q, x in the stepped form) -> registers / LDS
-    float ru[P], rv[P], qu[P], qv[P], a1[P], a2[P], a4[P];      // p of the own pixels lives in the LDS tile only
-    float wS[UNITW ? 1 : P], wW[UNITW ? 1 : P], wE[UNITW ? 1 : P], wN[UNITW ? 1 : P];   // merged neighbour weights (ref .cu:929-1001)
-    for (int i = tid; i < (ROWS + 2) * kMidLP; i += kMidT) { s_pu[i] = 0.f; s_pv[i] = 0.f; }
+    // ---- the sub-domain's state: operator, r (p, q, x in the stepped form) -> registers / LDS.  A slot without a pixel (ragged last
+    // row / column of sub-domains) holds r = q = 0, a unit diagonal and zero weights: it computes along and stays zero.
+    v2f r2[P], q2[P];                                      // p of the own pixels lives in the LDS tile only
+    float a1[P], a2[P], a4[P];
+    float wS[P], wW[P], wE[P], wN[P];                      // merged neighbour weights (ref .cu:929-1001); 0 where the level has no such neighbour
+    for (int i = tid; i < (ROWS + 2) * kMidLP; i += kMidT) s_p[i] = mk2(0.f, 0.f);
     if (tid == 0) *s_flag = 0;
     __syncthreads();
     const int par0 = (A.k0 + 1) & 1;                       // parity of iteration k0 - 1: where the stepped form left its state
@@ -202,38 +180,42 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         for (int s = 0; s < P; s++) {
             const int ly = s * kMidRG + rg, y = y0 + ly;
             const bool ok = colok && ly < sh;
-            ru[s] = rv[s] = qu[s] = qv[s] = 0.f;
-            float pu0 = 0.f, pv0 = 0.f;
+            r2[s] = mk2(0.f, 0.f); q2[s] = mk2(0.f, 0.f);
+            v2f p0 = mk2(0.f, 0.f), xx0 = mk2(0.f, 0.f);
             a1[s] = a4[s] = 1.f; a2[s] = 0.f;
-            if (!UNITW) { wS[s] = wW[s] = wE[s] = wN[s] = 0.f; }
-            float xu0 = 0.f, xv0 = 0.f;
+            wS[s] = wW[s] = wE[s] = wN[s] = 0.f;
             if (ok) {
                 const unsigned o = (unsigned)(y * pitch + x) * 4u;
                 a1[s] = *at(L.a1, o); a2[s] = *at(L.a2, o); a4[s] = *at(L.a4, o);
-                if (!UNITW) {
+                if (UNITW) {                               // al1 == 1: every weight is exactly -1 (ref .cu:837-864), merged border weights -2
+                    wS[s] = (y > 0) ? ((y == h - 1) ? -2.f : -1.f) : 0.f;
+                    wW[s] = (x > 0) ? ((x == w - 1) ? -2.f : -1.f) : 0.f;
+                    wE[s] = (x < w - 1) ? ((x == 0) ? -2.f : -1.f) : 0.f;
+                    wN[s] = (y < h - 1) ? ((y == 0) ? -2.f : -1.f) : 0.f;
+                } else {
                     const float wxc = *at(L.wx, o), wyc = *at(L.wy, o);
                     const float wys = (y > 0) ? *at(L.wy, o - 4u * (unsigned)pitch) : 0.f, wxw = (x > 0) ? *at(L.wx, o - 4u) : 0.f;
-                    wS[s] = (y == h - 1) ? wys + wyc : wys;
-                    wW[s] = (x == w - 1) ? wxw + wxc : wxw;
-                    wE[s] = (x == 0) ? wxc + wxc : wxc;
-                    wN[s] = (y == 0) ? wyc + wyc : wyc;
+                    wS[s] = (y > 0) ? ((y == h - 1) ? wys + wyc : wys) : 0.f;
+                    wW[s] = (x > 0) ? ((x == w - 1) ? wxw + wxc : wxw) : 0.f;
+                    wE[s] = (x < w - 1) ? ((x == 0) ? wxc + wxc : wxc) : 0.f;
+                    wN[s] = (y < h - 1) ? ((y == 0) ? wyc + wyc : wyc) : 0.f;
                 }
                 if (A.k0 == 0) {
-                    ru[s] = *at(L.rb_u[0], o); rv[s] = *at(L.rb_v[0], o);   // r_0 = the right-hand side the assembly wrote
+                    r2[s] = mk2(*at(L.rb_u[0], o), *at(L.rb_v[0], o));      // r_0 = the right-hand side the assembly wrote
                 } else {
-                    ru[s] = *at(L.rb_u[par0], o); rv[s] = *at(L.rb_v[par0], o);
-                    pu0 = *at(L.pf_u[par0], o); pv0 = *at(L.pf_v[par0], o);
-                    qu[s] = *at(L.qb_u[par0], o); qv[s] = *at(L.qb_v[par0], o);
-                    xu0 = *at(L.xu, o); xv0 = *at(L.xv, o);
+                    r2[s] = mk2(*at(L.rb_u[par0], o), *at(L.rb_v[par0], o));
+                    p0 = mk2(*at(L.pf_u[par0], o), *at(L.pf_v[par0], o));
+                    q2[s] = mk2(*at(L.qb_u[par0], o), *at(L.qb_v[par0], o));
+                    xx0 = mk2(*at(L.xu, o), *at(L.xv, o));
                 }
             }
-            s_xu[ly * kMidW + c] = xu0; s_xv[ly * kMidW + c] = xv0;
-            if (ok) { s_pu[(ly + 1) * kMidLP + c + 1] = pu0; s_pv[(ly + 1) * kMidLP + c + 1] = pv0; }     // p_{k0-1} (zero at k0 = 0)
+            s_x[ly * kMidW + c] = xx0;
+            if (ok) s_p[(ly + 1) * kMidLP + c + 1] = p0;       // p_{k0-1} (zero at k0 = 0)
         }
     }
     // ---- this thread's ring pixel (threads 0 .. 127 + 2 ROWS): where it lives, whose edge it is, its preconditioner entries
     int r_lds = -1, r_idx = 0, r_nb = 0, r_side = 0;
-    float r_iu = 0.f, r_iv = 0.f;
+    v2f r_i = mk2(0.f, 0.f);
     unsigned r_off = 0;
     {
         int rx = -1, ry = -1;
@@ -246,7 +228,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
                                                if (j < sh && rx < w) r_lds = (j + 1) * kMidLP + sw + 1; }
         if (r_lds >= 0) {
             r_off = (unsigned)(ry * pitch + rx) * 4u;
-            r_iu = rcp_exact(*at(L.a1, r_off)); r_iv = rcp_exact(*at(L.a4, r_off));
+            r_i = mk2(rcp_exact(*at(L.a1, r_off)), rcp_exact(*at(L.a4, r_off)));
         }
     }
     const unsigned e_nb_off = (unsigned)(r_lds >= 0 ? r_nb : wg) * (2 * 4 * 6 * kMidEdge) * 8u;   // byte offset of the neighbour's block of granules
@@ -258,12 +240,12 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
     __syncthreads();
 
     for (;; k++) {
-        // Everything a slot derives from its position (predicates, LDS addresses) is invariant over the iterations, and the compiler
-        // would hoist all of it out of this loop into registers it does not have (P = 16: 11 arrays of 16 are live already).  The empty
-        // asm statement makes the position opaque once per iteration, so those values are formed again where they are used.
+        // Everything a slot derives from its position (predicates, LDS addresses) and from the operator (packed pairs, reciprocals) is
+        // invariant over the iterations, and the compiler would hoist all of it out of this loop into registers it does not have
+        // (P = 14: 11 arrays of 14 are live already).  The empty asm statements make those inputs opaque once per phase, so the
+        // derived values are formed again where they are used.
         int c = c_, rg = rg_;
         asm volatile("" : "+v"(c), "+v"(rg));
-        const int x = x0 + c;
         const bool colok = c < sw;
         const bool first = (k == 0);
         // ---- wait for what iteration k - 1 left: the G x 7 partial sums (wave j < 7 sweeps sum j: lane l takes workgroups l, l + 64,
@@ -333,11 +315,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
 #pragma unroll
                 for (int s = 0; s < P; s++) {
                     const int ly = s * kMidRG + rg;
-                    if (colok && ly < sh) {
-                        const int li = (ly + 1) * kMidLP + c + 1;
-                        s_xu[ly * kMidW + c] = alpha * s_pu[li] + s_xu[ly * kMidW + c];  // jVecPVec(p0,x0,x0,alphak), ref .cu:1172
-                        s_xv[ly * kMidW + c] = alpha * s_pv[li] + s_xv[ly * kMidW + c];
-                    }
+                    if (colok && ly < sh) s_x[ly * kMidW + c] = alpha * s_p[(ly + 1) * kMidLP + c + 1] + s_x[ly * kMidW + c];   // ref .cu:1172
                 }
             }
             stopped = true;
@@ -347,94 +325,88 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         iters++;
         // ---- p_k on the ring, from the neighbouring sub-domains' edge pixels of iteration k - 1
         if (r_lds >= 0) {
-            float pku, pkv;
+            v2f pk;
             if (first) {
-                pku = r_iu * *at(L.rb_u[0], r_off); pkv = r_iv * *at(L.rb_v[0], r_off);
+                pk = r_i * mk2(*at(L.rb_u[0], r_off), *at(L.rb_v[0], r_off));
             } else {
-                float r0 = __uint_as_float(rbits[0]), r1 = __uint_as_float(rbits[1]);
-                const float q0 = __uint_as_float(rbits[2]), q1 = __uint_as_float(rbits[3]);
-                const float p0 = __uint_as_float(rbits[4]), p1 = __uint_as_float(rbits[5]);
-                r0 = nalpha * q0 + r0; r1 = nalpha * q1 + r1;
-                const float zu = r_iu * r0, zv = r_iv * r1;
-                pku = beta * p0 + zu; pkv = beta * p1 + zv;
+                v2f rr2 = mk2(__uint_as_float(rbits[0]), __uint_as_float(rbits[1]));
+                const v2f qq2 = mk2(__uint_as_float(rbits[2]), __uint_as_float(rbits[3]));
+                const v2f pp2 = mk2(__uint_as_float(rbits[4]), __uint_as_float(rbits[5]));
+                rr2 = nalpha * qq2 + rr2;
+                pk = beta * pp2 + r_i * rr2;
             }
-            s_pu[r_lds] = pku; s_pv[r_lds] = pkv;
+            s_p[r_lds] = pk;
         }
-        // ---- own pixels: x += alpha p, r -= alpha q, p = M^-1 r + beta p; direct sums of r.z and r.r.  Threads without a pixel
-        // in a slot hold zeros there (and a unit diagonal) and compute along: only stores are predicated.
-        float acc[kPartKinds];
+        // ---- own pixels: x += alpha p, r -= alpha q, p = M^-1 r + beta p; r.z and r.r.  Packed (u, v) arithmetic: one rounding per
+        // product and per sum, exactly as the scalar form; the seven sums are kept per component and per thread in float and meet in
+        // double across threads.
+        v2f acc[kPartKinds];
 #pragma unroll
-        for (int j = 0; j < kPartKinds; j++) acc[j] = 0.f;
-#pragma unroll
-        for (int s = 0; s < P; s++) {
-            const int ly = s * kMidRG + rg;
-            const bool ok = colok && ly < sh;
-            const int li = (ly + 1) * kMidLP + c + 1;
-            float pou = 0.f, pov = 0.f;                                                      // p_{k-1} of the own pixel
-            if (!first) {
-                if (ok) {
-                    pou = s_pu[li]; pov = s_pv[li];
-                    s_xu[ly * kMidW + c] = alpha * pou + s_xu[ly * kMidW + c];            // ref .cu:1172
-                    s_xv[ly * kMidW + c] = alpha * pov + s_xv[ly * kMidW + c];
-                }
-                ru[s] = nalpha * qu[s] + ru[s];                                              // ref .cu:1174
-                rv[s] = nalpha * qv[s] + rv[s];
-            }
-            const float iu = rcp_exact(a1[s]), iv = rcp_exact(a4[s]);
-            const float zu = iu * ru[s], zv = iv * rv[s];
-            const float pnu = first ? zu : beta * pou + zu;
-            const float pnv = first ? zv : beta * pov + zv;
-            if (ok) { s_pu[li] = pnu; s_pv[li] = pnv; }
-            float d = 0.f; d += ru[s] * zu; d += rv[s] * zv; acc[0] += d;
-            d = 0.f; d += ru[s] * ru[s]; d += rv[s] * rv[s]; acc[1] += d;
+        for (int j = 0; j < kPartKinds; j++) acc[j] = mk2(0.f, 0.f);
+#define MID_UPDATE_LOOP(FAST)                                                                                                          \
+        _Pragma("unroll") for (int s = 0; s < P; s++) {                                                                                \
+            const int ly = s * kMidRG + rg;                                                                                            \
+            const bool ok = FAST || (colok && ly < sh);                                                                                \
+            const int li = (ly + 1) * kMidLP + c + 1;                                                                                  \
+            v2f po = mk2(0.f, 0.f);                                                                /* p_{k-1} of the own pixel */      \
+            if (!first) {                                                                                                              \
+                if (ok) { po = s_p[li]; s_x[ly * kMidW + c] = alpha * po + s_x[ly * kMidW + c]; }    /* ref .cu:1172 */                  \
+                r2[s] = nalpha * q2[s] + r2[s];                                                    /* ref .cu:1174 */                  \
+            }                                                                                                                          \
+            const v2f i2 = mk2(rcp_exact(a1[s]), rcp_exact(a4[s]));                                                                    \
+            const v2f z2 = i2 * r2[s];                                                                                                 \
+            const v2f pn = first ? z2 : beta * po + z2;                                                                                \
+            if (ok) s_p[li] = pn;                                                                                                      \
+            acc[0] += r2[s] * z2; acc[1] += r2[s] * r2[s];                                                                             \
         }
+        if (fast) { MID_UPDATE_LOOP(true) } else { MID_UPDATE_LOOP(false) }
+#undef MID_UPDATE_LOOP
         __syncthreads();
-        // ---- q = A p and the sums that carry q.  (The reciprocals of the diagonal and z are formed again rather than kept across the
-        // barrier -- four registers per slot; the empty asm statements keep the compiler from "saving" that work.)
+        // ---- q = A p and the sums that carry q (the reciprocals of the diagonal and z are formed again rather than kept across the barrier)
 #pragma unroll
-        for (int s = 0; s < P; s++) {
-            asm volatile("" : "+v"(a1[s]), "+v"(a2[s]), "+v"(a4[s]));
-            if (!UNITW) asm volatile("" : "+v"(wS[UNITW ? 0 : s]), "+v"(wW[UNITW ? 0 : s]), "+v"(wE[UNITW ? 0 : s]), "+v"(wN[UNITW ? 0 : s]));
-        }
+        for (int s = 0; s < P; s++) asm volatile("" : "+v"(a1[s]), "+v"(a2[s]), "+v"(a4[s]), "+v"(wS[s]), "+v"(wW[s]), "+v"(wE[s]), "+v"(wN[s]));
         asm volatile("" : "+v"(c), "+v"(rg));
         const int par = k & 1;
-#define MID_STENCIL_LOOP(INTERIOR)                                                                                                      \
+#define MID_STENCIL_LOOP(FAST)                                                                                                         \
         _Pragma("unroll") for (int s = 0; s < P; s++) {                                                                                \
             const int ly = s * kMidRG + rg, y = y0 + ly;                                                                               \
-            const bool ok = colok && ly < sh;                                                                                          \
+            const bool ok = FAST || (colok && ly < sh);                                                                                \
             const int li = (ly + 1) * kMidLP + c + 1;                                                                                  \
-            float pcu, pcv, sumu, sumv;                                                                                                \
-            mid_stencil<UNITW, INTERIOR>(s_pu, s_pv, li, x, y, w, h, a1[s], a2[s], a4[s], UNITW ? 0.f : wS[UNITW ? 0 : s],             \
-                                         UNITW ? 0.f : wW[UNITW ? 0 : s], UNITW ? 0.f : wE[UNITW ? 0 : s], UNITW ? 0.f : wN[UNITW ? 0 : s], \
-                                         pcu, pcv, sumu, sumv);                                                                        \
-            sumu = ok ? sumu : 0.f; sumv = ok ? sumv : 0.f;     /* no pixel here: the neighbours in LDS are somebody else's */         \
-            qu[s] = sumu; qv[s] = sumv;                                                                                                \
-            const float iu = rcp_exact(a1[s]), iv = rcp_exact(a4[s]);                                                                  \
-            const float zu = iu * ru[s], zv = iv * rv[s];                                                                              \
-            float d = 0.f; d += pcu * sumu; d += pcv * sumv; acc[2] += d;                                                              \
-            d = 0.f; d += sumu * zu; d += sumv * zv; acc[3] += d;                                                                      \
-            d = 0.f; d += sumu * (iu * sumu); d += sumv * (iv * sumv); acc[4] += d;                                                    \
-            d = 0.f; d += ru[s] * sumu; d += rv[s] * sumv; acc[5] += d;                                                                \
-            d = 0.f; d += sumu * sumu; d += sumv * sumv; acc[6] += d;                                                                  \
+            const float ws = (FAST && UNITW) ? -1.f : wS[s], ww = (FAST && UNITW) ? -1.f : wW[s];                                      \
+            const float we = (FAST && UNITW) ? -1.f : wE[s], wn = (FAST && UNITW) ? -1.f : wN[s];                                      \
+            v2f sum = mk2(0.f, 0.f);                                                                                                   \
+            sum += ws * s_p[li - kMidLP];                                                                                              \
+            sum += ww * s_p[li - 1];                                                                                                   \
+            const v2f pc = s_p[li];                                                                                                    \
+            sum += mk2(a1[s], a2[s]) * pc.x;                                                                                           \
+            sum += mk2(a2[s], a4[s]) * pc.y;                                                                                           \
+            sum += we * s_p[li + 1];                                                                                                   \
+            sum += wn * s_p[li + kMidLP];                                                                                              \
+            if (!FAST) sum = ok ? sum : mk2(0.f, 0.f);   /* a slot without a pixel: its LDS cell may be a ring cell of the neighbours */ \
+            q2[s] = sum;                                                                                                               \
+            const v2f i2 = mk2(rcp_exact(a1[s]), rcp_exact(a4[s]));                                                                    \
+            const v2f z2 = i2 * r2[s];                                                                                                 \
+            acc[2] += pc * sum; acc[3] += sum * z2; acc[4] += sum * (i2 * sum); acc[5] += r2[s] * sum; acc[6] += sum * sum;            \
             /* r and q of the edge pixels go to LDS first (p is there already); the granules are written below, coalesced */           \
             if (ok) {                                                                                                                  \
-                if (ly == 0) { s_edge[0 * kMidEdge + c] = ru[s]; s_edge[2 * kMidEdge + c] = rv[s]; s_edge[4 * kMidEdge + c] = sumu; s_edge[6 * kMidEdge + c] = sumv; } \
-                if (ly == sh - 1) { s_edge[1 * kMidEdge + c] = ru[s]; s_edge[3 * kMidEdge + c] = rv[s]; s_edge[5 * kMidEdge + c] = sumu; s_edge[7 * kMidEdge + c] = sumv; } \
-                if (c == 0) { s_edge[(8 + 0) * kMidEdge + ly] = ru[s]; s_edge[(8 + 2) * kMidEdge + ly] = rv[s]; s_edge[(8 + 4) * kMidEdge + ly] = sumu; s_edge[(8 + 6) * kMidEdge + ly] = sumv; } \
-                if (c == sw - 1) { s_edge[(8 + 1) * kMidEdge + ly] = ru[s]; s_edge[(8 + 3) * kMidEdge + ly] = rv[s]; s_edge[(8 + 5) * kMidEdge + ly] = sumu; s_edge[(8 + 7) * kMidEdge + ly] = sumv; } \
+                if (ly == 0) { s_edge[(0 * 2 + 0) * kMidEdge + c] = r2[s]; s_edge[(0 * 2 + 1) * kMidEdge + c] = sum; }                 \
+                if (ly == sh - 1) { s_edge[(1 * 2 + 0) * kMidEdge + c] = r2[s]; s_edge[(1 * 2 + 1) * kMidEdge + c] = sum; }            \
+                if (c == 0) { s_edge[(2 * 2 + 0) * kMidEdge + ly] = r2[s]; s_edge[(2 * 2 + 1) * kMidEdge + ly] = sum; }                \
+                if (c == sw - 1) { s_edge[(3 * 2 + 0) * kMidEdge + ly] = r2[s]; s_edge[(3 * 2 + 1) * kMidEdge + ly] = sum; }           \
                 if (A.full_state) {                            /* stepped form: the whole state goes back to the planes */             \
-                    const unsigned o = (unsigned)(y * pitch + x) * 4u;                                                                 \
-                    *at(L.rb_u[par], o) = ru[s]; *at(L.rb_v[par], o) = rv[s]; *at(L.pf_u[par], o) = pcu; *at(L.pf_v[par], o) = pcv;     \
-                    *at(L.qb_u[par], o) = sumu; *at(L.qb_v[par], o) = sumv; *at(L.xu, o) = s_xu[ly * kMidW + c]; *at(L.xv, o) = s_xv[ly * kMidW + c]; \
+                    const unsigned o = (unsigned)(y * pitch + x0 + c) * 4u;                                                            \
+                    const v2f xx = s_x[ly * kMidW + c];                                                                                \
+                    *at(L.rb_u[par], o) = r2[s].x; *at(L.rb_v[par], o) = r2[s].y; *at(L.pf_u[par], o) = pc.x; *at(L.pf_v[par], o) = pc.y; \
+                    *at(L.qb_u[par], o) = sum.x; *at(L.qb_v[par], o) = sum.y; *at(L.xu, o) = xx.x; *at(L.xv, o) = xx.y;                 \
                 }                                                                                                                      \
             }                                                                                                                          \
         }
-        if (interior) { MID_STENCIL_LOOP(true) } else { MID_STENCIL_LOOP(false) }
+        if (fast) { MID_STENCIL_LOOP(true) } else { MID_STENCIL_LOOP(false) }
 #undef MID_STENCIL_LOOP
-        // ---- the workgroup's seven sums: every thread's subtotal (float, over its <= 16 pixels) through LDS, then wave j adds up
-        // sum j over the 512 threads in a fixed order, in double
+        // ---- the workgroup's seven sums: every thread's subtotal through LDS, then wave j adds up sum j over the 512 threads in a
+        // fixed order, in double
 #pragma unroll
-        for (int j = 0; j < kPartKinds; j++) s_acc[j * kMidT + tid] = acc[j];
+        for (int j = 0; j < kPartKinds; j++) s_acc[j * kMidT + tid] = acc[j].x + acc[j].y;
         __syncthreads();                                     // completes s_acc and s_edge
         const unsigned tag = A.tag0 + (unsigned)k + 1u;
         if (wv < kPartKinds) {
@@ -453,12 +425,15 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
             const int len = (side < 2) ? sw : sh;
             if (i < len) {
                 const unsigned eo = (unsigned)(((wg * 2 + par) * 4 + side) * 6 * kMidEdge + i) * 8u;
-                const int eb = (side < 2) ? side : 8 + (side - 2);
-#pragma unroll
-                for (int a = 0; a < 4; a++) st_granule(gat(A.edges, eo + (unsigned)a * kMidEdge * 8u), tag, __float_as_uint(s_edge[(eb + 2 * a) * kMidEdge + i]));
+                const v2f er = s_edge[(side * 2 + 0) * kMidEdge + i], eq = s_edge[(side * 2 + 1) * kMidEdge + i];
                 const int li = (side == 0) ? kMidLP + i + 1 : (side == 1) ? sh * kMidLP + i + 1 : (side == 2) ? (i + 1) * kMidLP + 1 : (i + 1) * kMidLP + sw;
-                st_granule(gat(A.edges, eo + 4u * kMidEdge * 8u), tag, __float_as_uint(s_pu[li]));
-                st_granule(gat(A.edges, eo + 5u * kMidEdge * 8u), tag, __float_as_uint(s_pv[li]));
+                const v2f ep = s_p[li];
+                st_granule(gat(A.edges, eo), tag, __float_as_uint(er.x));
+                st_granule(gat(A.edges, eo + 1u * kMidEdge * 8u), tag, __float_as_uint(er.y));
+                st_granule(gat(A.edges, eo + 2u * kMidEdge * 8u), tag, __float_as_uint(eq.x));
+                st_granule(gat(A.edges, eo + 3u * kMidEdge * 8u), tag, __float_as_uint(eq.y));
+                st_granule(gat(A.edges, eo + 4u * kMidEdge * 8u), tag, __float_as_uint(ep.x));
+                st_granule(gat(A.edges, eo + 5u * kMidEdge * 8u), tag, __float_as_uint(ep.y));
             }
         }
         rz_prev = rz_new;
@@ -477,9 +452,9 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
                 const int ly = s * kMidRG + rg, y = y0 + ly;
                 if (colok && ly < sh) {
                     const unsigned o = (unsigned)(y * pitch + x) * 4u;
-                    const float dx = s_xu[ly * kMidW + c], dy = s_xv[ly * kMidW + c];
-                    *at(L.u, o) = *at(L.u, o) + dx; *at(L.v, o) = *at(L.v, o) + dy;
-                    *at(L.xu, o) = dx; *at(L.xv, o) = dy;        // kept for the debug tap
+                    const v2f d = s_x[ly * kMidW + c];
+                    *at(L.u, o) = *at(L.u, o) + d.x; *at(L.v, o) = *at(L.v, o) + d.y;
+                    *at(L.xu, o) = d.x; *at(L.xv, o) = d.y;      // kept for the debug tap
                 }
             }
         }
@@ -495,7 +470,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
 static size_t mid_lds_bytes(int P)
 {
     const int rows = P * kMidRG;
-    return (size_t)(2 * (rows + 2) * kMidLP + 2 * rows * kMidW + 16 * kMidEdge + kPartKinds * kMidT) * sizeof(float) + 32 * sizeof(double) + 16;
+    return (size_t)(2 * (rows + 2) * kMidLP + 2 * rows * kMidW + 2 * 4 * 2 * kMidEdge + kPartKinds * kMidT) * sizeof(float) + 32 * sizeof(double) + 16;
 }
 
 // Sub-domain grid of a w x h level on a device with `ncu` CUs: 64-column strips, as many rows of sub-domains as keep every
