@@ -89,6 +89,11 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels, qform=False):
         out.append(f"| {k} | {rd / 1e6:.0f} | {ar / 1e6:.0f} | {wr / 1e6:.0f} | {aw / 1e6:.0f} | {(rd + wr) / (ar + aw):.3f} |")
     if traffic:
         import json
+        import subprocess
+        try:
+            traffic["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or os.environ.get("OCTANE_COMMIT", "unknown")
+        except OSError:
+            traffic["commit"] = os.environ.get("OCTANE_COMMIT", "unknown")
         with open(os.path.join(os.path.dirname(os.path.abspath(sys.argv[2])), "traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
     return out
@@ -127,7 +132,15 @@ def main():
     def lev_w(lev):
         return int(size * 0.5 ** (kiters - 1 - lev) + 0.5)
     small = [lev for lev in range(kiters) if lev_w(lev) ** 2 <= 6144]
-    two_pass_levels = {k: ([l for l in range(kiters) if l not in small] if k != "k_assemble" else list(range(kiters)))
+    # mid-size levels are solved by k_pcg_solve_mid (pcg_persist.hip: one launch per solve, flow update included) unless
+    # OCTANE_TUNE_PERSIST=0: the rule of pcg_mid_config on a 256-CU device, levels of at most 2 Mi pixels
+    def is_mid(wl):
+        if os.environ.get("OCTANE_TUNE_PERSIST", "1") == "0" or wl * wl > (2 << 20):
+            return False
+        gx = (wl + 63) // 64
+        return any(gx * ((wl + 8 * P - 1) // (8 * P)) <= 256 for P in (4, 6, 8, 10, 12, 14, 16))
+    mid = [lev for lev in range(kiters) if lev not in small and is_mid(lev_w(lev))]
+    two_pass_levels = {k: ([l for l in range(kiters) if l not in small and l not in mid] if k != "k_assemble" else list(range(kiters)))
                        for k in per_level}
     lines = [f"# rocprofv3 kernel-trace summary: bench.py, {size}x{size}, kiters={kiters} liters={liters} cgiters={cgiters}", "",
              "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...` on one MI355X;",
@@ -153,9 +166,22 @@ def main():
             m = sel[-1][3]         # template instances differ per level (tile height, q stored or recomputed)
             lines.append(f"| {k} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} | {lev} ({lw}x{lw}) | {len(durs)} | "
                          f"{sum(durs) / len(durs) / 1e3:.2f} | {min(durs) / 1e3:.2f} | {max(durs) / 1e3:.2f} | {sel[0][2]} |")
+    # the persistent mid-level solves: one launch per solve, told apart by their grid (workgroups = sub-domains of the level)
+    mids = defaultdict(list)
+    for k, v in rows.items():
+        if k.startswith("k_pcg_solve_mid"):
+            for r in v:
+                mids[(r[2] // 512, k)].append(r)
+    if mids:
+        lines += ["", f"| persistent solve (one launch = {cgiters} PCG iterations + flow update) | workgroups | VGPR | LDS B | scratch | launches | mean us | us per iteration |",
+                  "|---|---|---|---|---|---|---|---|"]
+        for (g, k), v in sorted(mids.items()):
+            durs = [r[1] for r in v]
+            m = v[-1][3]
+            lines.append(f"| {k} | {g} | {m[0]} | {m[3]} | {m[4]} | {len(durs)} | {sum(durs) / len(durs) / 1e3:.1f} | {sum(durs) / len(durs) / 1e3 / max(1, cgiters):.2f} |")
     lines += ["", "| other kernels | launches | mean us | total ms |", "|---|---|---|---|"]
     for k, v in sorted(rows.items()):
-        if k in per_level:
+        if k in per_level or k.startswith("k_pcg_solve_mid"):
             continue
         durs = [s[1] for s in v]
         lines.append(f"| {k} | {len(durs)} | {sum(durs) / len(durs) / 1e3:.2f} | {sum(durs) / 1e6:.3f} |")
