@@ -23,6 +23,14 @@
 //     (pcg_kernels.hip).  Copied, per linearisation: two rows of u, v per inner edge; per level: the bands of the flow,
 //     all-gathered for the next level's up-sampling.
 //
+// Transport (OCTANE_TILED_TRANSPORT): "inplace" (default) is the scheme above -- the consuming kernel dereferences the
+// neighbour's memory.  "copy" is the fallback SURVEY 5 asks for, there to tell a protocol error from a visibility problem of
+// in-kernel peer reads should a multi-GPU run ever disagree with the plain plan: the same rows and partial blocks are PULLED
+// into this band's own planes / a local mirror by stream-ordered runtime copies (hipMemcpyPeerAsync, or hipMemcpyAsync on an
+// IPC mapping) after the phase boundary, and every kernel reads local memory only.  Same arithmetic, same fold order, same
+// bits.  (RCCL itself is not used for this: ncclAllGather + ncclSend / Recv would carry exactly these copies, but RCCL
+// refuses two ranks on one device, so on the one-GPU boxes this code is tested on it could never run.)
+//
 // Ordering: every cross-band read is made by a kernel launched after an event wait on the producing band's stream,
 // i.e. after the producing kernel completed -- the visibility point HIP defines for device memory shared between
 // peers; nothing relies on stores becoming visible while a kernel runs.  No host synchronisation with the GPU inside
@@ -66,6 +74,7 @@ struct octane_vof_tiled {
     std::vector<int> dev;                       // device of band b
     std::vector<octane_vof_plan *> pl;          // one full-size plan per band
     std::vector<double *> parts;                // per band: its partial block [rz|rr|pq] x kMaxParts, read by every band
+    std::vector<double *> mirror;               // per band: local copies of every band's partial blocks (copy transport)
     std::vector<hipEvent_t> ev;                 // per band
     std::vector<std::vector<BandRows>> rows;    // [level][band]; empty vector = level is replicated
     int last_cur = 0;
@@ -99,6 +108,7 @@ extern "C" int octane_vof_tiled_destroy(octane_vof_tiled *t)
         if (t->pl[b] && t->pl[b]->own_stream) (void)hipStreamSynchronize(t->pl[b]->own_stream);
         if (b < (int)t->ev.size() && t->ev[b]) (void)hipEventDestroy(t->ev[b]);
         if (b < (int)t->parts.size() && t->parts[b]) (void)hipFree(t->parts[b]);
+        if (b < (int)t->mirror.size() && t->mirror[b]) (void)hipFree(t->mirror[b]);
         if (t->pl[b]) octane_vof_plan_destroy(t->pl[b]);
     }
     delete t;
@@ -148,6 +158,7 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
             }
     t->pl.assign(nbands, nullptr);
     t->parts.assign(nbands, nullptr);
+    t->mirror.assign(nbands, nullptr);
     t->ev.assign(nbands, nullptr);
     int rc = OCTANE_OK;
     for (int b = 0; b < nbands && rc == OCTANE_OK; b++) {
@@ -161,6 +172,8 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
         if (hipSetDevice(t->dev[b]) != hipSuccess ||
             hipMalloc((void **)&t->parts[b], (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
             hipMemset(t->parts[b], 0, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&t->mirror[b], (size_t)nbands * 2 * kPartBlock * sizeof(double)) != hipSuccess ||
+            hipMemset(t->mirror[b], 0, (size_t)nbands * 2 * kPartBlock * sizeof(double)) != hipSuccess ||
             hipEventCreateWithFlags(&t->ev[b], hipEventDisableTiming) != hipSuccess) {
             set_last_error("octane_vof_tiled_create: device allocation failed");
             rc = OCTANE_E_NOMEM;
@@ -271,6 +284,15 @@ struct BandNet {
     virtual void fail(int b, int rc, const std::string &msg) = 0;
     virtual void sync(int b) = 0;                                  // phase boundary, called by every band
     virtual hipError_t copy(int b, void *dst, int dband, const void *src, size_t bytes) = 0;   // on band b's stream
+    // copy transport: from band `sband`'s memory (as mapped here) into band b's own memory, on band b's stream
+    virtual hipError_t pull(int b, void *dst_local, int sband, const void *src, size_t bytes) = 0;
+    virtual double *mirror(int b) = 0;                             // band b's local copies of all bands' partial blocks
+    bool copy_transport = false;
+    void read_transport()
+    {
+        const char *e = getenv("OCTANE_TILED_TRANSPORT");
+        copy_transport = e && std::string(e) == "copy";
+    }
     float *peer(int c, int b, float *plane_of_b) const
     {
         return reinterpret_cast<float *>(arena[c] + (reinterpret_cast<char *>(plane_of_b) - arena[b]));
@@ -294,6 +316,24 @@ static void send_rows(BandNet &N, int b, float *plane, int pitch, int ya, int yb
     BAND_HIP(N.copy(b, N.peer(dst, b, plane) + (size_t)ya * pitch, dst, plane + (size_t)ya * pitch, (size_t)(yb - ya) * pitch * sizeof(float)));
 }
 
+// copy transport: rows [ya, yb) of band `src`'s copy of one of band b's planes into band b's own plane (same rows), and the
+// partial block(s) of every other band into band b's mirror
+static void pull_rows(BandNet &N, int b, int src, float *plane, int pitch, int ya, int yb)
+{
+    if (yb <= ya) return;
+    N.copies[b]++;
+    BAND_HIP(N.pull(b, plane + (size_t)ya * pitch, src, N.peer(src, b, plane) + (size_t)ya * pitch, (size_t)(yb - ya) * pitch * sizeof(float)));
+}
+static void pull_parts(BandNet &N, int b, int parity, int first, int count)
+{
+    for (int c = 0; c < N.nb; c++) {
+        if (c == b) continue;
+        N.copies[b]++;
+        const size_t off = (size_t)parity * kPartBlock + first;
+        BAND_HIP(N.pull(b, N.mirror(b) + (size_t)c * 2 * kPartBlock + off, c, N.parts[c] + off, (size_t)count * sizeof(double)));
+    }
+}
+
 // ---- one banded level, as band b issues it ----------------------------------------------------------------------------
 static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx &ctx, bool finest)
 {
@@ -311,10 +351,15 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
     L.nbands = nb;
     double *own = N.parts[b];
     L.part_rz = own + kPartRz; L.part_rr = own + kPartRr; L.part_pq = own + kPartPq; L.part_own = own;
-    for (int c = 0; c < kMaxBands; c++) L.band_parts[c] = N.parts[c < nb ? c : b];
+    const bool cp = N.copy_transport;                  // neighbours' rows and partial blocks are pulled into local memory, kernels read local
+    for (int c = 0; c < kMaxBands; c++) {
+        const int cc = c < nb ? c : b;
+        L.band_parts[c] = (cp && cc != b) ? N.mirror(b) + (size_t)cc * 2 * kPartBlock : N.parts[cc];
+    }
     const int up = b > 0 ? b - 1 : b, dn = b < nb - 1 ? b + 1 : b;
-    L.ru_up = N.peer(up, b, pl->ru); L.rv_up = N.peer(up, b, pl->rv);
-    L.ru_dn = N.peer(dn, b, pl->ru); L.rv_dn = N.peer(dn, b, pl->rv);
+    const int rup = cp ? b : up, rdn = cp ? b : dn;    // whose planes the kernels read the rows beyond the band's edges from
+    L.ru_up = N.peer(rup, b, pl->ru); L.rv_up = N.peer(rup, b, pl->rv);
+    L.ru_dn = N.peer(rdn, b, pl->ru); L.rv_dn = N.peer(rdn, b, pl->rv);
     int maxrows = 0;
     for (int c = 0; c < nb; c++) maxrows = rows[c].y1 - rows[c].y0 > maxrows ? rows[c].y1 - rows[c].y0 : maxrows;
     // every band launches the same grids, so that the blocks hold the same number of partials (idle workgroups
@@ -327,19 +372,19 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
     L.q_form = (fused && pcg_fused_q_form(li.w, maxrows, li.h)) ? 1 : 0;
     if (fused && !L.q_form)   // q of the neighbouring bands' edge rows is read from their planes (both halves of the double buffer)
         for (int i = 0; i < 2; i++) {
-            L.qup_u[i] = N.peer(up, b, L.qb_u[i]); L.qup_v[i] = N.peer(up, b, L.qb_v[i]);
-            L.qdn_u[i] = N.peer(dn, b, L.qb_u[i]); L.qdn_v[i] = N.peer(dn, b, L.qb_v[i]);
+            L.qup_u[i] = N.peer(rup, b, L.qb_u[i]); L.qup_v[i] = N.peer(rup, b, L.qb_v[i]);
+            L.qdn_u[i] = N.peer(rdn, b, L.qb_u[i]); L.qdn_v[i] = N.peer(rdn, b, L.qb_v[i]);
         }
     if (L.q_form) {           // q is recomputed: r on the row beyond an edge, p on the two rows beyond it, wy of the row above the upper one
         for (int i = 0; i < 2; i++) {
-            L.rup_u[i] = N.peer(up, b, L.rb_u[i]); L.rup_v[i] = N.peer(up, b, L.rb_v[i]);
-            L.rdn_u[i] = N.peer(dn, b, L.rb_u[i]); L.rdn_v[i] = N.peer(dn, b, L.rb_v[i]);
+            L.rup_u[i] = N.peer(rup, b, L.rb_u[i]); L.rup_v[i] = N.peer(rup, b, L.rb_v[i]);
+            L.rdn_u[i] = N.peer(rdn, b, L.rb_u[i]); L.rdn_v[i] = N.peer(rdn, b, L.rb_v[i]);
         }
         for (int i = 0; i < 3; i++) {
-            L.pup_u[i] = N.peer(up, b, L.pf_u[i]); L.pup_v[i] = N.peer(up, b, L.pf_v[i]);
-            L.pdn_u[i] = N.peer(dn, b, L.pf_u[i]); L.pdn_v[i] = N.peer(dn, b, L.pf_v[i]);
+            L.pup_u[i] = N.peer(rup, b, L.pf_u[i]); L.pup_v[i] = N.peer(rup, b, L.pf_v[i]);
+            L.pdn_u[i] = N.peer(rdn, b, L.pf_u[i]); L.pdn_v[i] = N.peer(rdn, b, L.pf_v[i]);
         }
-        L.wy_up = N.peer(up, b, pl->wy);
+        L.wy_up = N.peer(rup, b, pl->wy);
     }
 
     for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
@@ -359,10 +404,35 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
                 launch_assemble(s, La, ap, g_asm);
             }
             N.sync(b);
+            if (cp) {      // what the first launch reads of the others: the sums of their right-hand sides, wy of the row above the upper ring row
+                if (!fused) N.fail(b, OCTANE_E_INVALID, "OCTANE_TILED_TRANSPORT=copy needs the one-kernel PCG iteration (OCTANE_TUNE_FUSED=1)");
+                pull_parts(N, b, 1, kPartRz, 2 * kMaxParts);
+                if (L.q_form && b > 0 && L.y0 >= 2) pull_rows(N, b, up, pl->wy, li.pitch, L.y0 - 2, L.y0 - 1);
+            }
             if (fused) {
                 for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182: one kernel and one boundary per iteration
                     if (!N.failed()) launch_pcg_fused(s, L, it, it == 0 ? g_asm : g_f, g_f, pl->tol);
                     N.sync(b);
+                    if (cp) {   // what launch it + 1 (or the flow update) reads of the others: their sums, the rows beyond this band's edges
+                        pull_parts(N, b, it & 1, 0, kPartBlock);
+                        for (int side = 0; side < 2; side++) {
+                            const int nbr = side == 0 ? up : dn;
+                            if (nbr == b) continue;
+                            const int e0 = side == 0 ? L.y0 : L.y1;             // the edge: rows e0 - 2, e0 - 1 lie above it, e0, e0 + 1 below
+                            if (L.q_form) {
+                                const int ya = side == 0 ? e0 - 2 : e0, yb = side == 0 ? e0 : e0 + 2;
+                                const int ra = side == 0 ? e0 - 1 : e0;
+                                pull_rows(N, b, nbr, L.pf_u[it % 3], li.pitch, ya < 0 ? 0 : ya, yb > li.h ? li.h : yb);
+                                pull_rows(N, b, nbr, L.pf_v[it % 3], li.pitch, ya < 0 ? 0 : ya, yb > li.h ? li.h : yb);
+                                pull_rows(N, b, nbr, L.rb_u[it & 1], li.pitch, ra, ra + 1);
+                                pull_rows(N, b, nbr, L.rb_v[it & 1], li.pitch, ra, ra + 1);
+                            } else {
+                                const int qa = side == 0 ? e0 - 1 : e0;
+                                pull_rows(N, b, nbr, L.qb_u[it & 1], li.pitch, qa, qa + 1);
+                                pull_rows(N, b, nbr, L.qb_v[it & 1], li.pitch, qa, qa + 1);
+                            }
+                        }
+                    }
                 }
                 if (!N.failed()) launch_flow_update_fused(s, L, prm.cgiters, g_f);     // ref .cu:1185-1195
             } else {
@@ -441,6 +511,14 @@ struct ThreadNet : BandNet {
     {
         nb = t->nbands; prm = t->prm; rows = &t->rows;
         for (int b = 0; b < nb; b++) { arena[b] = reinterpret_cast<char *>(t->pl[b]->arena); parts[b] = t->parts[b]; }
+        read_transport();
+    }
+    double *mirror(int b) override { return t->mirror[b]; }
+    hipError_t pull(int b, void *dst_local, int sband, const void *src, size_t bytes) override
+    {
+        hipStream_t s = t->pl[b]->own_stream;
+        if (t->dev[sband] == t->dev[b]) return hipMemcpyAsync(dst_local, src, bytes, hipMemcpyDeviceToDevice, s);
+        return hipMemcpyPeerAsync(dst_local, t->dev[b], src, t->dev[sband], bytes, s);
     }
     octane_vof_plan *plan(int b) override { return t->pl[b]; }
     bool failed() override { return failed_.load(std::memory_order_relaxed) != 0; }
@@ -607,6 +685,7 @@ struct octane_vof_mp {
     octane_vof_params prm;
     octane_vof_plan *pl = nullptr;
     double *parts = nullptr;
+    double *mirror = nullptr;      // local copies of every rank's partial blocks (copy transport)
     char *arena[kMaxBands] = {nullptr};
     double *parts_all[kMaxBands] = {nullptr};
     bool connected = false;
@@ -630,6 +709,12 @@ struct ProcNet : BandNet {
     {
         nb = m->world; prm = m->prm; rows = &m->rows;
         for (int b = 0; b < nb; b++) { arena[b] = m->arena[b]; parts[b] = m->parts_all[b]; }
+        read_transport();
+    }
+    double *mirror(int) override { return m->mirror; }
+    hipError_t pull(int, void *dst_local, int, const void *src, size_t bytes) override
+    {
+        return hipMemcpyAsync(dst_local, src, bytes, hipMemcpyDefault, m->pl->own_stream);     // src is an IPC mapping
     }
     octane_vof_plan *plan(int) override { return m->pl; }
     bool dead() const { return m->shm->dead.load(std::memory_order_acquire) != 0; }
@@ -675,6 +760,7 @@ extern "C" int octane_vof_mp_destroy(octane_vof_mp *m)
         if (m->rank == 0) shm_unlink(m->shm_name.c_str());
     }
     if (m->parts) (void)hipFree(m->parts);
+    if (m->mirror) (void)hipFree(m->mirror);
     if (m->pl) octane_vof_plan_destroy(m->pl);
     delete m;
     return OCTANE_OK;
@@ -694,7 +780,9 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
     if (rc != OCTANE_OK) { delete m; return rc; }
     m->device = m->pl->device;
     if (hipMalloc((void **)&m->parts, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
-        hipMemset(m->parts, 0, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        hipMemset(m->parts, 0, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&m->mirror, (size_t)world * 2 * kPartBlock * sizeof(double)) != hipSuccess ||
+        hipMemset(m->mirror, 0, (size_t)world * 2 * kPartBlock * sizeof(double)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         set_last_error("octane_vof_mp_create: device allocation failed");
         octane_vof_mp_destroy(m);
         return OCTANE_E_NOMEM;

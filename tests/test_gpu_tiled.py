@@ -244,3 +244,28 @@ def test_bands_above_four_megapixels_recompute_q(capi, oracle, nbands):
         ut, vt, info = _tiled(capi, a, b, prm1, nbands)
         uo, vo, _ = oracle.flow(a, b, oracle.FlowParams(**prm1), flavour="omp", dot_threads=oracle.REF_GRID_THREADS)
         assert rel_l2(ut, vt, uo, vo) < ORDER_BAR
+
+
+@pytest.mark.parametrize("nx,ny,nbands,prm", [
+    (300, 420, 3, dict(kiters=3, liters=2, cgiters=20)),          # small bands: the stored-q form, one row of q per edge
+    (2432, 3584, 2, dict(kiters=2, liters=1, cgiters=9)),         # bands of 4.4 Mpixel: the q-recomputing form, r and two rows of p per edge, wy
+    (1700, 1100, 4, dict(kiters=2, liters=1, cgiters=12)),
+])
+def test_copy_transport_equals_in_place_reads_bit_for_bit(capi, nx, ny, nbands, prm):
+    """OCTANE_TILED_TRANSPORT=copy: the rows beyond a band's edges and the other bands' partial sums are pulled into local memory
+    by stream-ordered copies and every kernel reads local memory only -- the fallback that tells a protocol error from a
+    visibility problem of in-kernel peer reads.  Same arithmetic, same fold order: the flow has to be the in-place transport's
+    bit for bit, with more copies issued."""
+    import os
+    a, b = synth.lattice_scene(nx, ny, seed=29)
+    ui, vi, info_i = _tiled(capi, a, b, prm, nbands)
+    os.environ["OCTANE_TILED_TRANSPORT"] = "copy"
+    try:
+        uc, vc, info_c = _tiled(capi, a, b, prm, nbands)
+    finally:
+        del os.environ["OCTANE_TILED_TRANSPORT"]
+    print(f"TRANSPORT {nx}x{ny} {nbands} bands: copies in place {info_i['copies']}, copy transport {info_c['copies']}; "
+          f"{int((ui != uc).sum() + (vi != vc).sum())} values differ")
+    assert info_c["banded"] == info_i["banded"] >= 1 and info_c["its"] == info_i["its"]
+    assert info_c["copies"] > info_i["copies"]
+    assert np.array_equal(ui, uc) and np.array_equal(vi, vc)

@@ -18,12 +18,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, args, timeout=300):
+def _run(world, args, timeout=300, extra_env=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_band_worker.py"), *map(str, args)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -44,6 +44,15 @@ def test_one_band_per_process_matches_plain_plan(world, args):
     line = [l for l in outs[0].splitlines() if l.startswith("MP_RESULT")]
     assert line and "ok=True" in line[0], outs[0]
     assert "banded=0" not in line[0]
+
+
+def test_one_band_per_process_with_the_copy_transport():
+    """The same with OCTANE_TILED_TRANSPORT=copy: what crosses ranks is pulled through the IPC mappings by runtime copies, the
+    kernels read local memory only."""
+    codes, outs = _run(2, (320, 288, 3, 2, 12, 1), extra_env={"OCTANE_TILED_TRANSPORT": "copy"})
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    line = [l for l in outs[0].splitlines() if l.startswith("MP_RESULT")]
+    assert line and "ok=True" in line[0], outs[0]
 
 
 def test_a_dead_rank_does_not_leave_the_survivor_spinning():
