@@ -68,7 +68,17 @@ def device_state(torch, dev):
     dt = (_t.perf_counter() - t0) / reps
     del a, b
     torch.cuda.empty_cache()
-    return {"name": prop.name, "compute_units": prop.multi_processor_count, "copy_1gib_gbs": round(2 * n * 4 / dt / 1e9, 1),
+    where = None
+    try:    # which GPU of which node this is (best effort: the pool's boxes differ, see above)
+        import subprocess
+        txt = subprocess.run(["rocm-smi", "--showbus", "--showproductname", "--showmemorypartition", "--showcomputepartition"],
+                             capture_output=True, text=True, timeout=20).stdout
+        keep = [ln.split(":", 1)[1].strip().replace("\t", " ") for ln in txt.splitlines()
+                if ln.startswith("GPU[0]") and any(k in ln for k in ("PCI Bus", "Node ID", "GUID", "Partition"))]
+        where = "; ".join(keep) or None
+    except Exception:
+        pass
+    return {"name": prop.name, "compute_units": prop.multi_processor_count, "where": where, "copy_1gib_gbs": round(2 * n * 4 / dt / 1e9, 1),
             "note": "torch device-to-device copy of 1 GiB (read + write), a yardstick for the box's memory state, not a roofline"}
 
 

@@ -392,8 +392,13 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         float *cand[kMaxTrials] = {pl->arena};
         double ms[kMaxTrials] = {0};
         int ncand = 1;
+        // experiment (OCTANE_TUNE_ARENA_CONTIG=1): odd candidates ask for physically contiguous memory
+        const bool try_contig = getenv("OCTANE_TUNE_ARENA_CONTIG") && atoi(getenv("OCTANE_TUNE_ARENA_CONTIG")) != 0;
         for (int t = 1; t < trials; t++) {
-            if (hipMalloc((void **)&cand[t], pl->arena_bytes) != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
+            hipError_t ae = (try_contig && (t & 1)) ? hipExtMallocWithFlags((void **)&cand[t], pl->arena_bytes, hipDeviceMallocContiguous)
+                                                    : hipMalloc((void **)&cand[t], pl->arena_bytes);
+            if (ae != hipSuccess && try_contig && (t & 1)) { (void)hipGetLastError(); ae = hipMalloc((void **)&cand[t], pl->arena_bytes); if (getenv("OCTANE_TUNE_VERBOSE")) fprintf(stderr, "[octane] contiguous candidate %d refused\n", t); }
+            if (ae != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
             ncand = t + 1;
         }
         int best = 0;
