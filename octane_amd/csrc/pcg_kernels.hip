@@ -1013,19 +1013,10 @@ __device__ __forceinline__ void stencil_group(const float *s_u, const float *s_v
     }
 }
 
-// Diagnostic build (STAMP, launched by octane_vof_plan_probe_stamps only): every wave reads the shader clock at the seams of a
-// tile and adds up where its time goes; one atomic add per wave and seam at the end.  [0] loads of the own groups issued, [1] p
-// staged (includes the wait for p), [2] first barrier, [3] ring group, [4] own groups, [5] second barrier, [6] phase 2,
-// [7] tiles, [8] everything before the first tile (fold of the partial sums), [9] the final reduction
-__device__ unsigned long long g_q_stamps[16];
-
-template <bool UNITW, bool BANDED, bool STAMP = false>
+template <bool UNITW, bool BANDED>
 __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int nparts_prev, float tol)
 {
     constexpr int TY = kQTY, TX = kTileX;
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
-    if (STAMP) st_last = clock64();
-#define Q_STAMP(i) do { if (STAMP) { const unsigned long long now_ = clock64(); st_acc[i] += now_ - st_last; st_last = now_; } } while (0)
     __shared__ __attribute__((aligned(16))) float s_ou[(TY + 4) * kQCols], s_ov[(TY + 4) * kQCols];   // p_{k-1}: rows ty0-2 .. ty0+TY+1
     // p_k: rows ty0-1 .. ty0+TY, two buffers used alternately -- a workgroup's fast waves may stage and compute the next tile
     // while its slow ones still read this one's p_k in phase 2, which saves the barrier at the end of a tile
@@ -1092,23 +1083,10 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
     double acc_pq = 0., acc_qz = 0., acc_qmq = 0., acc_rq = 0., acc_qq = 0., acc_rz = 0., acc_rr = 0.;
 
     const ItemRange tr = item_range_walk(ntiles, L.xcd_bands);
-    // xcd_bands >= 5: vertical slabs per XCD inside super-rows of (xcd_bands & 63) tile rows (device_util.hpp, SlabWalk)
-    const bool slabs = L.xcd_bands >= 5 && (gridDim.x & 7) == 0 && tiles_x >= 8;
-    SlabWalk sw = slab_walk_begin(tiles_x, tiles_y, slabs ? (L.xcd_bands & 63) : 1);
     int parity = 0;
-    Q_STAMP(8);
-    for (int t = tr.first; ; t += tr.step, parity ^= 1) {
-        int tcol, trow;
-        if (slabs) {
-            if (!slab_walk_tile(sw, tcol, trow)) break;
-            slab_walk_next(sw);
-        } else {
-            if (t >= tr.end) break;
-            tcol = t % tiles_x; trow = t / tiles_x;
-        }
-        if (STAMP) st_acc[7] += 1;
+    for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1) {
         float *const s_nu = s_nu2 + parity * NSZ, *const s_nv = s_nv2 + parity * NSZ;
-        const int tx0 = tcol * TX, ty0 = y0 + trow * TY;
+        const int tx0 = (t % tiles_x) * TX, ty0 = y0 + (t / tiles_x) * TY;
         // ---- loads of the thread's two tile groups first (r_{k-1} and the operator; addresses of groups beyond a ragged
         // edge are clamped into the frame, their values never used), so that they are in flight while phase 0 waits for p
         QCoef c3[2];
@@ -1120,8 +1098,8 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
             const bool valid = y < y1 && x0 < w;
             const unsigned o = valid ? (unsigned)(y * pitch + x0) * 4u : 0u;
             QCoef &c = c3[slot];
-            *(float4 *)r3u[slot] = ld4_if(at(rin_u, o), L.nt_hints & 512); *(float4 *)r3v[slot] = ld4_if(at(rin_v, o), L.nt_hints & 512);
-            *(float4 *)c.a1 = ld4_if(at(L.a1, o), L.nt_hints & 1024); *(float4 *)c.a4 = ld4_if(at(L.a4, o), L.nt_hints & 1024);
+            *(float4 *)r3u[slot] = ld4(at(rin_u, o)); *(float4 *)r3v[slot] = ld4(at(rin_v, o));
+            *(float4 *)c.a1 = ld4(at(L.a1, o)); *(float4 *)c.a4 = ld4(at(L.a4, o));
             // no streaming hint by default (bit 256, not the stored-q kernels' bit 8): the neighbouring tiles' rings read these
             // lines too, -1.5 % without it.  The switch stays because the kernel is 3 % slower without the branch (sic).
             *(float4 *)c.a2 = ld4_if(at(L.a2, o), L.nt_hints & 256);
@@ -1130,12 +1108,11 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                 for (int e = 0; e < 4; e++) { c.wx[e] = -1.f; c.wy[e] = -1.f; c.wys[e] = -1.f; }
                 c.wxw = -1.f;
             } else {
-                *(float4 *)c.wx = ld4_if(at(L.wx, o), L.nt_hints & 2048); *(float4 *)c.wy = ld4_if(at(L.wy, o), L.nt_hints & 2048);
+                *(float4 *)c.wx = ld4(at(L.wx, o)); *(float4 *)c.wy = ld4(at(L.wy, o));
                 *(float4 *)c.wys = ld4(at(L.wy, (valid && y > 0) ? o - 4u * (unsigned)pitch : o));     // unused in the frame's first row
                 c.wxw = *at(L.wx, (valid && x0 > 0) ? o - 4u : o);                                      // unused in its first column
             }
         }
-        Q_STAMP(0);
         // ---- phase 0: p_{k-1} on the tile + 2 rows / one float4 group around it (zero outside the frame)
         if (!first) {
             constexpr int GW = TX / 4 + 2;                        // groups per staged row: one left, one right of the tile
@@ -1147,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                     const unsigned o = (unsigned)(y * pitch + x0) * 4u;
                     if (BANDED && y < y0) { pu = ld4(at(L.pup_u[(k + 2) % 3], o)); pv = ld4(at(L.pup_v[(k + 2) % 3], o)); }
                     else if (BANDED && y >= y1) { pu = ld4(at(L.pdn_u[(k + 2) % 3], o)); pv = ld4(at(L.pdn_v[(k + 2) % 3], o)); }
-                    else { pu = ld4_if(at(pin_u, o), L.nt_hints & 4096); pv = ld4_if(at(pin_v, o), L.nt_hints & 4096); }   // planes are padded to a multiple of 64 floats: in bounds
+                    else { pu = ld4(at(pin_u, o)); pv = ld4(at(pin_v, o)); }   // planes are padded to a multiple of 64 floats: in bounds
                     if (x0 + 3 >= w) {                            // beyond the frame's last column: zero, as the other forms do
                         if (x0 + 1 >= w) { pu.y = 0.f; pv.y = 0.f; }
                         if (x0 + 2 >= w) { pu.z = 0.f; pv.z = 0.f; }
@@ -1157,9 +1134,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                 st4(&s_ou[(gy + 2) * kQCols + kQOff + 4 * gx], pu);
                 st4(&s_ov[(gy + 2) * kQCols + kQOff + 4 * gx], pv);
             }
-            Q_STAMP(1);
             __syncthreads();
-            Q_STAMP(2);
         }
         // ---- phase 1: the ring group (one each for the first 100 threads), then the two tile groups
 #pragma unroll
@@ -1247,11 +1222,8 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
 #pragma unroll
                 for (int e = 0; e < 4; e++) { r3u[slot & 1][e] = ru[e]; r3v[slot & 1][e] = rv[e]; }     // r_k, for the sums of phase 2
             }
-            if (STAMP && sl == 0) Q_STAMP(3);
         }
-        Q_STAMP(4);
         __syncthreads();
-        Q_STAMP(5);
         // ---- phase 2: q_k on the tile and the partial sums (q_k is not stored: the next launch forms it again)
         if (active) {
 #pragma unroll
@@ -1283,7 +1255,6 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
                 }
             }
         }
-        Q_STAMP(6);
     }
     if (!active) return;
     double *own_blk = L.part_own + pout_off;
@@ -1294,25 +1265,6 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
 #pragma unroll
         for (int j = 0; j < kPartKinds; j++) own_blk[j * kMaxParts + blockIdx.x] = tot[j];
     }
-    if (STAMP) {
-        Q_STAMP(9);
-        if ((tid & 63) == 0) {
-#pragma unroll
-            for (int j = 0; j < 10; j++) atomicAdd(&g_q_stamps[j], st_acc[j]);
-        }
-    }
-#undef Q_STAMP
-}
-
-// Diagnostic (tools/probe_stamps.py): one stamped launch of the q-recomputing kernel on whatever the planes hold
-int pcg_fused_q_stamps(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol, unsigned long long *out16)
-{
-    unsigned long long zero[16] = {0};
-    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q_stamps), zero, sizeof zero, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
-    if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused_q<true, false, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-    else hipLaunchKernelGGL((k_pcg_fused_q<false, false, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-    if (hipMemcpyFromSymbolAsync(out16, HIP_SYMBOL(g_q_stamps), sizeof zero, 0, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
 }
 
 // u += dx, v += dy after a solve made of `nlaunched` fused kernels (ref .cu:1185-1195).  A solve that ran into its
@@ -1657,10 +1609,13 @@ int pcg_fused_grid_size(int w, int rows, int unit_w, int q_form)
     return g;
 }
 
+static int g_q_diag = 0;              // diagnostics: route whole-level q-form launches to the copy in pcg_fused_q_diag.hip
+void set_q_diag(int v) { g_q_diag = v != 0; }
 void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
     const bool small = fused_rows(L.w, L.y1 - L.y0) == 1;
     const bool whole = L.nbands == 1 && L.y0 == 0 && L.y1 == L.h;
+    if (g_q_diag && L.q_form && whole) { launch_pcg_fused_q_diag(s, L, k, nparts_prev, grid, tol); return; }
     if (L.q_form) {                                                    // q = A p is not stored but formed again
         if (whole) {
             if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused_q<true, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);

@@ -1406,6 +1406,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "unit_w") pl->use_unit_w = value != 0;
     else if (k == "fused") pl->use_fused = value != 0;
     else if (k == "fused_q") set_fused_q(value);
+    else if (k == "q_diag") set_q_diag(value);
     else if (k == "persist") pl->use_persist = value != 0;
     else if (k == "persist_step") pl->persist_step = value;
     else if (k == "persist_p") pl->persist_p = value;

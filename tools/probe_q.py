@@ -12,9 +12,10 @@ for plan_i in range(2):
     res = {}
     for rep in range(4):
         for xcd, nt in combos:
+            pl.tune("q_diag", 0 if (xcd == 4 and nt == 15) else 1)      # the production kernel for its own setting, the diagnostic copy otherwise
             pl.tune("xcd", xcd); pl.tune("nt", nt)
             a, b = pl.probe(lev, 40)
             res.setdefault((xcd, nt), []).append(a * 1e3)
-    pl.tune("xcd", 4); pl.tune("nt", 15)
+    pl.tune("xcd", 4); pl.tune("nt", 15); pl.tune("q_diag", 0)
     print("plan", plan_i, " | ".join(f"xcd{c[0]} nt{c[1]}: {min(res[c]):.1f}" for c in combos), "us (min of 4)", flush=True)
     pl.close()
