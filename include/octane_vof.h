@@ -96,7 +96,12 @@ int octane_vof_plan_solve(octane_vof_plan *plan, const float *img1, const float 
                           float *u_out, float *v_out, int mem, void *hip_stream);
 
 /* Number of PCG iterations the last completed run executed (sum over all solves); blocks on the stream. */
-int octane_vof_plan_wait(octane_vof_plan *plan);          /* blocks until the plan's private stream is idle */
+int octane_vof_plan_wait(octane_vof_plan *plan);          /* blocks until the plan's private stream is idle; OCTANE_E_HIP when a
+                                                            * persistent solve of the run gave up (see below) */
+/* -2 when the last run is not valid: the mid-size pyramid levels are solved by ONE persistent launch each whose workgroups all
+ * have to be resident on the GPU at once; if they cannot become so within 0.25 s (another process running the same kind of
+ * kernel on this GPU) the solve gives up instead of hanging the GPU.  Host-buffer runs return OCTANE_E_HIP themselves;
+ * OCTANE_TUNE_PERSIST=0 selects one launch per iteration. */
 long long octane_vof_plan_last_iterations(octane_vof_plan *plan);
 
 /* Debug tap (NULL = off, zero cost): called on the host after each stage with a copy of the stage's
