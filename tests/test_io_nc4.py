@@ -421,3 +421,63 @@ def test_writers_emit_the_references_variables_without_a_gpu(io_demo, tmp_path, 
         assert np.array_equal(_read(io_demo, out, "Rad", "float", tmp_path), img[:n]) and "Rad2" not in d
         p = d["merc_imager_projection"]["atts"]
         assert p["grid_mapping_name"] == "Mercator" and float(p["lon1"]) == -100.0 and abs(float(p["R"]) - 6371228.0) < 1.0
+
+
+H5DUMP = os.path.join(HDF5_ROOT, "bin", "h5dump")
+
+
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="no h5dump on this machine")
+def test_outfile_is_read_by_an_independent_hdf5_tool(io_demo, tmp_path):
+    """Interoperability of nc4lite's output: `h5dump -H` -- HDF5's own tool, nothing of this repository --
+    opens outfile.nc, and its header lists the variables, types, dimension-scale conventions and attributes that
+    ref src/oct_filewrite.cc:17-349 writes through netcdf-cxx4: U / V / U_raw / V_raw / Rad as 16-bit integers on (y, x) with a
+    float `scale_factor` (NC_FLOAT, ref :118-175), `grid_mapping` strings, x / y as dimension scales, the two container
+    variables `goes_imager_projection` (doubles, ref :219-227) and `optical_flow_settings` (ref :229-251).  Still "parity
+    unpinned": no netCDF library exists on either box, so the netCDF-4 layer (`_Netcdf4Dimid`, `DIMENSION_LIST`,
+    dimension scales) is checked by its documented HDF5 representation, not by `ncdump`."""
+    nx, ny = 40, 24
+    out = tmp_path / "o.nc"
+    subprocess.check_call([io_demo, "--write-out", str(out), "GOES", str(nx), str(ny), "1"])
+    r = subprocess.run([H5DUMP, "-H", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = r.stdout
+    assert txt.startswith("HDF5 \"") and "GROUP \"/\"" in txt
+
+    def block(name):
+        i = txt.index(f'DATASET "{name}" {{')
+        depth, j = 0, i
+        while True:
+            if txt[j] == "{":
+                depth += 1
+            elif txt[j] == "}":
+                depth -= 1
+                if depth == 0:
+                    return txt[i:j + 1]
+            j += 1
+
+    for name in ("U", "V", "U_raw", "V_raw", "Rad"):
+        b = block(name)
+        assert "DATATYPE  H5T_STD_I16LE" in b, name
+        assert f"DATASPACE  SIMPLE {{ ( {ny}, {nx} ) / ( {ny}, {nx} ) }}" in b, name
+        assert 'ATTRIBUTE "DIMENSION_LIST"' in b and 'ATTRIBUTE "scale_factor"' in b and 'ATTRIBUTE "grid_mapping"' in b, name
+        sf = b[b.index('ATTRIBUTE "scale_factor"'):]
+        assert "H5T_IEEE_F32LE" in sf[:sf.index("}")+200].split("DATASPACE")[0], name        # NC_FLOAT, as the reference writes it
+    for name in ("Upix", "Vpix"):
+        assert "DATATYPE  H5T_IEEE_F32LE" in block(name), name
+    for name, n in (("x", nx), ("y", ny)):
+        b = block(name)
+        assert "DATATYPE  H5T_STD_I16LE" in b and f"( {n} )" in b
+        assert 'ATTRIBUTE "CLASS"' in b and "DIMENSION_SCALE" not in b.split('ATTRIBUTE "CLASS"')[0] and 'ATTRIBUTE "_Netcdf4Dimid"' in b
+    g = block("goes_imager_projection")
+    for att in ("perspective_point_height", "semi_major_axis", "semi_minor_axis", "inverse_flattening",
+                "latitude_of_projection_origin", "longitude_of_projection_origin"):
+        a = g[g.index(f'ATTRIBUTE "{att}"'):]
+        assert "H5T_IEEE_F64LE" in a[:400], att                                          # NC_DOUBLE
+    assert 'ATTRIBUTE "grid_mapping_name"' in g and 'ATTRIBUTE "sweep_angle_axis"' in g
+    s = block("optical_flow_settings")
+    for att in ("long_name", "key", "Image2_xOffset", "Image2_yOffset", "alpha", "K_Iterations", "dt_seconds"):
+        assert f'ATTRIBUTE "{att}"' in s, att
+    # (nc4lite does not write the hidden root attribute _NCProperties; netCDF readers treat it as optional provenance)
+    # and the values come back through the tool as well: a corner of U
+    r = subprocess.run([H5DUMP, "-d", "/U", "-s", "0,0", "-c", "1,5", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "(0,0): 0, 1, 2, 3, 4" in r.stdout, r.stdout
