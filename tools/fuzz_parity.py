@@ -1,6 +1,6 @@
 """Randomised parity sweep: HIP path against the oracle on random frame shapes, channel counts and solver parameters
-(first guess and hint term included), with the bar of tests/test_gpu_parity.py (2e-5, or twice the problem's own
-sensitivity to rounding as measured between the oracle's two builds).  A development tool, not part of the test suite:
+(first guess and hint term included), with the criterion of tests/test_gpu_parity.py (distance to the primary oracle
+below 2e-5; cases on which the oracle's own variants are further apart than half of that are reported as CHAOTIC).  A development tool, not part of the test suite:
    python tools/fuzz_parity.py [cases] [seed] [only_case [forms]]     needs a GPU; prints one line per case and a summary;
    with only_case just that case is run, with a fifth argument the three forms of the PCG iteration are compared on it."""
 import os
@@ -28,7 +28,7 @@ def main():
     forms = len(sys.argv) > 4                                     # and compare the three forms of the PCG iteration on it
     oo.build()
     oo.set_threads(oo.host_cpu_share())
-    worst, bad = 0.0, 0
+    worst, bad, chaotic = 0.0, 0, 0
     for case in range(ncases):
         big = case % 10 == 9                       # every tenth case is large enough for the q-recomputing kernel
         if big:
@@ -81,17 +81,20 @@ def main():
         ug, vg = pl.run_host(a, b, u0, v0)
         its_g = pl.last_iterations()
         pl.close()
+        # the tests' criterion (tests/test_gpu_parity.py, _check): distance to the PRIMARY oracle (strict build, the reference's
+        # launch geometry) below 2e-5 -- the bar does not move with the problem.  A case above it is either a defect or a parameter
+        # set on which the truncated solve amplifies single roundings (the oracle's own variants are then as far apart): the latter
+        # kind is what the tests' allow-list is for, and is reported as CHAOTIC with the oracle's spread, never silently passed.
         d = rel_l2(ug, vg, uo, vo)
-        if u2 is not None:
-            d = min(d, rel_l2(ug, vg, u2, v2))
-        if us is not None:
-            d = min(d, rel_l2(ug, vg, us, vs))
-        bar = max(2e-5, 2.0 * floor)
-        ok = np.isfinite(ug).all() and d < bar and its_g == its_o
+        d_other = min([rel_l2(ug, vg, x, y) for x, y in ((u2, v2), (us, vs)) if x is not None] or [float("nan")])
+        bar = 2e-5
+        fine = bool(np.isfinite(ug).all()) and its_g == its_o
+        verdict = "ok " if (fine and d < bar) else ("CHAOTIC" if (fine and floor > bar / 2) else "BAD")
         worst = max(worst, d / bar)
-        bad += 0 if ok else 1
-        print(f"{'ok ' if ok else 'BAD'} {nx}x{ny}x{nc} {prm} guess={u0 is not None}: {d:.2e} (floor {floor:.1e}, bar {bar:.1e}) its {its_g}/{its_o}", flush=True)
-    print(f"{ncases} cases, {bad} bad, worst distance / bar = {worst:.2f}")
+        bad += 1 if verdict == "BAD" else 0
+        chaotic += 1 if verdict == "CHAOTIC" else 0
+        print(f"{verdict} {nx}x{ny}x{nc} {prm} guess={u0 is not None}: d_primary {d:.2e} (bar {bar:.0e}; oracle spread {floor:.1e}, nearest other oracle variant {d_other:.1e}) its {its_g}/{its_o}", flush=True)
+    print(f"{ncases} cases, {bad} bad, {chaotic} chaotic (would need an allow-list entry), worst distance / bar = {worst:.2f}")
     return 1 if bad else 0
 
 
