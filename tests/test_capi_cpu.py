@@ -129,3 +129,15 @@ def test_band_partition_covers_the_level_with_aligned_inner_edges(capi):
     assert capi.band_partition(10848, 4) == [0, 2720, 5440, 8128, 10848]
     with pytest.raises(capi.OctaneError):
         capi.band_partition(100, 9)
+
+
+def test_bench_refuses_more_gpus_than_are_visible():
+    """bench.py --gpus N starts N ranks itself -- and exits non-zero, before touching any GPU, when fewer than N are visible."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OCTANE_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "--gpus 64 but only" in r.stderr, r.stderr
+    env["WORLD_SIZE"] = "3"; env["RANK"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "disagrees with WORLD_SIZE" in r.stderr, r.stderr
