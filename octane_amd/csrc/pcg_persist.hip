@@ -157,6 +157,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
 
     // The solve's scalars between the launches of the stepped form, double-buffered by the parity of the first iteration (a
     // one-iteration launch has no barrier, so workgroup 0 may write the new state before another workgroup has read the old)
+    if (A.fault && wg == A.G - 1) return;                  // test hook: a workgroup that never shows up -- the others have to give up, not hang
     PcgState st = L.st[A.k0 & 1];
     if (A.k0 == 0) { st.rz = 0.f; st.stopped = 0; st.iters = 0; }
     if (st.stopped) {                                      // stepped form: the loop ended in an earlier launch (uniform)
@@ -514,10 +515,14 @@ size_t pcg_mid_workspace_bytes()
 }
 
 // Iterations [k0, k1) of one solve; k0 = 0 and k1 = cgiters is the whole solve in one launch (plus the flow update).
+static int g_mid_fault = 0;
+void set_mid_fault(int v) { g_mid_fault = v != 0; }
+
 hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom &g, void *workspace, unsigned seq, int k0, int k1, int kcap,
                                 int nparts_asm, float tol)
 {
     MidArgs A;
+    A.fault = g_mid_fault;
     A.gx = g.gx; A.gy = g.gy; A.bh = g.bh; A.G = g.G;
     A.k0 = k0; A.k1 = k1; A.kcap = kcap; A.nparts_asm = nparts_asm;
     A.full_state = (k0 != 0 || k1 != kcap) ? 1 : 0;

@@ -1410,6 +1410,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "persist") pl->use_persist = value != 0;
     else if (k == "persist_step") pl->persist_step = value;
     else if (k == "persist_p") pl->persist_p = value;
+    else if (k == "persist_fault") set_mid_fault(value);
     else if (k == "persist_max_g") pl->persist_max_g = value;
     else if (k == "fused_rows") set_fused_rows(value);
     else return OCTANE_E_INVALID;

@@ -112,3 +112,28 @@ def test_three_instruction_reciprocal_equals_the_division_everywhere(capi):
     print(f"PERSIST reciprocal self-test: {out[0]} patterns, {out[1]} mismatches" + (f" (e.g. 0x{out[2]:08x})" if out[1] else ""))
     assert out[0] == 0x7E000000 - 0x01000000
     assert out[1] == 0
+
+
+def test_a_missing_workgroup_makes_the_solve_give_up_instead_of_hanging(capi):
+    """The persistent solve needs all its workgroups resident; one that never shows up (a test hook makes the last workgroup
+    leave at once -- what a co-tenant process holding a CU would amount to) must not leave the others spinning: their waits give
+    up after 0.25 s, every workgroup leaves, the call returns an error, and the plan works again afterwards."""
+    import time
+    nx, ny = 640, 500
+    a, b = synth.lattice_scene(nx, ny, seed=5)
+    pl = capi.Plan(nx, ny, 1, capi.FlowParams(kiters=1, liters=1, cgiters=10))
+    try:
+        good = pl.run_host(a, b)
+        pl.tune("persist_fault", 1)
+        t0 = time.perf_counter()
+        with pytest.raises(capi.OctaneError) as e:
+            pl.run_host(a, b)
+        dt = time.perf_counter() - t0
+        pl.tune("persist_fault", 0)
+        print(f"PERSIST fault drill: error after {dt:.2f} s: {e.value}")
+        assert dt < 5.0 and "resident" in str(e.value)
+        again = pl.run_host(a, b)
+        assert np.array_equal(good[0], again[0]) and np.array_equal(good[1], again[1])
+    finally:
+        pl.tune("persist_fault", 0)
+        pl.close()
