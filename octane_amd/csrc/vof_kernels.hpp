@@ -102,6 +102,8 @@ void launch_gradient(hipStream_t s, const float *f, float *gx, float *gy, int w,
 void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpitch,
                      float *fine, int fw, int fh, int fpitch, float sf);
 void set_max_blocks(int n);
+void set_q_dma(int v);                   // the q-form kernel with LDS-DMA staging of p (pcg_fused_q_dma.hip)
+void launch_pcg_fused_q_dma(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 void set_q_diag(int v);                  // diagnostics: the q-form kernel's copy in pcg_fused_q_diag.hip instead of the production one
 void launch_pcg_fused_q_diag(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 int  pcg_fused_q_stamps(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol, unsigned long long *out16);   // diagnostic

@@ -255,6 +255,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_FUSED_ROWS")) set_fused_rows(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_FUSED_Q")) set_fused_q(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_FUSED_Q_MIN")) set_fused_q_min(atol(e));
+    if (const char *e = getenv("OCTANE_TUNE_Q_DMA")) set_q_dma(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_PERSIST")) pl->use_persist = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_STEP")) pl->persist_step = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_P")) pl->persist_p = atoi(e);
@@ -1407,6 +1408,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "fused") pl->use_fused = value != 0;
     else if (k == "fused_q") set_fused_q(value);
     else if (k == "q_diag") set_q_diag(value);
+    else if (k == "q_dma") set_q_dma(value);
     else if (k == "persist") pl->use_persist = value != 0;
     else if (k == "persist_step") pl->persist_step = value;
     else if (k == "persist_p") pl->persist_p = value;
