@@ -82,6 +82,9 @@ __device__ __forceinline__ void stencil_group(const float *s_u, const float *s_v
 }
 
 
+constexpr int kRingGroups = 100;          // 34 above, 34 below, 16 left, 16 right of a 128 x 16 tile
+constexpr int kRingOps = 9;
+
 // every float4 group the staging touches (2 rows above / below, one group left / right of the tile) lies inside the level
 __device__ __forceinline__ bool tile_is_interior(int tx0, int ty0, int w, int h)
 {
@@ -111,6 +114,41 @@ __device__ __forceinline__ void dma_p_tile(const float *pin_u, const float *pin_
     }
 }
 
+// LDS-DMA of the ring groups' operands: lane l of instruction i carries ring group 64 i + l (the ring group of thread 64 i + l in
+// phase 1); operand planes dealt over the four waves.  NOPS = 5 where the weights are the constant -1.
+__device__ __forceinline__ void dma_one(const float *g, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
+}
+template <int NOPS>
+__device__ __forceinline__ void dma_ring(const float *const (&plane)[kRingOps], const int (&shift)[kRingOps], float *s_ring, int tx0, int ty0,
+                                         int pitch, int lane, int wv)
+{
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned base = (unsigned)(unsigned long)(lds_float *)s_ring;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int j = 64 * i + lane;                       // ring group
+        int gx, gy;
+        if (j < 34) { gx = j - 1; gy = -1; }
+        else if (j < 68) { gx = j - 35; gy = kQTY; }
+        else if (j < 84) { gx = -1; gy = j - 68; }
+        else { gx = kTileX / 4; gy = j - 84; }
+        if (j < kRingGroups) {
+            const long o = (long)(ty0 + gy) * pitch + tx0 + 4 * gx;
+#pragma unroll
+            for (int op = 0; op < NOPS; op++) {
+                if ((op & 3) == wv) {                      // uniform: this wave's operands
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)((op * kRingGroups + 64 * i) * 16));
+                    dma_one(plane[op] + o + shift[op], dst);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 template <bool UNITW>
@@ -124,6 +162,9 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int
     constexpr int NSZ = (TY + 2) * kQCols;
     __shared__ __attribute__((aligned(16))) float s_nu2[2 * NSZ], s_nv2[2 * NSZ];
     __shared__ double s_red[4 * kPartKinds];
+    // operands of the 100 ring groups of a tile (r_u r_v a1 a4 a2 wx wy, wy of the row above, wx of the group to the west), fetched
+    // by LDS-DMA together with the p tile: [operand][ring group]
+    __shared__ __attribute__((aligned(16))) float s_ring[kRingOps * kRingGroups * 4];
     const int tid = threadIdx.x;
     const bool first = (k == 0);
 
@@ -190,11 +231,17 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int
     // first tile here, for every later one at the start of the previous tile's phase 2 (s_ou / s_ov are free then: phase 1 has
     // read them and the barrier before phase 2 has been passed).  Nothing else is loaded between the DMA and the wait for it at
     // the tile's phase 0, so the wait does not hold anything else up.  Border tiles stage through registers as before.
+    // ring operands: r_u r_v a1 a4 a2 | wx wy wy(row above) wx(group to the west); the last four only where the weights vary
+    const float *const ring_plane[kRingOps] = {rin_u, rin_v, L.a1, L.a4, L.a2, L.wx, L.wy, L.wy, L.wx};
+    const int ring_shift[kRingOps] = {0, 0, 0, 0, 0, 0, 0, -pitch, -4};
     bool dma_cur = false;
     if (!first && tr.first < tr.end) {
         const int ftx0 = (tr.first % tiles_x) * TX, fty0 = y0 + (tr.first / tiles_x) * TY;
         dma_cur = tile_is_interior(ftx0, fty0, w, h);
-        if (dma_cur) dma_p_tile(pin_u, pin_v, s_ou, s_ov, ftx0, fty0, pitch, lane, wv);
+        if (dma_cur) {
+            dma_p_tile(pin_u, pin_v, s_ou, s_ov, ftx0, fty0, pitch, lane, wv);
+            dma_ring<UNITW ? 5 : kRingOps>(ring_plane, ring_shift, s_ring, ftx0, fty0, pitch, lane, wv);
+        }
     }
     for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1) {
         float *const s_nu = s_nu2 + parity * NSZ, *const s_nv = s_nv2 + parity * NSZ;
@@ -271,7 +318,22 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int
 #pragma unroll
                 for (int e = 0; e < 4; e++) { cr.a1[e] = 1.f; cr.a4[e] = 1.f; cr.a2[e] = 0.f; cr.wx[e] = 0.f; cr.wy[e] = 0.f; cr.wys[e] = 0.f; }
                 cr.wxw = 0.f;
-                if (valid) {
+                if (dma_cur && !first) {                           // an interior tile: every ring group is valid, its operands are in LDS
+                    if (tid < kRingGroups) {
+                        *(float4 *)ru = ld4(&s_ring[(0 * kRingGroups + tid) * 4]); *(float4 *)rv = ld4(&s_ring[(1 * kRingGroups + tid) * 4]);
+                        *(float4 *)cr.a1 = ld4(&s_ring[(2 * kRingGroups + tid) * 4]); *(float4 *)cr.a4 = ld4(&s_ring[(3 * kRingGroups + tid) * 4]);
+                        *(float4 *)cr.a2 = ld4(&s_ring[(4 * kRingGroups + tid) * 4]);
+                        if (UNITW) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { cr.wx[e] = -1.f; cr.wy[e] = -1.f; cr.wys[e] = -1.f; }
+                            cr.wxw = -1.f;
+                        } else {
+                            *(float4 *)cr.wx = ld4(&s_ring[(5 * kRingGroups + tid) * 4]); *(float4 *)cr.wy = ld4(&s_ring[(6 * kRingGroups + tid) * 4]);
+                            *(float4 *)cr.wys = ld4(&s_ring[(7 * kRingGroups + tid) * 4]);
+                            cr.wxw = s_ring[(8 * kRingGroups + tid) * 4 + 3];
+                        }
+                    }
+                } else if (valid) {
                     const unsigned o = (unsigned)(y * pitch + x0) * 4u;
                     const int kr = first ? 0 : ko;
                     if (BANDED && y < y0) { *(float4 *)ru = ld4(at(L.rup_u[kr], o)); *(float4 *)rv = ld4(at(L.rup_v[kr], o)); }
@@ -346,7 +408,10 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int
             if (!first && tn < tr.end) {
                 const int ntx0 = (tn % tiles_x) * TX, nty0 = y0 + (tn / tiles_x) * TY;
                 dma_next = tile_is_interior(ntx0, nty0, w, h);
-                if (dma_next) dma_p_tile(pin_u, pin_v, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);
+                if (dma_next) {
+                    dma_p_tile(pin_u, pin_v, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);
+                    dma_ring<UNITW ? 5 : kRingOps>(ring_plane, ring_shift, s_ring, ntx0, nty0, pitch, lane, wv);
+                }
             }
             dma_cur = dma_next;
         }
