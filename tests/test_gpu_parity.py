@@ -506,3 +506,28 @@ def test_q_recomputing_form_equals_stored_q_form(capi, nx, ny):
     # element by element the two forms compute the same bits; their persistent grids differ, hence the grouping of the
     # fp64 partial sums, hence -- rarely -- the last bit of an alpha or beta
     assert d < 1e-6, f"{d:.3e}, {nbad} pixels differ"
+
+
+@pytest.mark.parametrize("nx,ny,prm", [
+    (2300, 1900, dict(kiters=1, liters=1, cgiters=7)),      # ragged tiles right and below: border tiles stage through registers
+    (2503, 1699, dict(kiters=2, liters=1, cgiters=11)),     # a width that is no multiple of 4
+    (2560, 2048, dict(kiters=1, liters=2, cgiters=6)),      # whole tiles only
+])
+def test_lds_dma_form_of_the_q_recomputing_kernel_is_bit_identical(capi, nx, ny, prm):
+    """Whole levels run the q-recomputing kernel with the next tile's p and ring operands fetched by LDS-DMA during phase 2
+    (pcg_fused_q_dma.hip; the default).  Same arithmetic, same tile walk, same partial sums as the register-staged kernel
+    (tune("q_dma", 0)): the flow has to be the same bits, in all three GNC steps (unit and varying weights)."""
+    a, b = synth.lattice_scene(nx, ny, seed=nx - ny)
+    outs = {}
+    for dma in (0, 1):
+        pl = capi.Plan(nx, ny, 1, capi.FlowParams(**prm))
+        try:
+            pl.tune("q_dma", dma)
+            outs[dma] = pl.run_host(a, b)
+            its = pl.last_iterations()
+        finally:
+            pl.tune("q_dma", 1)
+            pl.close()
+    ndiff = int((outs[0][0] != outs[1][0]).sum() + (outs[0][1] != outs[1][1]).sum())
+    print(f"PARITY case=q_dma {nx}x{ny} {prm}: LDS-DMA vs register staging: {ndiff} values differ ({its} iterations)")
+    assert np.isfinite(outs[1][0]).all() and ndiff == 0
