@@ -42,7 +42,7 @@ PASS_B_BYTES_PER_PIXEL = 40 + 16   # reads x(2) r(2) p(2) q(2) a1 a4, writes x(2
 # launch only, which then also reads x and the p before last (16) and writes x (8): 92.  Mean 80 (84 with OCTANE_TUNE_DEFER_X=0).
 FUSED_BYTES_PER_PIXEL = 80
 FUSED_BYTES_PER_PIXEL_GNC0 = 72        # first GNC step: wx == wy == -1, not read
-FUSED_Q_BYTES_PER_PIXEL = 64           # k_pcg_fused_q (levels of >= 3 * 2^20 pixels): q = A p is formed again, neither written nor read
+FUSED_Q_BYTES_PER_PIXEL = 64           # k_pcg_fused_q_dma / k_pcg_fused_q (levels of >= 3 * 2^20 pixels): q = A p is formed again, neither written nor read
 FUSED_Q_BYTES_PER_PIXEL_GNC0 = 56
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 TILED_SEED = 20240615              # (with 20240616 the 85 x 85 coarsest level of a 10848^2 / 8-level pyramid runs away at R1's iteration counts)
@@ -70,9 +70,15 @@ def device_state(torch, dev):
     torch.cuda.empty_cache()
     where = None
     try:    # which GPU of which node this is (best effort: the pool's boxes differ, see above)
-        import subprocess
-        txt = subprocess.run(["rocm-smi", "--showbus", "--showproductname", "--showmemorypartition", "--showcomputepartition"],
-                             capture_output=True, text=True, timeout=20).stdout
+        import shutil, subprocess
+        smi = shutil.which("rocm-smi")
+        # under rocprofv3 every child inherits the profiler's preload (which initialises the GPU) and rocm-smi's `#!/usr/bin/env python3`
+        # is then an exec from a GPU-initialised process, which this pool's boxes refuse: no query there, and no env hop anywhere
+        if smi is None or "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+            raise RuntimeError("no rocm-smi query under a profiler")
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+        txt = subprocess.run([sys.executable, os.path.realpath(smi), "--showbus", "--showproductname", "--showmemorypartition", "--showcomputepartition"],
+                             capture_output=True, text=True, timeout=20, env=env).stdout
         keep = [ln.split(":", 1)[1].strip().replace("\t", " ") for ln in txt.splitlines()
                 if ln.startswith("GPU[0]") and any(k in ln for k in ("PCI Bus", "Node ID", "GUID", "Partition"))]
         where = "; ".join(keep) or None
@@ -505,7 +511,8 @@ def main():
             b_all, b_gnc0 = ((FUSED_Q_BYTES_PER_PIXEL, FUSED_Q_BYTES_PER_PIXEL_GNC0) if qform
                              else (FUSED_BYTES_PER_PIXEL, FUSED_BYTES_PER_PIXEL_GNC0))
             bpp = ((b_gnc0 + 2 * b_all) / 3.0 if unit_w else b_all) + imm
-            dom, dms = ("k_pcg_fused_q" if qform else "k_pcg_fused"), a_ms
+            qname = "k_pcg_fused_q_dma" if os.environ.get("OCTANE_TUNE_Q_DMA", "1") != "0" else "k_pcg_fused_q"   # LDS-DMA staging is the default
+            dom, dms = (qname if qform else "k_pcg_fused"), a_ms
             iter_ms = a_ms
         else:
             bpp_a = (PASS_A_BYTES_PER_PIXEL_GNC0 + 2 * PASS_A_BYTES_PER_PIXEL) / 3.0 if unit_w else PASS_A_BYTES_PER_PIXEL

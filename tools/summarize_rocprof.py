@@ -24,7 +24,7 @@ def norm(short):
     return short
 
 
-def pmc_section(d, size, kiters, per_level, two_pass_levels, qform=False):
+def pmc_section(d, size, kiters, per_level, two_pass_levels, qform=False, qname="k_pcg_fused_q"):
     """HBM traffic of the finest level from the FETCH_SIZE / WRITE_SIZE passes (sub-directories fetch/ and
     write/ of the profile directory).  Units and the gfx950 correction follow MI355X_MICROARCH.md 'HBM':
     both counters are in KiB; FETCH_SIZE reads exactly half the bytes of a wide (16 B/lane) coalesced
@@ -83,7 +83,7 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels, qform=False):
         wr = vals[(k, "WRITE_SIZE")] * 1024
         ar, aw = alg[k][0] * px, alg[k][1] * px
         traffic[k] = {"read_bytes": round(rd), "write_bytes": round(wr), "size": size,
-                      "kernel": "k_pcg_fused_q" if (k == "k_pcg_fused" and qform) else k,
+                      "kernel": qname if (k == "k_pcg_fused" and qform) else k,
                       "how": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 wide-load correction) and --pmc WRITE_SIZE, separate passes, "
                              "mean over the finest-level launches of bench.py"}
         out.append(f"| {k} | {rd / 1e6:.0f} | {ar / 1e6:.0f} | {wr / 1e6:.0f} | {aw / 1e6:.0f} | {(rd + wr) / (ar + aw):.3f} |")
@@ -108,13 +108,15 @@ def main():
     rows = defaultdict(list)
     meta = {}
     qform = False
+    qname = "k_pcg_fused_q"
     with open(trace) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
             if "octane::" not in name:
                 continue
             short = name.split("octane::")[1].split("(")[0]
-            qform = qform or short.startswith("k_pcg_fused_q")
+            if short.startswith("k_pcg_fused_q"):
+                qform, qname = True, short.split("<")[0]
             short = norm(short)
             m = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Workgroup_Size_X"])
             rows[short].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"]), m))
@@ -215,7 +217,7 @@ def main():
                   f"**{56 * px / fin['k_pcg_pass_b']:.0f} GB/s** ({56 * px / fin['k_pcg_pass_b'] / 80:.1f} % of 8 TB/s)",
                   f"* one PCG iteration at SURVEY 8(d)'s 116 B/px: {116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']):.0f} GB/s "
                   f"({116 * px / (fin['k_pcg_pass_a'] + fin['k_pcg_pass_b']) / 80:.1f} % of 8 TB/s)"]
-    lines += pmc_section(d, size, kiters, per_level, two_pass_levels, qform)
+    lines += pmc_section(d, size, kiters, per_level, two_pass_levels, qform, qname)
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
