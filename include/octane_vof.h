@@ -134,6 +134,10 @@ int octane_vof_plan_probe_stamps(octane_vof_plan *plan, int level, int even, int
  * IEEE division on every positive normal float whose reciprocal is normal: out3 = {patterns compared, mismatches, one
  * mismatching bit pattern}.  No reference counterpart (the reference divides, ref .cu:141-149). */
 int octane_selftest_rcp(int device, unsigned long long *out3);
+/* Diagnostic: cycles per seam of an iteration of the persistent mid-level solve (stamped build, octane_vof_tune "persist_diag"),
+ * summed over workgroups and iterations since the last call: 32 values, [0..15] interior sub-domains, [16..31] the predicated ones,
+ * [14] / [30] = workgroups x iterations.  Clears the counters. */
+int octane_vof_mid_stamps(int device, unsigned long long *out32);
 /* Diagnostic: time `iterations` (>= 2) PCG iterations of pyramid level `level` (0 = coarsest) in isolation, on
  * whatever the plan's planes hold (the stop test is held open, values are irrelevant, the planes are clobbered).
  * With the one-kernel iteration (the default) its time comes back in *pass_a_ms and *pass_b_ms is 0. */

@@ -51,6 +51,16 @@ __device__ __forceinline__ void block_sum_multi(const double (&v)[N], double *sc
         out[j] = t;
     }
 }
+// 1 / x, correctly rounded for every normal x whose reciprocal is normal (checked against the division on all of them by
+// octane_selftest_rcp (pcg_persist.hip) / tests/test_gpu_persist.py): the hardware estimate (1 ulp) and one Newton step in fused arithmetic.
+// Three instructions instead of the eleven of an IEEE division; the diagonal of the operator is >= 1, far inside that range.
+__device__ __forceinline__ float rcp_exact(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
 template <int N, int NT>
 __device__ __forceinline__ void fold_band_partials_multi(const double *const *blocks, int first_off, int kind_stride, int n,
                                                          int nbands, double *scratch /* >= (NT / 64) * N */, double (&out)[N])

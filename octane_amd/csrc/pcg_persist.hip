@@ -39,6 +39,15 @@
 
 namespace octane {
 
+// Diagnostic build (pcg_persist_diag.hip includes this file with MID_DIAG defined and the entry points renamed): thread 0 of
+// every workgroup reads the shader clock at the seams of an iteration and adds up where its time goes (tools/probe_mid_stamps.py).
+#ifdef MID_DIAG
+__device__ unsigned long long g_mid_stamps[32];     // [0..15] sub-domains on the fast path, [16..31] the others
+#define MID_STAMP(i) do { if (tid == 0) { const unsigned long long now_ = clock64(); s_stamp[i] += now_ - s_stamp[15]; s_stamp[15] = now_; } } while (0)
+#else
+#define MID_STAMP(i) do { } while (0)
+#endif
+
 constexpr int kMidT = 512;              // threads per workgroup: 8 waves, two per SIMD, up to 256 VGPRs each
 constexpr int kMidW = 64;               // columns of a sub-domain: one wavefront per row
 constexpr int kMidRG = kMidT / kMidW;   // rows one slot of all threads covers
@@ -94,16 +103,7 @@ __device__ __forceinline__ bool mid_keep_waiting(const MidArgs &A, unsigned &spi
     return true;
 }
 
-// 1 / x, correctly rounded for every normal x whose reciprocal is normal (checked against the division on all of them by
-// octane_selftest_rcp / tests/test_gpu_persist.py): the hardware estimate (1 ulp) and one Newton step in fused arithmetic.
-// Three instructions instead of the eleven of an IEEE division; the diagonal of the operator is >= 1, far inside that range.
-__device__ __forceinline__ float rcp_exact(float x)
-{
-    float r = __builtin_amdgcn_rcpf(x);
-    const float e = __builtin_fmaf(-x, r, 1.0f);
-    return __builtin_fmaf(e, r, r);
-}
-
+#ifndef MID_DIAG
 __global__ void k_selftest_rcp(unsigned long long *out)     // out[0] = patterns compared, out[1] = mismatches, out[2] = first mismatch
 {
     unsigned long long n = 0, bad = 0, firstbad = 0;
@@ -131,6 +131,7 @@ int pcg_selftest_rcp(hipStream_t s, unsigned long long *host3)
     (void)hipFree(d);
     return rc;
 }
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));     // (u, v) of one pixel: one packed instruction per pair of operations
 __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
@@ -146,6 +147,10 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
     float *s_acc = reinterpret_cast<float *>(s_edge + 4 * 2 * kMidEdge);   // every thread's seven partial sums, [kind][thread]
     double *s_tot = reinterpret_cast<double *>(s_acc + kPartKinds * kMidT);   // the seven folded sums of the previous iteration (+ scratch)
     int *s_flag = reinterpret_cast<int *>(s_tot + 32);     // raised by a lane whose wait was abandoned
+#ifdef MID_DIAG
+    unsigned long long *s_stamp = reinterpret_cast<unsigned long long *>(s_flag + 4);
+    if (threadIdx.x == 0) { for (int i = 0; i < 15; i++) s_stamp[i] = 0ull; }
+#endif
 
     const int tid = threadIdx.x, c_ = tid & (kMidW - 1), rg_ = tid >> 6, wv = tid >> 6, lane = tid & 63;
     const int w = L.w, h = L.h, pitch = L.pitch;
@@ -249,6 +254,9 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         asm volatile("" : "+v"(c), "+v"(rg));
         const bool colok = c < sw;
         const bool first = (k == 0);
+#ifdef MID_DIAG
+        if (tid == 0) s_stamp[15] = clock64();
+#endif
         // ---- wait for what iteration k - 1 left: the G x 7 partial sums (wave j < 7 sweeps sum j: lane l takes workgroups l, l + 64,
         // l + 128, l + 192) and this thread's ring pixel.  All loads of a pass are issued before the first tag is looked at.
         float nalpha = 0.f, beta = 0.f, rz_new, rr;
@@ -290,6 +298,10 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
                 if (ok) break;
                 if (!mid_keep_waiting(A, spins, t0)) { *s_flag = 1; break; }
             }
+            MID_STAMP(0);                                    // wave 0's wait for the sums (and its ring pixels) of iteration k - 1
+#ifdef MID_DIAG
+            if (tid == 0) s_stamp[7] += spins;               // failed polling rounds of thread 0
+#endif
             if (sweeper) {
                 double v = 0.;
 #pragma unroll
@@ -301,6 +313,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
                 if (lane == 0) s_tot[wv] = v;
             }
             __syncthreads();
+            MID_STAMP(1);                                    // ... until the slowest wave has them, folded
             if (*s_flag) { aborted = true; break; }
             const double rzd = s_tot[0], rrd = s_tot[1], pq = s_tot[2], qz = s_tot[3], qmq = s_tot[4], rq = s_tot[5], qq = s_tot[6];
             alpha = rz_prev / (float)pq;                   // ref .cu:1169
@@ -362,7 +375,9 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         }
         if (fast) { MID_UPDATE_LOOP(true) } else { MID_UPDATE_LOOP(false) }
 #undef MID_UPDATE_LOOP
+        MID_STAMP(2);                                        // scalars, ring pixel, update loop
         __syncthreads();
+        MID_STAMP(3);
         // ---- q = A p and the sums that carry q (the reciprocals of the diagonal and z are formed again rather than kept across the barrier)
 #pragma unroll
         for (int s = 0; s < P; s++) asm volatile("" : "+v"(a1[s]), "+v"(a2[s]), "+v"(a4[s]), "+v"(wS[s]), "+v"(wW[s]), "+v"(wE[s]), "+v"(wN[s]));
@@ -404,11 +419,13 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         }
         if (fast) { MID_STENCIL_LOOP(true) } else { MID_STENCIL_LOOP(false) }
 #undef MID_STENCIL_LOOP
+        MID_STAMP(4);                                        // stencil loop
         // ---- the workgroup's seven sums: every thread's subtotal through LDS, then wave j adds up sum j over the 512 threads in a
         // fixed order, in double
 #pragma unroll
         for (int j = 0; j < kPartKinds; j++) s_acc[j * kMidT + tid] = acc[j].x + acc[j].y;
         __syncthreads();                                     // completes s_acc and s_edge
+        MID_STAMP(5);
         const unsigned tag = A.tag0 + (unsigned)k + 1u;
         if (wv < kPartKinds) {
             double v = 0.;
@@ -437,12 +454,19 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
                 st_granule(gat(A.edges, eo + 5u * kMidEdge * 8u), tag, __float_as_uint(ep.y));
             }
         }
+        MID_STAMP(6);                                        // workgroup sums and edges published
+#ifdef MID_DIAG
+        if (tid == 0) s_stamp[14] += 1;
+#endif
         rz_prev = rz_new;
         const bool last_of_launch = (k + 1 >= A.k1) && (A.k1 < A.kcap);   // stepped form: the next launch folds these sums
         if (last_of_launch) { k++; break; }
     }
     if (aborted) return;
     __syncthreads();
+#ifdef MID_DIAG
+    if (tid == 0) { for (int i = 0; i < 15; i++) atomicAdd(&g_mid_stamps[(fast ? 0 : 16) + i], s_stamp[i]); }
+#endif
     // ---- the end of the solve: u += dx, v += dy (ref .cu:1185-1195); the stepped form only carries its scalars on
     if (stopped) {
         if (k > 0) {
@@ -471,9 +495,10 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
 static size_t mid_lds_bytes(int P)
 {
     const int rows = P * kMidRG;
-    return (size_t)(2 * (rows + 2) * kMidLP + 2 * rows * kMidW + 2 * 4 * 2 * kMidEdge + kPartKinds * kMidT) * sizeof(float) + 32 * sizeof(double) + 16;
+    return (size_t)(2 * (rows + 2) * kMidLP + 2 * rows * kMidW + 2 * 4 * 2 * kMidEdge + kPartKinds * kMidT) * sizeof(float) + 32 * sizeof(double) + 16 + 16 * sizeof(unsigned long long);
 }
 
+#ifndef MID_DIAG
 // Sub-domain grid of a w x h level on a device with `ncu` CUs: 64-column strips, as many rows of sub-domains as keep every
 // workgroup on a CU of its own, P (slots of 8 rows) from {4, 6, .. 16}.  0 = the level does not fit.
 int pcg_mid_config(int w, int h, int ncu, int force_p, MidGeom *g)
@@ -499,6 +524,8 @@ int pcg_mid_config(int w, int h, int ncu, int force_p, MidGeom *g)
     return 0;
 }
 
+#endif
+
 void pcg_mid_configure()
 {
 #define MID_ATTR(P, U) (void)hipFuncSetAttribute((const void *)k_pcg_solve_mid<P, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds_bytes(P))
@@ -508,15 +535,19 @@ void pcg_mid_configure()
 #undef MID_ATTR
 }
 
+#ifndef MID_DIAG
 size_t pcg_mid_workspace_bytes()
 {
     // [abort word] [partial sums: 2 parities x 14 granules x G] [edge pixels: G x 2 parities x 4 sides x 6 arrays x 128 granules]
     return 256 + (size_t)2 * 2 * kPartKinds * kMidMaxG * 8 + (size_t)kMidMaxG * 2 * 4 * 6 * kMidEdge * 8;
 }
 
+#endif
 // Iterations [k0, k1) of one solve; k0 = 0 and k1 = cgiters is the whole solve in one launch (plus the flow update).
 static int g_mid_fault = 0;
+#ifndef MID_DIAG
 void set_mid_fault(int v) { g_mid_fault = v != 0; }
+#endif
 
 hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom &g, void *workspace, unsigned seq, int k0, int k1, int kcap,
                                 int nparts_asm, float tol)
@@ -548,5 +579,18 @@ hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom
 #undef MID_LAUNCH
     return hipGetLastError();
 }
+
+#ifdef MID_DIAG
+// read (and clear) the stamps: [0..6] cycles per seam summed over the workgroups' thread 0 and the iterations, [7] failed polling
+// rounds of thread 0, [14] iterations x workgroups; the same at [16..] for the sub-domains that touch a border of the level or are
+// not full (the predicated path)
+int pcg_mid_stamps(hipStream_t s, unsigned long long *out32)
+{
+    static const unsigned long long zero[32] = {0};
+    if (hipMemcpyFromSymbolAsync(out32, HIP_SYMBOL(g_mid_stamps), sizeof zero, 0, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_mid_stamps), zero, sizeof zero, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace octane

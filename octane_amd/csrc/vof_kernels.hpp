@@ -150,6 +150,12 @@ void pcg_mid_configure();
 size_t pcg_mid_workspace_bytes();
 hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom &g, void *workspace, unsigned seq, int k0, int k1, int kcap,
                                 int nparts_asm, float tol);
+// the stamped diagnostic build of the same source (pcg_persist_diag.hip)
+void pcg_mid_configure_diag();
+hipError_t launch_pcg_solve_mid_diag(hipStream_t s, const LevelPtrs &L, const MidGeom &g, void *workspace, unsigned seq, int k0, int k1, int kcap,
+                                int nparts_asm, float tol);
+int pcg_mid_stamps(hipStream_t s, unsigned long long *out16);
+
 int  pcg_selftest_rcp(hipStream_t s, unsigned long long *host3);
 bool pcg_small_applicable(int w, int h);
 void pcg_small_configure();

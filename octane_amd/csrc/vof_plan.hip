@@ -272,6 +272,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     }
     pcg_small_configure();
     pcg_mid_configure();
+    pcg_mid_configure_diag();
     set_grid_multiple(pl->xcd_bands == 1 ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
 
@@ -558,6 +559,7 @@ int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur
 // for the event the previous one recorded (on whatever stream that was) and records the next.  Everything else overlaps as
 // before.  (Another PROCESS on the same GPU is not covered: the kernel's barriers are bounded and abort the solve.)
 static std::mutex g_persist_mu;
+static int g_persist_diag = 0;      // octane_vof_tune(plan, "persist_diag", 1): the stamped build of the persistent solve (diagnostic)
 static hipEvent_t g_persist_ev[64] = {nullptr};
 static int persist_launch(octane_vof_plan *pl, hipStream_t s, const LevelPtrs &L, const MidGeom &mg, unsigned seq, int k0, int k1, int kcap, int nparts_asm)
 {
@@ -568,7 +570,7 @@ static int persist_launch(octane_vof_plan *pl, hipStream_t s, const LevelPtrs &L
     } else if (hipStreamWaitEvent(s, g_persist_ev[d], 0) != hipSuccess) {
         g_last_error = "persistent solve: hipStreamWaitEvent failed"; return OCTANE_E_HIP;
     }
-    hipError_t e = launch_pcg_solve_mid(s, L, mg, pl->d_mid, seq, k0, k1, kcap, nparts_asm, pl->tol);
+    hipError_t e = (g_persist_diag ? launch_pcg_solve_mid_diag : launch_pcg_solve_mid)(s, L, mg, pl->d_mid, seq, k0, k1, kcap, nparts_asm, pl->tol);
     if (e == hipSuccess) e = hipEventRecord(g_persist_ev[d], s);
     if (e != hipSuccess) { g_last_error = std::string("persistent solve: ") + hipGetErrorString(e); return OCTANE_E_HIP; }
     return OCTANE_OK;
@@ -1384,6 +1386,17 @@ extern "C" int octane_vof_plan_probe_stamps(octane_vof_plan *pl, int level, int 
 
 // Self-test: the three-instruction reciprocal of pcg_persist.hip against the IEEE division on every positive normal float whose
 // reciprocal is normal.  out3 = {patterns compared, mismatches, a mismatching bit pattern}.
+// Diagnostic: where thread 0 of the persistent solve's workgroups spent its shader-clock cycles since the last call (seams of an
+// iteration, pcg_persist.hip MID_STAMP; only launches made under octane_vof_tune(plan, "persist_diag", 1) count): 32 values, [0..15] the
+// sub-domains on the fast path, [16..31] the predicated ones; [14] / [30] = workgroups x iterations.  Clears the counters.
+extern "C" int octane_vof_mid_stamps(int device, unsigned long long *out16)
+{
+    if (!out16) { g_last_error = "octane_vof_mid_stamps: null output"; return OCTANE_E_INVALID; }
+    if (hipSetDevice(device) != hipSuccess) { g_last_error = "octane_vof_mid_stamps: no such device"; return OCTANE_E_HIP; }
+    if (hipDeviceSynchronize() != hipSuccess) return OCTANE_E_HIP;
+    return pcg_mid_stamps(nullptr, out16) == 0 ? OCTANE_OK : OCTANE_E_HIP;
+}
+
 extern "C" int octane_selftest_rcp(int device, unsigned long long *out3)
 {
     if (!out3) return OCTANE_E_INVALID;
@@ -1413,6 +1426,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "persist_step") pl->persist_step = value;
     else if (k == "persist_p") pl->persist_p = value;
     else if (k == "persist_fault") set_mid_fault(value);
+    else if (k == "persist_diag") g_persist_diag = value != 0;
     else if (k == "persist_max_g") pl->persist_max_g = value;
     else if (k == "fused_rows") set_fused_rows(value);
     else return OCTANE_E_INVALID;
