@@ -5,6 +5,22 @@
 // wait for all of them, write LDS, barrier -- a phase that moves 16 of the tile's 52-76 B/pixel and overlaps with nothing.
 #include "vof_kernels.hpp"
 #include "device_util.hpp"
+// Compile-time switches of this kernel's text (tools/sweep_variants.sh builds and times all 32 combinations with both scheduling
+// strategies; the kernel's speed moves by +-5 % with how the text reaches the register allocator, so the choice is measured, not
+// argued).  Sweep of round 2, ms per finest-level launch at 5000^2 / 2000^2 on one box: neither border-free phase 0.318 / 0.0619,
+// phase 1 only 0.298 / 0.0611, both 0.2952 / 0.0607, both + rotated columns 0.2960 / 0.0578 (the defaults below, max-ilp scheduling).
+#ifndef Q_P1
+#define Q_P1 1          // border-free form of phase 1 for tiles strictly inside the frame
+#endif
+#ifndef Q_P2
+#define Q_P2 1          // the same for phase 2
+#endif
+#ifndef Q_LB
+#define Q_LB 1          // second launch bound (minimum waves per SIMD); tests/test_capi_cpu.py checks the built kernel's occupancy instead
+#endif
+#ifndef Q_ROT
+#define Q_ROT 1         // rotate the tile columns by the round number when the column count divides the grid
+#endif
 
 namespace octane {
 namespace {
@@ -51,7 +67,10 @@ constexpr int kQOff = 8;                    // LDS column of the tile's first pi
 struct QCoef { float a1[4], a2[4], a4[4], wx[4], wy[4], wys[4]; float wxw; };
 
 // the 5-point operator on one float4 group at frame position (x0, y), from an LDS tile whose row `lrow` / column `lcol`
-// hold the group's own pixels (same arithmetic, in the same order, as every other form of A p in this file)
+// hold the group's own pixels (same arithmetic, in the same order, as every other form of A p in this file).
+// INTERIOR: the group and its four neighbours lie strictly inside the frame -- no merged border weight, no missing neighbour:
+// the same sums without the 21 compare / select instructions per pixel that only the frame's outermost pixels need.
+template <bool INTERIOR>
 __device__ __forceinline__ void stencil_group(const float *s_u, const float *s_v, int lrow, int lcol, int x0, int y, int w, int h,
                                               const QCoef &c, float (&qu)[4], float (&qv)[4])
 {
@@ -67,17 +86,17 @@ __device__ __forceinline__ void stencil_group(const float *s_u, const float *s_v
         const float pwu = (e == 0) ? uwest : cu[(e + 3) & 3], pwv = (e == 0) ? vwest : cv[(e + 3) & 3];
         const float peu = (e == 3) ? ueast : cu[(e + 1) & 3], pev = (e == 3) ? veast : cv[(e + 1) & 3];
         const float a5 = (e == 0) ? c.wxw : c.wx[(e + 3) & 3];
-        const float wS = (y == h - 1) ? c.wys[e] + c.wy[e] : c.wys[e];
-        const float wW = (i == w - 1) ? a5 + c.wx[e] : a5;
-        const float wE = (i == 0) ? c.wx[e] + c.wx[e] : c.wx[e];
-        const float wN = (y == 0) ? c.wy[e] + c.wy[e] : c.wy[e];
+        const float wS = (!INTERIOR && y == h - 1) ? c.wys[e] + c.wy[e] : c.wys[e];
+        const float wW = (!INTERIOR && i == w - 1) ? a5 + c.wx[e] : a5;
+        const float wE = (!INTERIOR && i == 0) ? c.wx[e] + c.wx[e] : c.wx[e];
+        const float wN = (!INTERIOR && y == 0) ? c.wy[e] + c.wy[e] : c.wy[e];
         float sumu = 0.f, sumv = 0.f;
-        if (y > 0) { sumu += wS * su[e]; sumv += wS * sv[e]; }
-        if (i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
+        if (INTERIOR || y > 0) { sumu += wS * su[e]; sumv += wS * sv[e]; }
+        if (INTERIOR || i > 0) { sumu += wW * pwu; sumv += wW * pwv; }
         sumu += c.a1[e] * cu[e]; sumv += c.a2[e] * cu[e];
         sumu += c.a2[e] * cv[e]; sumv += c.a4[e] * cv[e];
-        if (i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
-        if (y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
+        if (INTERIOR || i < w - 1) { sumu += wE * peu; sumv += wE * pev; }
+        if (INTERIOR || y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
         qu[e] = sumu; qv[e] = sumv;
     }
 }
@@ -89,7 +108,9 @@ constexpr int kRingOps = 9;
 // every float4 group the staging touches (2 rows above / below, one group left / right of the tile) lies inside the level
 __device__ __forceinline__ bool tile_is_interior(int tx0, int ty0, int w, int h)
 {
-    return tx0 >= 4 && tx0 + kTileX + 4 <= w && ty0 >= 2 && ty0 + kQTY + 2 <= h;
+    // (strictly inside on the right: the last pixel of the ring group east of the tile is not the frame's last column, so no pixel the
+    // tile touches -- own or ring -- has a merged border weight or a missing neighbour: stencil_group<true>)
+    return tx0 >= 4 && tx0 + kTileX + 4 < w && ty0 >= 2 && ty0 + kQTY + 2 <= h;
 }
 
 // LDS-DMA of the staged p tile: one instruction per staged row and component, lanes 0..33 <-> the row's 34 float4 groups (544
@@ -152,8 +173,12 @@ __device__ __forceinline__ void dma_ring(const float *const (&plane)[kRingOps], 
 
 }  // namespace
 
+// Two waves per SIMD (two workgroups per CU) is the design point.  The register allocator does not know that: one experimental build
+// came out with 256 VGPRs + 2 AGPRs, ran at one workgroup per CU (0.377 instead of 0.30 ms per launch), and nothing but the
+// "Occupancy" line of the assembly said so.  The Makefile keeps the compiler's resource remarks of this file
+// (pcg_fused_q_dma.usage.txt) and tests/test_capi_cpu.py fails when the kernel's occupancy is not 2.
 template <bool UNITW>
-__global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int nparts_prev, float tol)
+__global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int k, int nparts_prev, float tol)
 {
     constexpr int TY = kQTY, TX = kTileX;
     constexpr bool BANDED = false;                         // whole levels only
@@ -226,7 +251,12 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int
     double acc_pq = 0., acc_qz = 0., acc_qmq = 0., acc_rq = 0., acc_qq = 0., acc_rz = 0., acc_rr = 0.;
 
     const ItemRange tr = item_range_walk(ntiles, L.xcd_bands);
-    int parity = 0;
+    // When the number of tile columns divides the grid (2000 or 2048 pixels wide: 16 columns, 512 workgroups) the round-robin walk
+    // gives a workgroup the same column in every round, and the 1 / 8 of the workgroups that own the frame's first and last column
+    // -- the tiles that stage through registers and run the bordered operator -- finish last in every launch.  The columns of a
+    // tile row are then rotated by the round number (a permutation within the row, so every tile is still done exactly once).
+    const bool rotate = Q_ROT && tr.step == (int)gridDim.x && tr.step % tiles_x == 0 && tiles_x > 1;
+    int parity = 0, round = 0;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // p_{k-1} of an interior tile (every staged float4 group inside the level) comes by LDS-DMA, issued one phase ahead: for the
     // first tile here, for every later one at the start of the previous tile's phase 2 (s_ou / s_ov are free then: phase 1 has
@@ -237,16 +267,16 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int
     const int ring_shift[kRingOps] = {0, 0, 0, 0, 0, 0, 0, -pitch, -4};
     bool dma_cur = false;
     if (!first && tr.first < tr.end) {
-        const int ftx0 = (tr.first % tiles_x) * TX, fty0 = y0 + (tr.first / tiles_x) * TY;
+        const int ftx0 = (tr.first % tiles_x) * TX, fty0 = y0 + (tr.first / tiles_x) * TY;      // round 0: no rotation
         dma_cur = tile_is_interior(ftx0, fty0, w, h);
         if (dma_cur) {
             dma_p_tile(pin_u, pin_v, s_ou, s_ov, ftx0, fty0, pitch, lane, wv);
             dma_ring<UNITW ? 5 : kRingOps>(ring_plane, ring_shift, s_ring, ftx0, fty0, pitch, lane, wv);
         }
     }
-    for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1) {
+    for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1, round++) {
         float *const s_nu = s_nu2 + parity * NSZ, *const s_nv = s_nv2 + parity * NSZ;
-        const int tx0 = (t % tiles_x) * TX, ty0 = y0 + (t / tiles_x) * TY;
+        const int tx0 = ((t % tiles_x + (rotate ? round : 0)) % tiles_x) * TX, ty0 = y0 + (t / tiles_x) * TY;
         // ---- loads of the thread's two tile groups first (r_{k-1} and the operator; addresses of groups beyond a ragged
         // edge are clamped into the frame, their values never used), so that they are in flight while phase 0 waits for p
         QCoef c3[2];
@@ -299,107 +329,18 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int
             }
             __syncthreads();
         }
-        // ---- phase 1: the ring group (one each for the first 100 threads), then the two tile groups
-#pragma unroll
-        for (int sl = 0; sl < 3; sl++) {
-            const int slot = (sl + 2) % 3;
-            int gx, gy;
-            const bool own = slot < 2;
-            if (own) { gx = tid & 31; gy = (tid >> 5) + kTileY * slot; }
-            else if (tid < 34) { gx = tid - 1; gy = -1; }
-            else if (tid < 68) { gx = tid - 35; gy = TY; }
-            else if (tid < 84) { gx = -1; gy = tid - 68; }
-            else if (tid < 100) { gx = TX / 4; gy = tid - 84; }
-            else { gx = 0; gy = -9; }                              // no ring group for this thread
-            const int x0 = tx0 + 4 * gx, y = ty0 + gy;
-            const bool valid = (gy >= -1) && y >= 0 && y < h && x0 >= 0 && x0 < w && (!own || y < y1);
-            QCoef cr;
-            float ru[4] = {0, 0, 0, 0}, rv[4] = {0, 0, 0, 0}, pnu[4] = {0, 0, 0, 0}, pnv[4] = {0, 0, 0, 0};
-            if (!own) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) { cr.a1[e] = 1.f; cr.a4[e] = 1.f; cr.a2[e] = 0.f; cr.wx[e] = 0.f; cr.wy[e] = 0.f; cr.wys[e] = 0.f; }
-                cr.wxw = 0.f;
-                if (dma_cur && !first) {                           // an interior tile: every ring group is valid, its operands are in LDS
-                    if (tid < kRingGroups) {
-                        *(float4 *)ru = ld4(&s_ring[(0 * kRingGroups + tid) * 4]); *(float4 *)rv = ld4(&s_ring[(1 * kRingGroups + tid) * 4]);
-                        *(float4 *)cr.a1 = ld4(&s_ring[(2 * kRingGroups + tid) * 4]); *(float4 *)cr.a4 = ld4(&s_ring[(3 * kRingGroups + tid) * 4]);
-                        *(float4 *)cr.a2 = ld4(&s_ring[(4 * kRingGroups + tid) * 4]);
-                        if (UNITW) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) { cr.wx[e] = -1.f; cr.wy[e] = -1.f; cr.wys[e] = -1.f; }
-                            cr.wxw = -1.f;
-                        } else {
-                            *(float4 *)cr.wx = ld4(&s_ring[(5 * kRingGroups + tid) * 4]); *(float4 *)cr.wy = ld4(&s_ring[(6 * kRingGroups + tid) * 4]);
-                            *(float4 *)cr.wys = ld4(&s_ring[(7 * kRingGroups + tid) * 4]);
-                            cr.wxw = s_ring[(8 * kRingGroups + tid) * 4 + 3];
-                        }
-                    }
-                } else if (valid) {
-                    const unsigned o = (unsigned)(y * pitch + x0) * 4u;
-                    const int kr = first ? 0 : ko;
-                    if (BANDED && y < y0) { *(float4 *)ru = ld4(at(L.rup_u[kr], o)); *(float4 *)rv = ld4(at(L.rup_v[kr], o)); }
-                    else if (BANDED && y >= y1) { *(float4 *)ru = ld4(at(L.rdn_u[kr], o)); *(float4 *)rv = ld4(at(L.rdn_v[kr], o)); }
-                    else { *(float4 *)ru = ld4(at(rin_u, o)); *(float4 *)rv = ld4(at(rin_v, o)); }
-                    *(float4 *)cr.a1 = ld4(at(L.a1, o)); *(float4 *)cr.a4 = ld4(at(L.a4, o));
-                    *(float4 *)cr.a2 = ld4(at(L.a2, o));
-                    if (UNITW) {
-#pragma unroll
-                        for (int e = 0; e < 4; e++) { cr.wx[e] = -1.f; cr.wy[e] = -1.f; cr.wys[e] = -1.f; }
-                        cr.wxw = -1.f;
-                    } else {
-                        *(float4 *)cr.wx = ld4(at(L.wx, o)); *(float4 *)cr.wy = ld4(at(L.wy, o));
-                        if (y > 0) *(float4 *)cr.wys = ld4(at((BANDED && y < y0) ? L.wy_up : L.wy, o - 4u * (unsigned)pitch));
-                        if (x0 > 0) cr.wxw = *at(L.wx, o - 4u);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) { ru[e] = r3u[slot & 1][e]; rv[e] = r3v[slot & 1][e]; }
-            }
-            const QCoef &c = own ? c3[slot & 1] : cr;
-            if (valid) {
-                const unsigned o = (unsigned)(y * pitch + x0) * 4u;
-                float pu[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
-                if (!first) {
-                    float qu[4], qv[4];
-                    stencil_group(s_ou, s_ov, gy + 2, kQOff + 4 * gx, x0, y, w, h, c, qu, qv);        // q_{k-1}, again
-                    *(float4 *)pu = ld4(&s_ou[(gy + 2) * kQCols + kQOff + 4 * gx]);
-                    *(float4 *)pv = ld4(&s_ov[(gy + 2) * kQCols + kQOff + 4 * gx]);
-                    if (own && (x_two || x_one)) {
-                        float xu[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0};
-                        if (x_read) { *(float4 *)xu = ld4_if(at(L.xu, o), L.nt_hints & 1); *(float4 *)xv = ld4_if(at(L.xv, o), L.nt_hints & 1); }
-                        if (x_two) {
-                            float ou[4], ov[4];
-                            *(float4 *)ou = ld4_nt(at(pin2_u, o)); *(float4 *)ov = ld4_nt(at(pin2_v, o));
-#pragma unroll
-                            for (int e = 0; e < 4; e++) { xu[e] = alpha2 * ou[e] + xu[e]; xv[e] = alpha2 * ov[e] + xv[e]; }
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; e++) { xu[e] = alpha * pu[e] + xu[e]; xv[e] = alpha * pv[e] + xv[e]; }   // ref .cu:1172
-                        st4_if(at(L.xu, o), *(float4 *)xu, L.nt_hints & 1);
-                        st4_if(at(L.xv, o), *(float4 *)xv, L.nt_hints & 1);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { ru[e] = nalpha * qu[e] + ru[e]; rv[e] = nalpha * qv[e] + rv[e]; }    // ref .cu:1174
-                    if (own && active) { st4_nt(at(rout_u, o), *(float4 *)ru); st4_nt(at(rout_v, o), *(float4 *)rv); }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const bool ok = (x0 + e) < w;
-                    if (!ok) { ru[e] = 0.f; rv[e] = 0.f; }
-                    pnu[e] = ok ? direction(ru[e], pu[e], c.a1[e], beta, first) : 0.f;
-                    pnv[e] = ok ? direction(rv[e], pv[e], c.a4[e], beta, first) : 0.f;
-                }
-                if (own && active) { st4_nt(at(pout_u, o), *(float4 *)pnu); st4_nt(at(pout_v, o), *(float4 *)pnv); }
-            }
-            if (gy >= -1) {
-                st4(&s_nu[(gy + 1) * kQCols + kQOff + 4 * gx], *(float4 *)pnu);
-                st4(&s_nv[(gy + 1) * kQCols + kQOff + 4 * gx], *(float4 *)pnv);
-            }
-            if (own) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) { r3u[slot & 1][e] = ru[e]; r3v[slot & 1][e] = rv[e]; }     // r_k, for the sums of phase 2
-            }
+        // ---- phase 1: the ring group (one each for the first 100 threads), then the two tile groups.  Twice in the text: for a tile
+        // strictly inside the frame (INT: every group valid, no border case in the operator; these are the tiles whose staging came by
+        // DMA) and for the tiles along the frame's border.
+        const bool interior = dma_cur && !first;
+        if (Q_P1 && interior) {
+#define Q_INT true
+#include "pcg_fused_q_phase1.inc"
+#undef Q_INT
+        } else {
+#define Q_INT false
+#include "pcg_fused_q_phase1.inc"
+#undef Q_INT
         }
         __syncthreads();
         // ---- the next tile's p_{k-1}: LDS-DMA now, to land under phase 2 and the next tile's own loads
@@ -407,7 +348,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int
             const int tn = t + tr.step;
             bool dma_next = false;
             if (!first && tn < tr.end) {
-                const int ntx0 = (tn % tiles_x) * TX, nty0 = y0 + (tn / tiles_x) * TY;
+                const int ntx0 = ((tn % tiles_x + (rotate ? round + 1 : 0)) % tiles_x) * TX, nty0 = y0 + (tn / tiles_x) * TY;
                 dma_next = tile_is_interior(ntx0, nty0, w, h);
                 if (dma_next) {
                     dma_p_tile(pin_u, pin_v, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);
@@ -418,33 +359,14 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_dma(LevelPtrs L, int k, int
         }
         // ---- phase 2: q_k on the tile and the partial sums (q_k is not stored: the next launch forms it again)
         if (active) {
-#pragma unroll
-            for (int slot = 0; slot < 2; slot++) {
-                const int gx = tid & 31, gy = (tid >> 5) + kTileY * slot;
-                const int x0 = tx0 + 4 * gx, y = ty0 + gy;
-                if (y < y1 && x0 < w) {
-                    float qu[4], qv[4];
-                    stencil_group(s_nu, s_nv, gy + 1, kQOff + 4 * gx, x0, y, w, h, c3[slot], qu, qv);
-                    float pku[4], pkv[4];
-                    *(float4 *)pku = ld4(&s_nu[(gy + 1) * kQCols + kQOff + 4 * gx]); *(float4 *)pkv = ld4(&s_nv[(gy + 1) * kQCols + kQOff + 4 * gx]);
-                    float d_pq = 0.f, d_qz = 0.f, d_qmq = 0.f, d_rq = 0.f, d_qq = 0.f, d_rz = 0.f, d_rr = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        if (x0 + e < w) {
-                            const float iu = rcp_exact(c3[slot].a1[e]), iv = rcp_exact(c3[slot].a4[e]);
-                            const float zu = iu * r3u[slot][e], zv = iv * r3v[slot][e];
-                            d_pq += pku[e] * qu[e]; d_pq += pkv[e] * qv[e];
-                            d_qz += qu[e] * zu; d_qz += qv[e] * zv;
-                            d_qmq += qu[e] * (iu * qu[e]); d_qmq += qv[e] * (iv * qv[e]);
-                            d_rq += r3u[slot][e] * qu[e]; d_rq += r3v[slot][e] * qv[e];
-                            d_qq += qu[e] * qu[e]; d_qq += qv[e] * qv[e];
-                            d_rz += r3u[slot][e] * zu; d_rz += r3v[slot][e] * zv;
-                            d_rr += r3u[slot][e] * r3u[slot][e]; d_rr += r3v[slot][e] * r3v[slot][e];
-                        }
-                    }
-                    acc_pq += (double)d_pq; acc_qz += (double)d_qz; acc_qmq += (double)d_qmq; acc_rq += (double)d_rq;
-                    acc_qq += (double)d_qq; acc_rz += (double)d_rz; acc_rr += (double)d_rr;
-                }
+            if (Q_P2 && interior) {
+#define Q_INT true
+#include "pcg_fused_q_phase2.inc"
+#undef Q_INT
+            } else {
+#define Q_INT false
+#include "pcg_fused_q_phase2.inc"
+#undef Q_INT
             }
         }
     }

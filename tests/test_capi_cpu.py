@@ -141,3 +141,22 @@ def test_bench_refuses_more_gpus_than_are_visible():
     env["WORLD_SIZE"] = "3"; env["RANK"] = "0"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2 and "disagrees with WORLD_SIZE" in r.stderr, r.stderr
+
+
+def test_lds_dma_pcg_kernel_is_built_for_two_waves_per_simd():
+    """k_pcg_fused_q_dma is designed for two workgroups per CU (two waves per SIMD: <= 256 registers, VGPRs + AGPRs, and no scratch).
+    The register allocator is free to give that up -- one experimental build did, silently, and ran 25 % slower -- so the Makefile
+    keeps the compiler's resource remarks of that file and this test reads them."""
+    import re
+    usage = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "octane_amd", "csrc", "pcg_fused_q_dma.usage.txt")
+    if not os.path.exists(usage):
+        pytest.skip("liboctane_vof.so was not built in this tree (no compiler remarks to read)")
+    txt = open(usage).read()
+    kernels = re.findall(r"Function Name: (\S*k_pcg_fused_q_dma\S*)", txt)
+    assert len(kernels) == 2, kernels                      # unit-weight and varying-weight instances
+    occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", txt)]
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)]
+    vg = [int(x) for x in re.findall(r" VGPRs: (\d+)", txt)]
+    ag = [int(x) for x in re.findall(r" AGPRs: (\d+)", txt)]
+    print("k_pcg_fused_q_dma: VGPRs", vg, "AGPRs", ag, "occupancy", occ, "scratch", scratch)
+    assert occ == [2, 2] and scratch == [0, 0] and all(v + a <= 256 for v, a in zip(vg, ag))

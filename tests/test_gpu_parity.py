@@ -514,9 +514,12 @@ def test_q_recomputing_form_equals_stored_q_form(capi, nx, ny):
     (2560, 2048, dict(kiters=1, liters=2, cgiters=6)),      # whole tiles only
 ])
 def test_lds_dma_form_of_the_q_recomputing_kernel_is_bit_identical(capi, nx, ny, prm):
-    """Whole levels run the q-recomputing kernel with the next tile's p and ring operands fetched by LDS-DMA during phase 2
+    """Whole levels run the q-recomputing kernel with the next tile's p and ring operands fetched by LDS-DMA during phase 2, the
+    border-free form of the operator on tiles strictly inside the frame and the reciprocal of the diagonal by rcp_exact
     (pcg_fused_q_dma.hip; the default).  Same arithmetic, same tile walk, same partial sums as the register-staged kernel
-    (tune("q_dma", 0)): the flow has to be the same bits, in all three GNC steps (unit and varying weights)."""
+    (tune("q_dma", 0)): the flow has to be the same bits, in all three GNC steps (unit and varying weights).  (Widths whose
+    tile-column count divides the 512-workgroup grid -- 2000, 2048 -- walk the tiles in another order in the DMA kernel, hence
+    group the fp64 partial sums differently: the next test.)"""
     a, b = synth.lattice_scene(nx, ny, seed=nx - ny)
     outs = {}
     for dma in (0, 1):
@@ -531,3 +534,24 @@ def test_lds_dma_form_of_the_q_recomputing_kernel_is_bit_identical(capi, nx, ny,
     ndiff = int((outs[0][0] != outs[1][0]).sum() + (outs[0][1] != outs[1][1]).sum())
     print(f"PARITY case=q_dma {nx}x{ny} {prm}: LDS-DMA vs register staging: {ndiff} values differ ({its} iterations)")
     assert np.isfinite(outs[1][0]).all() and ndiff == 0
+
+
+def test_lds_dma_kernel_with_rotated_tile_columns_agrees_with_the_register_staged_kernel(capi):
+    """2048 pixels = 16 tile columns, which divides the grid of 512 workgroups: the DMA kernel rotates the columns of a tile row by the
+    round number so that no workgroup owns the frame's border column in every round.  Another tile order = another grouping of
+    the fp64 partial sums: not the same bits as the register-staged kernel, the same flow within 1e-5 and the same iteration count."""
+    nx, ny, prm = 2048, 1800, dict(kiters=1, liters=2, cgiters=8)
+    a, b = synth.lattice_scene(nx, ny, seed=77)
+    outs, its = {}, {}
+    for dma in (0, 1):
+        pl = capi.Plan(nx, ny, 1, capi.FlowParams(**prm))
+        try:
+            pl.tune("q_dma", dma)
+            outs[dma] = pl.run_host(a, b)
+            its[dma] = pl.last_iterations()
+        finally:
+            pl.tune("q_dma", 1)
+            pl.close()
+    d = rel_l2(outs[1][0], outs[1][1], outs[0][0], outs[0][1])
+    print(f"PARITY case=q_dma_rotated {nx}x{ny} {prm}: rel-L2 {d:.3e}, iterations {its}")
+    assert its[0] == its[1] and d < 1e-5
