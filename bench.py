@@ -104,7 +104,7 @@ def pair_lanes(args, capi, shard, synth, torch, dist, world, rank, dev, n, prm):
     pairs = [synth.lattice_scene(n, n, seed=20240613 + 2 + rank + 31 * ln, device=dev) for ln in range(lanes)]
     plans = [capi.Plan(n, n, 1, prm) for _ in range(lanes)]
     for pl in plans:
-        pl.tune("persist_max_g", 16)      # beside other lanes only the tiny levels keep the persistent solve (octane_vof_batch_run does the same)
+        pl.tune("lane_mode", 1)      # beside other lanes only the tiny levels keep the persistent solve (octane_vof_batch_run does the same)
     outs = [(torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)) for _ in range(lanes)]
 
     def lane_work(ln, count):
@@ -162,7 +162,7 @@ def batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev):
     pool = [synth.lattice_scene(n, n, seed=20240613 + 4 + 97 * rank + i, device=dev) for i in range(4)]
     plans = [capi.Plan(n, n, 1, prm) for _ in range(lanes)]
     for pl in plans:
-        pl.tune("persist_max_g", 16)      # as octane_vof_batch_run does for its lanes
+        pl.tune("lane_mode", 1)      # as octane_vof_batch_run does for its lanes
     outs = [(torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)) for _ in range(lanes)]
 
     # Each lane runs on its plan's private stream: those sit on different hardware queues, so one pair's latency-bound

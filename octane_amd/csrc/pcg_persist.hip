@@ -48,6 +48,12 @@ __device__ unsigned long long g_mid_stamps[32];     // [0..15] sub-domains on th
 #define MID_STAMP(i) do { } while (0)
 #endif
 
+#ifndef MID_KEEP_RCP_P
+#define MID_KEEP_RCP_P 10  // ... and up to this many keep the reciprocals of the diagonal (two registers per slot) instead of forming them twice per iteration
+#endif
+#ifndef MID_HOIST_P
+#define MID_HOIST_P 6     // sub-domains of up to this many slots per thread have the registers to keep what is invariant over the iterations
+#endif
 constexpr int kMidT = 512;              // threads per workgroup: 8 waves, two per SIMD, up to 256 VGPRs each
 constexpr int kMidW = 64;               // columns of a sub-domain: one wavefront per row
 constexpr int kMidRG = kMidT / kMidW;   // rows one slot of all threads covers
@@ -239,6 +245,11 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
     }
     const unsigned e_nb_off = (unsigned)(r_lds >= 0 ? r_nb : wg) * (2 * 4 * 6 * kMidEdge) * 8u;   // byte offset of the neighbour's block of granules
 
+    v2f i2s[P <= MID_KEEP_RCP_P ? P : 1];
+    if (P <= MID_KEEP_RCP_P) {
+#pragma unroll
+        for (int s = 0; s < P; s++) i2s[s] = mk2(rcp_exact(a1[s]), rcp_exact(a4[s]));
+    }
     float rz_prev = st.rz;                                 // (r.z) of iteration k - 1 as that iteration formed it
     float alpha = 0.f;
     int iters = 0, k = A.k0;
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         // (P = 14: 11 arrays of 14 are live already).  The empty asm statements make those inputs opaque once per phase, so the
         // derived values are formed again where they are used.
         int c = c_, rg = rg_;
-        asm volatile("" : "+v"(c), "+v"(rg));
+        if (P > MID_HOIST_P) asm volatile("" : "+v"(c), "+v"(rg));
         const bool colok = c < sw;
         const bool first = (k == 0);
 #ifdef MID_DIAG
@@ -367,7 +378,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
                 if (ok) { po = s_p[li]; s_x[ly * kMidW + c] = alpha * po + s_x[ly * kMidW + c]; }    /* ref .cu:1172 */                  \
                 r2[s] = nalpha * q2[s] + r2[s];                                                    /* ref .cu:1174 */                  \
             }                                                                                                                          \
-            const v2f i2 = mk2(rcp_exact(a1[s]), rcp_exact(a4[s]));                                                                    \
+            const v2f i2 = (P <= MID_KEEP_RCP_P) ? i2s[s] : mk2(rcp_exact(a1[s]), rcp_exact(a4[s]));                                   \
             const v2f z2 = i2 * r2[s];                                                                                                 \
             const v2f pn = first ? z2 : beta * po + z2;                                                                                \
             if (ok) s_p[li] = pn;                                                                                                      \
@@ -380,8 +391,8 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         MID_STAMP(3);
         // ---- q = A p and the sums that carry q (the reciprocals of the diagonal and z are formed again rather than kept across the barrier)
 #pragma unroll
-        for (int s = 0; s < P; s++) asm volatile("" : "+v"(a1[s]), "+v"(a2[s]), "+v"(a4[s]), "+v"(wS[s]), "+v"(wW[s]), "+v"(wE[s]), "+v"(wN[s]));
-        asm volatile("" : "+v"(c), "+v"(rg));
+        for (int s = 0; s < P; s++) { if (P > MID_HOIST_P) asm volatile("" : "+v"(a1[s]), "+v"(a2[s]), "+v"(a4[s]), "+v"(wS[s]), "+v"(wW[s]), "+v"(wE[s]), "+v"(wN[s])); }
+        if (P > MID_HOIST_P) asm volatile("" : "+v"(c), "+v"(rg));
         const int par = k & 1;
 #define MID_STENCIL_LOOP(FAST)                                                                                                         \
         _Pragma("unroll") for (int s = 0; s < P; s++) {                                                                                \
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
             sum += wn * s_p[li + kMidLP];                                                                                              \
             if (!FAST) sum = ok ? sum : mk2(0.f, 0.f);   /* a slot without a pixel: its LDS cell may be a ring cell of the neighbours */ \
             q2[s] = sum;                                                                                                               \
-            const v2f i2 = mk2(rcp_exact(a1[s]), rcp_exact(a4[s]));                                                                    \
+            const v2f i2 = (P <= MID_KEEP_RCP_P) ? i2s[s] : mk2(rcp_exact(a1[s]), rcp_exact(a4[s]));                                   \
             const v2f z2 = i2 * r2[s];                                                                                                 \
             acc[2] += pc * sum; acc[3] += sum * z2; acc[4] += sum * (i2 * sum); acc[5] += r2[s] * sum; acc[6] += sum * sum;            \
             /* r and q of the edge pixels go to LDS first (p is there already); the granules are written below, coalesced */           \

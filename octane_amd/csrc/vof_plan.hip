@@ -247,6 +247,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_PASS_A")) set_pass_a_variant(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_XCD")) pl->xcd_bands = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_SMALL")) pl->use_small = atoi(e) != 0;
+    if (const char *e = getenv("OCTANE_TUNE_SMALL_MAX")) pl->small_max_pixels = atol(e);
     if (const char *e = getenv("OCTANE_TUNE_NT")) pl->nt_hints = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_DEFER_X")) pl->defer_x = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_GRAPH")) pl->use_graph = atoi(e) != 0;
@@ -558,6 +559,10 @@ int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur
 // CUs the other is waiting for, so within this process they are serialised among themselves per device: every launch waits
 // for the event the previous one recorded (on whatever stream that was) and records the next.  Everything else overlaps as
 // before.  (Another PROCESS on the same GPU is not covered: the kernel's barriers are bounded and abort the solve.)
+// A plan that runs beside other plans on the same device (the lanes of octane_vof_batch_run, bench.py --lanes): its persistent
+// solves are serialised with theirs (persist_launch below), so only the tiny levels keep them (<= 16 workgroups: 157^2 and below)
+// and everything one workgroup can hold goes to the single-workgroup solve, whose launches overlap freely.
+static void plan_lane_mode(octane_vof_plan *pl) { pl->persist_max_g = 16; pl->small_max_pixels = 6144; }
 static std::mutex g_persist_mu;
 static int g_persist_diag = 0;      // octane_vof_tune(plan, "persist_diag", 1): the stamped build of the persistent solve (diagnostic)
 static hipEvent_t g_persist_ev[64] = {nullptr};
@@ -589,11 +594,16 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
     const int g_a_plain = pcg_grid_size(li.w, li.h);
     const int g_a_unit = pcg_grid_size_unit_w(li.w, li.h);
     const int g_b = pcg_b_grid_size(li.w, li.h);
-    const bool small = pl->use_small && pcg_small_applicable(li.w, li.h);
     // mid-size levels: the whole solve in one persistent launch, the level resident on chip (pcg_persist.hip)
     MidGeom mg;
-    const bool mid = !small && pl->use_persist && pl->use_fused && !pl->use_graph && pl->d_mid && (long)li.w * li.h <= pl->persist_max_pixels &&
-                     pcg_mid_config(li.w, li.h, pl->ncu < pl->persist_max_g ? pl->ncu : pl->persist_max_g, pl->persist_p, &mg) == 1;
+    const bool mid_ok = pl->use_persist && pl->use_fused && !pl->use_graph && pl->d_mid && (long)li.w * li.h <= pl->persist_max_pixels &&
+                        pcg_mid_config(li.w, li.h, pl->ncu < pl->persist_max_g ? pl->ncu : pl->persist_max_g, pl->persist_p, &mg) == 1;
+    // the coarsest levels: one workgroup holds the whole level (k_pcg_solve_small, <= 6144 pixels).  Above ~3000 pixels a handful of
+    // persistent sub-domains is faster than one workgroup with 8-12 pixels per thread (63^2: 424 against 536 us for three solves,
+    // 78^2: 449 against 667; 50^2: 416 against 373), so the single workgroup keeps only what is smaller, or everything if the
+    // persistent solve is not available
+    const bool small = pl->use_small && pcg_small_applicable(li.w, li.h) && (!mid_ok || (long)li.w * li.h <= pl->small_max_pixels);
+    const bool mid = !small && mid_ok;
 
     for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
         AssembleParams ap;
@@ -968,7 +978,7 @@ extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const 
             // Lanes fill one another's latency-bound levels already; a persistent solve holds its CUs for a whole solve and such
             // launches are serialised per device, so beside other lanes only the tiny levels keep it (64 x 2000^2: 145 Mpix/s with a
             // cap of 16 workgroups, 143 without the persistent solve, 130 with a cap of 130, 136 uncapped)
-            if (rc == OCTANE_OK && lanes > 1 && !getenv("OCTANE_TUNE_PERSIST_MAXG")) pl->persist_max_g = 16;
+            if (rc == OCTANE_OK && lanes > 1 && !getenv("OCTANE_TUNE_PERSIST_MAXG")) plan_lane_mode(pl);
             for (int b = first; rc == OCTANE_OK && b < npairs; b += step)
                 rc = octane_vof_plan_run(pl, img1[b], img2[b], u[b], v[b], OCTANE_MEM_HOST, nullptr);
             if (rc != OCTANE_OK) errs[wk] = g_last_error;
@@ -1417,6 +1427,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "nt") pl->nt_hints = value;
     else if (k == "defer_x") pl->defer_x = value != 0;
     else if (k == "small") pl->use_small = value != 0;
+    else if (k == "small_max") pl->small_max_pixels = value;
     else if (k == "unit_w") pl->use_unit_w = value != 0;
     else if (k == "fused") pl->use_fused = value != 0;
     else if (k == "fused_q") set_fused_q(value);
@@ -1428,6 +1439,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "persist_fault") set_mid_fault(value);
     else if (k == "persist_diag") g_persist_diag = value != 0;
     else if (k == "persist_max_g") pl->persist_max_g = value;
+    else if (k == "lane_mode") { if (value) plan_lane_mode(pl); else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 3072; } }
     else if (k == "fused_rows") set_fused_rows(value);
     else return OCTANE_E_INVALID;
     return OCTANE_OK;

@@ -330,7 +330,7 @@ def test_config4_batch_of_64_pairs_2000(capi):
     # workgroups; vof_plan.hip): the single-plan run they have to reproduce bit for bit is configured the same way.  Against the
     # default plan (persistent solves on every mid-size level: another grouping of the fp64 partial sums) the distance is printed.
     pl = capi.Plan(n, n, 1, prm)
-    pl.tune("persist_max_g", 16)
+    pl.tune("lane_mode", 1)
     pd = capi.Plan(n, n, 1, prm)
     ud, vd = pd.run_host(*pairs[0])
     pd.close()

@@ -15,6 +15,8 @@ for n in sizes:
     a, b = synth.lattice_scene(n, n, seed=n, device="cuda")
     u = torch.zeros(n, n, device="cuda"); v = torch.zeros(n, n, device="cuda")
     pl = capi.Plan(n, n, 1, capi.FlowParams(kiters=1, liters=1, cgiters=CG))
+    if os.environ.get("SMALL_MAX"):
+        pl.tune("small_max", int(os.environ["SMALL_MAX"]))
     st = torch.cuda.current_stream().cuda_stream
     for diag in (0, 1):
         pl.tune("persist_diag", diag)
