@@ -106,25 +106,31 @@ constexpr int kRingGroups = 100;          // 34 above, 34 below, 16 left, 16 rig
 constexpr int kRingOps = 9;
 
 // every float4 group the staging touches (2 rows above / below, one group left / right of the tile) lies inside the level
-__device__ __forceinline__ bool tile_is_interior(int tx0, int ty0, int w, int h)
+__device__ __forceinline__ bool tile_is_interior(int tx0, int ty0, int w, int h, int y1)
 {
     // (strictly inside on the right: the last pixel of the ring group east of the tile is not the frame's last column, so no pixel the
     // tile touches -- own or ring -- has a merged border weight or a missing neighbour: stencil_group<true>)
-    return tx0 >= 4 && tx0 + kTileX + 4 < w && ty0 >= 2 && ty0 + kQTY + 2 <= h;
+    // (a row band: all 16 rows of the tile are the band's own; the rows staged from beyond its edges are the neighbouring band's)
+    return tx0 >= 4 && tx0 + kTileX + 4 < w && ty0 >= 2 && ty0 + kQTY + 2 <= h && ty0 + kQTY <= y1;
 }
 
 // LDS-DMA of the staged p tile: one instruction per staged row and component, lanes 0..33 <-> the row's 34 float4 groups (544
 // contiguous bytes at column kQOff - 4 of the padded LDS row), rows dealt over the four waves.  The destination is M0 + lane * 16.
-__device__ __forceinline__ void dma_p_tile(const float *pin_u, const float *pin_v, float *s_ou, float *s_ov, int tx0, int ty0, int pitch,
-                                           int lane, int wv)
+// A row band takes the staged rows above its first / below its last row from the neighbouring band's planes (up_* / dn_*; the
+// band's own planes for a whole level).
+template <bool BANDED>
+__device__ __forceinline__ void dma_p_tile(const float *pin_u, const float *pin_v, const float *up_u, const float *up_v, const float *dn_u,
+                                           const float *dn_v, int y0, int y1, float *s_ou, float *s_ov, int tx0, int ty0, int pitch, int lane, int wv)
 {
     typedef __attribute__((address_space(3))) float lds_float;
     const unsigned base_u = (unsigned)(unsigned long)(lds_float *)s_ou, base_v = (unsigned)(unsigned long)(lds_float *)s_ov;
     if (lane < kTileX / 4 + 2) {
         const int x0 = tx0 + 4 * (lane - 1);
         for (int r = wv; r < kQTY + 4; r += 4) {
-            const size_t o = (size_t)(ty0 + r - 2) * pitch + x0;
-            const float *gu = pin_u + o, *gv = pin_v + o;
+            const int y = ty0 + r - 2;
+            const size_t o = (size_t)y * pitch + x0;
+            const float *gu = ((BANDED && y < y0) ? up_u : (BANDED && y >= y1) ? dn_u : pin_u) + o;
+            const float *gv = ((BANDED && y < y0) ? up_v : (BANDED && y >= y1) ? dn_v : pin_v) + o;
             const unsigned du = __builtin_amdgcn_readfirstlane(base_u + (unsigned)(r * kQCols + kQOff - 4) * 4u);
             const unsigned dv = __builtin_amdgcn_readfirstlane(base_v + (unsigned)(r * kQCols + kQOff - 4) * 4u);
             unsigned keep;
@@ -144,9 +150,12 @@ __device__ __forceinline__ void dma_one(const float *g, unsigned lds_byte)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_byte) : "memory");
 }
-template <int NOPS>
-__device__ __forceinline__ void dma_ring(const float *const (&plane)[kRingOps], const int (&shift)[kRingOps], float *s_ring, int tx0, int ty0,
-                                         int pitch, int lane, int wv)
+// In a row band the residual of a ring row beyond the band's edge is the neighbouring band's (rup / rdn) and so is wy of the row
+// above the upper ring row (wy_up); every other operand of the ring rows is the band's own (its assembly covers one halo row).
+struct RingBand { const float *rup_u, *rup_v, *rdn_u, *rdn_v, *wy_up; int y0, y1; };
+template <int NOPS, bool BANDED>
+__device__ __forceinline__ void dma_ring(const float *const (&plane)[kRingOps], const int (&shift)[kRingOps], const RingBand &rb, float *s_ring,
+                                         int tx0, int ty0, int pitch, int lane, int wv)
 {
     typedef __attribute__((address_space(3))) float lds_float;
     const unsigned base = (unsigned)(unsigned long)(lds_float *)s_ring;
@@ -159,12 +168,17 @@ __device__ __forceinline__ void dma_ring(const float *const (&plane)[kRingOps], 
         else if (j < 84) { gx = -1; gy = j - 68; }
         else { gx = kTileX / 4; gy = j - 84; }
         if (j < kRingGroups) {
-            const long o = (long)(ty0 + gy) * pitch + tx0 + 4 * gx;
+            const int y = ty0 + gy;
+            const long o = (long)y * pitch + tx0 + 4 * gx;
 #pragma unroll
             for (int op = 0; op < NOPS; op++) {
                 if ((op & 3) == wv) {                      // uniform: this wave's operands
                     const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)((op * kRingGroups + 64 * i) * 16));
-                    dma_one(plane[op] + o + shift[op], dst);
+                    const float *pl = plane[op];
+                    if (BANDED && op == 0) pl = y < rb.y0 ? rb.rup_u : y >= rb.y1 ? rb.rdn_u : pl;
+                    if (BANDED && op == 1) pl = y < rb.y0 ? rb.rup_v : y >= rb.y1 ? rb.rdn_v : pl;
+                    if (BANDED && op == 7) pl = y < rb.y0 ? rb.wy_up : pl;
+                    dma_one(pl + o + shift[op], dst);
                 }
             }
         }
@@ -177,11 +191,10 @@ __device__ __forceinline__ void dma_ring(const float *const (&plane)[kRingOps], 
 // came out with 256 VGPRs + 2 AGPRs, ran at one workgroup per CU (0.377 instead of 0.30 ms per launch), and nothing but the
 // "Occupancy" line of the assembly said so.  The Makefile keeps the compiler's resource remarks of this file
 // (pcg_fused_q_dma.usage.txt) and tests/test_capi_cpu.py fails when the kernel's occupancy is not 2.
-template <bool UNITW>
+template <bool UNITW, bool BANDED>
 __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int k, int nparts_prev, float tol)
 {
     constexpr int TY = kQTY, TX = kTileX;
-    constexpr bool BANDED = false;                         // whole levels only
     __shared__ __attribute__((aligned(16))) float s_ou[(TY + 4) * kQCols], s_ov[(TY + 4) * kQCols];   // p_{k-1}: rows ty0-2 .. ty0+TY+1
     // p_k: rows ty0-1 .. ty0+TY, two buffers used alternately -- a workgroup's fast waves may stage and compute the next tile
     // while its slow ones still read this one's p_k in phase 2, which saves the barrier at the end of a tile
@@ -265,13 +278,16 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     // ring operands: r_u r_v a1 a4 a2 | wx wy wy(row above) wx(group to the west); the last four only where the weights vary
     const float *const ring_plane[kRingOps] = {rin_u, rin_v, L.a1, L.a4, L.a2, L.wx, L.wy, L.wy, L.wx};
     const int ring_shift[kRingOps] = {0, 0, 0, 0, 0, 0, 0, -pitch, -4};
+    const float *const up_u = L.pup_u[(k + 2) % 3], *const up_v = L.pup_v[(k + 2) % 3];      // the neighbouring bands' p_{k-1} (row bands only)
+    const float *const dn_u = L.pdn_u[(k + 2) % 3], *const dn_v = L.pdn_v[(k + 2) % 3];
+    const RingBand rb = {L.rup_u[ko], L.rup_v[ko], L.rdn_u[ko], L.rdn_v[ko], L.wy_up, y0, y1};
     bool dma_cur = false;
     if (!first && tr.first < tr.end) {
         const int ftx0 = (tr.first % tiles_x) * TX, fty0 = y0 + (tr.first / tiles_x) * TY;      // round 0: no rotation
-        dma_cur = tile_is_interior(ftx0, fty0, w, h);
+        dma_cur = tile_is_interior(ftx0, fty0, w, h, y1);
         if (dma_cur) {
-            dma_p_tile(pin_u, pin_v, s_ou, s_ov, ftx0, fty0, pitch, lane, wv);
-            dma_ring<UNITW ? 5 : kRingOps>(ring_plane, ring_shift, s_ring, ftx0, fty0, pitch, lane, wv);
+            dma_p_tile<BANDED>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ftx0, fty0, pitch, lane, wv);
+            dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ftx0, fty0, pitch, lane, wv);
         }
     }
     for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1, round++) {
@@ -349,10 +365,10 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
             bool dma_next = false;
             if (!first && tn < tr.end) {
                 const int ntx0 = ((tn % tiles_x + (rotate ? round + 1 : 0)) % tiles_x) * TX, nty0 = y0 + (tn / tiles_x) * TY;
-                dma_next = tile_is_interior(ntx0, nty0, w, h);
+                dma_next = tile_is_interior(ntx0, nty0, w, h, y1);
                 if (dma_next) {
-                    dma_p_tile(pin_u, pin_v, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);
-                    dma_ring<UNITW ? 5 : kRingOps>(ring_plane, ring_shift, s_ring, ntx0, nty0, pitch, lane, wv);
+                    dma_p_tile<BANDED>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);
+                    dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ntx0, nty0, pitch, lane, wv);
                 }
             }
             dma_cur = dma_next;
@@ -384,8 +400,14 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
 
 void launch_pcg_fused_q_dma(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
-    if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused_q_dma<true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
-    else hipLaunchKernelGGL((k_pcg_fused_q_dma<false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    const bool whole = L.nbands == 1 && L.y0 == 0 && L.y1 == L.h;
+    if (whole) {
+        if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused_q_dma<true, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        else hipLaunchKernelGGL((k_pcg_fused_q_dma<false, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    } else {                   // a row band (vof_tiled.hip)
+        if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused_q_dma<true, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+        else hipLaunchKernelGGL((k_pcg_fused_q_dma<false, true>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);
+    }
 }
 
 }  // namespace octane

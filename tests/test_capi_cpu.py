@@ -153,10 +153,10 @@ def test_lds_dma_pcg_kernel_is_built_for_two_waves_per_simd():
         pytest.skip("liboctane_vof.so was not built in this tree (no compiler remarks to read)")
     txt = open(usage).read()
     kernels = re.findall(r"Function Name: (\S*k_pcg_fused_q_dma\S*)", txt)
-    assert len(kernels) == 2, kernels                      # unit-weight and varying-weight instances
+    assert len(kernels) == 4, kernels                      # unit-weight / varying-weight x whole level / row band
     occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", txt)]
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)]
     vg = [int(x) for x in re.findall(r" VGPRs: (\d+)", txt)]
     ag = [int(x) for x in re.findall(r" AGPRs: (\d+)", txt)]
     print("k_pcg_fused_q_dma: VGPRs", vg, "AGPRs", ag, "occupancy", occ, "scratch", scratch)
-    assert occ == [2, 2] and scratch == [0, 0] and all(v + a <= 256 for v, a in zip(vg, ag))
+    assert occ == [2] * 4 and scratch == [0] * 4 and all(v + a <= 256 for v, a in zip(vg, ag))
