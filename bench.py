@@ -42,7 +42,7 @@ PASS_B_BYTES_PER_PIXEL = 40 + 16   # reads x(2) r(2) p(2) q(2) a1 a4, writes x(2
 # launch only, which then also reads x and the p before last (16) and writes x (8): 92.  Mean 80 (84 with OCTANE_TUNE_DEFER_X=0).
 FUSED_BYTES_PER_PIXEL = 80
 FUSED_BYTES_PER_PIXEL_GNC0 = 72        # first GNC step: wx == wy == -1, not read
-FUSED_Q_BYTES_PER_PIXEL = 64           # k_pcg_fused_q_dma / k_pcg_fused_q (levels of >= 3 * 2^20 pixels): q = A p is formed again, neither written nor read
+FUSED_Q_BYTES_PER_PIXEL = 64           # k_pcg_fused_q_dma / k_pcg_fused_q (levels of >= 2 * 2^20 pixels): q = A p is formed again, neither written nor read
 FUSED_Q_BYTES_PER_PIXEL_GNC0 = 56
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 TILED_SEED = 20240615              # (with 20240616 the 85 x 85 coarsest level of a 10848^2 / 8-level pyramid runs away at R1's iteration counts)
@@ -507,7 +507,7 @@ def main():
         if fused:
             # mean algorithmic bytes of a finest-level launch: 80 B/px, 72 in the first of the three GNC steps
             imm = 4 if os.environ.get("OCTANE_TUNE_DEFER_X", "1") == "0" else 0     # immediate x updates move 4 B/px more on average
-            qform = os.environ.get("OCTANE_TUNE_FUSED_Q", "1") != "0" and n * n >= (3 << 20)
+            qform = os.environ.get("OCTANE_TUNE_FUSED_Q", "1") != "0" and n * n >= (2 << 20)
             b_all, b_gnc0 = ((FUSED_Q_BYTES_PER_PIXEL, FUSED_Q_BYTES_PER_PIXEL_GNC0) if qform
                              else (FUSED_BYTES_PER_PIXEL, FUSED_BYTES_PER_PIXEL_GNC0))
             bpp = ((b_gnc0 + 2 * b_all) / 3.0 if unit_w else b_all) + imm

@@ -1581,10 +1581,12 @@ void set_fused_q(int v) { g_fused_q = v != 0; }
 static int g_fused_r = 0;            // tuning: 0 = by size, 1 / 2 = force the 128 x 8 / 128 x 16 tile
 void set_fused_rows(int r) { g_fused_r = (r == 1 || r == 2) ? r : 0; }
 static int fused_rows(int w, int rows) { return g_fused_r ? g_fused_r : (((long)w * rows < (1L << 20)) ? 1 : 2); }
-// q is recomputed where that pays: from 3 M pixels (measured: 1250^2 33 -> 35 us; 2000^2 +2 %; 2500^2 112 -> 99 us; 5000^2
-// 395 -> 339 us); below, the level sits in the Infinity Cache and the extra ring work costs more than q's traffic
-static long g_fused_q_min = 3L << 20; // pixels from which q is recomputed
-void set_fused_q_min(long px) { g_fused_q_min = px > 0 ? px : (3L << 20); }
+// q is recomputed where that pays.  Round 1 (register-staged kernel): from 3 M pixels (1250^2 33 -> 35 us; 2000^2 +2 %; 2500^2
+// 112 -> 99 us; 5000^2 395 -> 339 us).  Round 2 (LDS-DMA kernel): from 2 M pixels, i.e. every level above the persistent solve's
+// range (1500^2: 49.4 -> 41.4 us per launch, 1700^2: 56.2 -> 45.9); at 1 M pixels, where only plans beside other lanes get
+// (their persistent solves are capped), the stored-q form is still as good (64 x 2000^2: 181.4 against 179.1 Mpix/s)
+static long g_fused_q_min = 2L << 20; // pixels from which q is recomputed
+void set_fused_q_min(long px) { g_fused_q_min = px > 0 ? px : (2L << 20); }
 int pcg_fused_q_form(int w, int rows, int h)
 {
     return g_fused_q && fused_rows(w, rows) == 2 && (long)w * rows >= g_fused_q_min &&

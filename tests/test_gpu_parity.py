@@ -123,7 +123,7 @@ def test_one_thread_schedule_of_the_oracle_also_agrees_on_small_frames(capi, ora
 
 
 def test_level_above_four_megapixels_matches_oracle(capi, oracle):
-    """Levels of 3 * 2^20 pixels and more run the q-recomputing form of the fused PCG kernel (k_pcg_fused_q: tile + ring,
+    """Levels of 2 * 2^20 pixels and more run the q-recomputing form of the fused PCG kernel (k_pcg_fused_q: tile + ring,
     p staged two pixels out, x updated every second launch) -- and, with OCTANE_TUNE_FUSED=0, the LDS-ring marching
     form of pass A.  2300 x 1900 has ragged last tiles in both directions; seven iterations reach every branch of the
     deferred x update (first launch, odd, even without and with a stored x)."""
@@ -485,7 +485,7 @@ def test_fused_iteration_equals_two_pass_form(capi, nx, ny, prm):
 
 @pytest.mark.parametrize("nx,ny", [(2500, 1750), (2503, 1699)])
 def test_q_recomputing_form_equals_stored_q_form(capi, nx, ny):
-    """k_pcg_fused_q (levels of at least 3 * 2^20 pixels; OCTANE_TUNE_FUSED_Q=0 / tune("fused_q", 0) turns it off) does not
+    """k_pcg_fused_q (levels of at least 2 * 2^20 pixels; OCTANE_TUNE_FUSED_Q=0 / tune("fused_q", 0) turns it off) does not
     store q = A p but forms it again in the next launch from the stored p, on the tile and its one-pixel ring: same
     inputs, same operations as the form that stores q.  Frame with ragged right / bottom tiles and more tiles than
     workgroups; the second size has a width that is no multiple of 4 (a float4 group straddles the frame's edge)."""

@@ -226,7 +226,7 @@ def test_config3_full_disk_10848_four_bands_equals_plain_plan(capi):
 
 @pytest.mark.parametrize("nbands", [2, 3])
 def test_bands_above_four_megapixels_recompute_q(capi, oracle, nbands):
-    """Bands of 3 * 2^20 pixels and more run the q-recomputing fused kernel: nothing is stored on halo rows, a band reads r on
+    """Bands of 2 * 2^20 pixels and more run the q-recomputing fused kernel: nothing is stored on halo rows, a band reads r on
     the row beyond its edge and p on the two rows beyond it from the neighbour's planes.  The coarser level of the same
     plan keeps the stored-q form, so both exchange schemes run in one solve.  Checked against the plain plan (same
     kernels, one band) and, on a single level, against the oracle."""
