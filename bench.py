@@ -391,8 +391,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="GPUs = ranks (one process per GPU).  N > 1 without a launcher "
                     "starts the N ranks itself; under torchrun it has to equal WORLD_SIZE.  Default: WORLD_SIZE, else 1")
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=None, help="frame edge: 5000 (pair), 10848 (tiled) unless given")
     ap.add_argument("--kiters", type=int, default=8)
     ap.add_argument("--liters", type=int, default=3)
