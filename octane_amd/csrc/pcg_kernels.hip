@@ -64,7 +64,7 @@ __device__ __forceinline__ void st4_if(float *p, float4 v, bool nt) { if (nt) st
 // boundary (probability ~2^-29 per value, 1 ulp then).
 __device__ __forceinline__ float direction(float r, float pold, float diag, float beta, bool first)
 {
-    float z = (1.0f / diag) * r;
+    float z = rcp_exact(diag) * r;          // the bits of 1.0f / diag in three instructions (device_util.hpp)
     return first ? z : beta * pold + z;
 }
 
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
                     if (y < h - 1) { sumu += wN * nu[e]; sumv += wN * nv[e]; }
                     qu[e] = sumu; qv[e] = sumv;
                     if (i < w) {
-                        const float iu = 1.0f / a1[q][e], iv = 1.0f / a4[q][e];
+                        const float iu = rcp_exact(a1[q][e]), iv = rcp_exact(a4[q][e]);
                         const float zu = iu * nru[q][e], zv = iv * nrv[q][e];
                         d_pq += npu[q][e] * sumu; d_pq += npv[q][e] * sumv;
                         d_qz += sumu * zu; d_qz += sumv * zv;
@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q(LevelPtrs L, int k, int npa
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         if (x0 + e < w) {
-                            const float iu = 1.0f / c3[slot].a1[e], iv = 1.0f / c3[slot].a4[e];
+                            const float iu = rcp_exact(c3[slot].a1[e]), iv = rcp_exact(c3[slot].a4[e]);
                             const float zu = iu * r3u[slot][e], zv = iv * r3v[slot][e];
                             d_pq += pku[e] * qu[e]; d_pq += pkv[e] * qv[e];
                             d_qz += qu[e] * zu; d_qz += qv[e] * zv;
