@@ -137,3 +137,31 @@ def test_a_missing_workgroup_makes_the_solve_give_up_instead_of_hanging(capi):
     finally:
         pl.tune("persist_fault", 0)
         pl.close()
+
+
+def test_stamped_diagnostic_build_gives_the_same_flow_and_counts_its_iterations(capi):
+    """pcg_persist_diag.hip is the persistent solve's own source compiled with shader-clock stamps at the seams of an iteration
+    (octane_vof_tune(plan, "persist_diag", 1); tools/probe_mid_stamps.py).  Instrumentation must not change a bit of the flow,
+    and the counters it leaves (octane_vof_mid_stamps) have to add up: workgroups x iterations at [14] + [30], cycles at every seam."""
+    import ctypes as C
+    nx, ny, prm = 640, 500, dict(kiters=1, liters=1, cgiters=9)
+    a, b = synth.lattice_scene(nx, ny, seed=5)
+    L = capi.lib()
+    L.octane_vof_mid_stamps.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+    buf = (C.c_ulonglong * 32)()
+    up, vp, ip = _run(capi, a, b, prm)
+    assert L.octane_vof_mid_stamps(0, buf) == 0            # clear
+    try:
+        ud, vd, idg = _run(capi, a, b, prm, persist_diag=1)
+        assert L.octane_vof_mid_stamps(0, buf) == 0
+    finally:
+        pl = capi.Plan(64, 64, 1, capi.FlowParams(kiters=1))
+        pl.tune("persist_diag", 0)
+        pl.close()
+    s = list(buf)
+    ndiff = int((ud != up).sum() + (vd != vp).sum())
+    groups = 10 * 16                                      # 640 x 500 in sub-domains of 64 x 32
+    print(f"PERSIST diag: {ndiff} values differ, iterations {ip}/{idg}, stamped workgroup-iterations {s[14]} + {s[30]}")
+    assert ndiff == 0 and idg == ip
+    assert s[14] + s[30] == groups * ip                   # every workgroup stamped every iteration it ran
+    assert all(s[i] + s[16 + i] > 0 for i in (0, 1, 2, 4, 6))
