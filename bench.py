@@ -104,7 +104,8 @@ def pair_lanes(args, capi, shard, synth, torch, dist, world, rank, dev, n, prm):
     pairs = [synth.lattice_scene(n, n, seed=20240613 + 2 + rank + 31 * ln, device=dev) for ln in range(lanes)]
     plans = [capi.Plan(n, n, 1, prm) for _ in range(lanes)]
     for pl in plans:
-        pl.tune("lane_mode", 1)      # beside other lanes only the tiny levels keep the persistent solve (octane_vof_batch_run does the same)
+        if lanes > 2:
+            pl.tune("lane_mode", 1)      # beside more than one other lane only the tiny levels keep the persistent solve (octane_vof_batch_run does the same)
     outs = [(torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)) for _ in range(lanes)]
 
     def lane_work(ln, count):
@@ -150,19 +151,21 @@ def pair_lanes(args, capi, shard, synth, torch, dist, world, rank, dev, n, prm):
 
 def batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev):
     """BASELINE.json configs[4]: 64 independent 2000x2000 pairs (kiters=6) over the ranks, pair b on rank b % world;
-    each GPU runs four lanes (four plans, each on its private stream, one host thread each) so one pair's
+    each GPU runs two lanes (two plans, each on its private stream, one host thread each) so one pair's
     latency-bound coarse levels overlap the others' bandwidth-bound fine levels.  Strong scaling: the work is fixed
     at 64 pairs per step."""
     n, npairs = 2000, 64
-    # 4 hardware queues (the runtime's default): 147 / 161 / 145 Mpix/s with 2 / 3 / 4 lanes; 8 queues: 166 / 171 / 160 with 3 / 4 / 6
-    lanes = int(os.environ.get("OCTANE_BENCH_LANES", "4" if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 8 else "3"))
+    # round 1 (no persistent solves): three or four lanes, one per hardware queue; round 2: two lanes with the persistent solves uncapped
+    # (188.6 against 182.4 / 177.3 Mpix/s with three / four lanes on the same box)
+    lanes = int(os.environ.get("OCTANE_BENCH_LANES", "2"))     # octane_vof_batch_run's choice (vof_plan.hip): two lanes, persistent solves uncapped
     prm = capi.FlowParams(kiters=6, liters=args.liters, cgiters=args.cgiters, device=local)
     mine = shard.pairs_for_rank(npairs, rank, world)
     # four distinct resident pairs per rank stand in for its share (inputs stay in HBM; values do not matter for time)
     pool = [synth.lattice_scene(n, n, seed=20240613 + 4 + 97 * rank + i, device=dev) for i in range(4)]
     plans = [capi.Plan(n, n, 1, prm) for _ in range(lanes)]
     for pl in plans:
-        pl.tune("lane_mode", 1)      # as octane_vof_batch_run does for its lanes
+        if lanes > 2 and os.environ.get("OCTANE_BENCH_LANE_MODE", "1") != "0":
+            pl.tune("lane_mode", 1)      # as octane_vof_batch_run does for more than two lanes
     outs = [(torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)) for _ in range(lanes)]
 
     # Each lane runs on its plan's private stream: those sit on different hardware queues, so one pair's latency-bound

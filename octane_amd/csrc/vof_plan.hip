@@ -952,14 +952,14 @@ extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const 
     }
     // Frames up to ~8 Mpixel leave the GPU latency-bound on their coarse levels, so each device gets several lanes
     // (plans on their private streams -- distinct hardware queues --, one host thread each) whose kernels interleave.
-    // The HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues, 4 by default: 147 / 161 / 145 Mpix/s with 2 / 3 / 4
-    // lanes at 2000^2 (a fourth lane shares a queue with another one and the two serialise).  With 8 queues -- what
-    // this library asks for when it is loaded before the runtime initialises, see octane_runtime_defaults -- it is
-    // 166 / 171 / 160 with 3 / 4 / 6 lanes.  Larger frames spend less of their time on latency-bound levels, but two lanes
-    // still pay: 5000^2 168 -> 185 Mpix/s (190 with three; tools/lanes_sweep.py).  Beyond 64 Mpixel one lane.
-    const char *hwq = getenv("GPU_MAX_HW_QUEUES");
+    // Round 1 (one launch per PCG iteration on every level): three or four lanes, as many as the runtime has hardware queues for
+    // (GPU_MAX_HW_QUEUES, 4 by default: 147 / 161 / 145 Mpix/s with 2 / 3 / 4 lanes at 2000^2; 166 / 171 / 160 with 3 / 4 / 6 and 8
+    // queues).  Round 2: the mid-size levels of a plan are persistent solves, which are serialised per device but short, and TWO
+    // lanes with those solves uncapped beat every other combination (64 x 2000^2, same box: 2 lanes 188.6, 3 lanes 182.4, 4 lanes
+    // 177.3; with the round-1 arrangement -- persistent solves only on the tiny levels -- 155 / 176 / 181 for 2 / 3 / 4 lanes).
+    // Beyond 64 Mpixel one lane.
     const long px = (long)nx * ny;
-    int lanes = px <= (8L << 20) ? ((hwq && atoi(hwq) >= 8) ? 4 : 3) : (px <= (64L << 20) ? 2 : 1);
+    int lanes = px <= (64L << 20) ? 2 : 1;
     if (const char *e = getenv("OCTANE_TUNE_BATCH_LANES")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
     const int nworkers = ndevices * lanes;
     std::vector<int> rcs(nworkers, OCTANE_OK);
@@ -975,10 +975,9 @@ extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const 
             const int first = d + ndevices * lane, step = ndevices * lanes;
             if (first >= npairs) return;
             int rc = octane_vof_plan_create(&pl, nx, ny, nchan, &prm);
-            // Lanes fill one another's latency-bound levels already; a persistent solve holds its CUs for a whole solve and such
-            // launches are serialised per device, so beside other lanes only the tiny levels keep it (64 x 2000^2: 145 Mpix/s with a
-            // cap of 16 workgroups, 143 without the persistent solve, 130 with a cap of 130, 136 uncapped)
-            if (rc == OCTANE_OK && lanes > 1 && !getenv("OCTANE_TUNE_PERSIST_MAXG")) plan_lane_mode(pl);
+            // more than two lanes (OCTANE_TUNE_BATCH_LANES): a persistent solve holds its CUs for a whole solve and such launches are
+            // serialised per device, so only the tiny levels keep it then (plan_lane_mode)
+            if (rc == OCTANE_OK && lanes > 2 && !getenv("OCTANE_TUNE_PERSIST_MAXG")) plan_lane_mode(pl);
             for (int b = first; rc == OCTANE_OK && b < npairs; b += step)
                 rc = octane_vof_plan_run(pl, img1[b], img2[b], u[b], v[b], OCTANE_MEM_HOST, nullptr);
             if (rc != OCTANE_OK) errs[wk] = g_last_error;
