@@ -18,6 +18,13 @@
 #ifndef Q_LB
 #define Q_LB 1          // second launch bound (minimum waves per SIMD); tests/test_capi_cpu.py checks the built kernel's occupancy instead
 #endif
+#ifndef Q_A2BR
+#define Q_A2BR 1        // the a2 load behind the run-time streaming switch (0: a plain load; measured both ways, see Q_VMN)
+#endif
+#ifndef Q_VMN
+#define Q_VMN 1         // phase 0 waits for the DMA only (vmcnt = the own loads issued since), not for the tile's own loads too:
+                        // 0.2947 -> 0.2910 ms per launch at 5000^2 with the a2 switch, 0.3044 -> 0.2930 without it
+#endif
 #ifndef Q_ROT
 #define Q_ROT 1         // rotate the tile columns by the round number when the column count divides the grid
 #endif
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
             *(float4 *)c.a1 = ld4(at(L.a1, o)); *(float4 *)c.a4 = ld4(at(L.a4, o));
             // no streaming hint by default (bit 256, not the stored-q kernels' bit 8): the neighbouring tiles' rings read these
             // lines too, -1.5 % without it.  The switch stays because the kernel is 3 % slower without the branch (sic).
-            *(float4 *)c.a2 = ld4_if(at(L.a2, o), L.nt_hints & 256);
+            *(float4 *)c.a2 = Q_A2BR ? ld4_if(at(L.a2, o), L.nt_hints & 256) : ld4(at(L.a2, o));
             if (UNITW) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) { c.wx[e] = -1.f; c.wy[e] = -1.f; c.wys[e] = -1.f; }
@@ -321,7 +328,11 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
         }
         // ---- phase 0: p_{k-1} on the tile + 2 rows / one float4 group around it (zero outside the frame)
         if (!first && dma_cur) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA (and this tile's own loads, issued after it) have landed
+            // The DMA was issued before this tile's own loads and loads return in order: once no more than the own loads issued since
+            // (5 or 9 per slot, all unconditional) are outstanding, the DMA has landed -- the ring groups, which need nothing else,
+            // then run under the own loads' latency.  (Q_VMN 0: wait for everything.)
+            if (Q_VMN) { if (UNITW) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         } else if (!first) {
             constexpr int GW = TX / 4 + 2;                        // groups per staged row: one left, one right of the tile
