@@ -16,10 +16,16 @@ driver's launch) the ranks come from the environment and --gpus has to agree wit
 The JSON line also carries
   value_with_transfers -- SURVEY 8d's primary metric: one oct_variational_optical_flow-shaped call on HOST buffers
                    (H2D + all levels + D2H through octane_vof_run), pageable and pinned; never `value`;
-  placement_trials_ms -- [min, median, max] ms per PCG iteration over the candidate arenas the plan timed when it was
-                   created: the headline is a best-of-n-placements figure (DESIGN.md 8);
-  roofline      -- dominant kernel (the fused PCG iteration at the finest level): algorithmic bytes per launch
-                   (80 B/pixel, 72 in the first GNC step; DESIGN.md) / its mean duration from HIP events on the launch stream;
+  placement_trials -- min / median / max over the candidate arenas the plan timed when it was created (the headline is a
+                   best-of-n-placements figure).  A trial is a few PCG iterations driven from the host WITH two
+                   small H2D copies each: comparable among the candidates only, NOT with roofline.avg_launch_ms;
+  roofline      -- dominant kernel (the fused, q-recomputing PCG iteration at the finest level, k_pcg_fused_q_dma): its
+                   algorithmic bytes per launch (r p a1 a2 a4 wx wy read, r p written = 52 B/pixel; every second launch
+                   + x and the p before last read, x written = 76; mean 64, and 8 less in the first GNC step, whose
+                   weights are the constant -1: 61.33 B/pixel over a pyramid's finest-level launches; 80 / 72 for the
+                   stored-q kernel of smaller levels) / its mean duration from HIP events on the launch stream.  SURVEY
+                   8d's 116 B/pixel (two passes, seven coefficient planes, q stored) does not describe this kernel --
+                   the line carries that pricing too, as frac_at_survey_bytes;
   cpu_baseline  -- the CPU oracle ("port", OpenMP over the host cores) timed on a bounded sample (rank 0, N=1 only).
 """
 import argparse
@@ -242,6 +248,11 @@ def tiled(args, capi, synth, torch):
     torch.cuda.synchronize()
     plain_its = pl.last_iterations()
     pl.close()
+    transport = os.environ.get("OCTANE_TILED_TRANSPORT", "inplace")
+    peers = sorted({(devices[i], devices[i + 1]) for i in range(len(devices) - 1) if devices[i] != devices[i + 1]})
+    print(f"bench.py tiled preflight: {args.bands} bands on devices {devices} ({ndev} visible); transport '{transport}' "
+          + (f"({'in-kernel peer reads + LDS-DMA from the neighbouring band over xGMI' if transport != 'copy' else 'stream-ordered hipMemcpyPeerAsync into local planes'}); "
+             f"peer pairs {peers}" if peers else "; all bands share one device: VIRTUAL bands, no xGMI traffic"), file=sys.stderr, flush=True)
     tp = capi.TiledPlan(n, n, 1, prm, nbands=args.bands, devices=devices)
     tp.load_device(a.data_ptr(), b.data_ptr(), z.data_ptr(), z.data_ptr())     # the pair resident on every band's device
     tp.solve()
@@ -260,6 +271,9 @@ def tiled(args, capi, synth, torch):
     tp.wait()
     elapsed = time.perf_counter() - t0
     iters, expect = tp.last_iterations(), args.kiters * 3 * args.liters * args.cgiters
+    if iters < 0 or (iters != expect and not args.allow_early_exit):
+        print(f"bench.py tiled: the timed solves ran {iters} PCG iterations per pyramid, expected {expect}", file=sys.stderr)
+        raise SystemExit(4)
     ngpu = len(set(devices))
     out = {"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n),
            "value": round(n * n * args.steps / elapsed / 1e6, 3), "unit": "Mpix/s", "n_gpus": ngpu, "steps": args.steps,
@@ -271,7 +285,8 @@ def tiled(args, capi, synth, torch):
                       "sharding": f"row bands of the {tp.banded_levels} finest level(s), coarser levels replicated; per PCG iteration "
                                   "two event-ordered phase boundaries, partial sums and one residual row per inner edge read in "
                                   "place from the neighbouring band",
-                      "device_bytes_per_band": tp.device_bytes},
+                      "device_bytes_per_band": tp.device_bytes, "devices": devices, "transport": transport,
+                      "peer_pairs": [list(p) for p in peers]},
            "parity_vs_plain": {"rel_l2": parity, "bar": TILED_PARITY_BAR, "iterations_plain": plain_its, "iterations_banded": parity_its,
                                "ok": bool(parity <= TILED_PARITY_BAR and plain_its == parity_its)},
            "roofline": None, "cpu_baseline": None}
@@ -404,13 +419,15 @@ def main():
     ap.add_argument("--no-transfers", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--workload", default="pair", choices=["pair", "batch64", "tiled"],
                     help="pair (default): one --size pair per GPU; batch64: BASELINE.json configs[4], 64 pairs of "
-                         "2000x2000 (kiters=6) shared by all ranks, four concurrent lanes per GPU (three on 4 hardware queues); tiled: BASELINE.json "
+                         "2000x2000 (kiters=6) shared by all ranks, two concurrent lanes per GPU (OCTANE_BENCH_LANES overrides); tiled: BASELINE.json "
                          "configs[3], one --size frame as row bands: --bands bands driven by a single process, or -- "
                          "under torchrun -- one band per rank")
     ap.add_argument("--bands", type=int, default=4, help="row bands of the tiled workload")
     ap.add_argument("--lanes", type=int, default=1, help="pair workload only: this many pairs in flight per GPU, each on its own plan, "
                     "stream and host thread (a step is then one pair per lane); 1 = the headline configuration")
     ap.add_argument("--cpu-sample", type=int, default=3072, help="edge of the CPU-baseline sample pair")
+    ap.add_argument("--allow-early-exit", action="store_true", help="do not fail when solves stop early by the tolerance test "
+                    "(fewer PCG iterations than kiters * 3 * liters * cgiters); an abandoned persistent solve always fails the run")
     args = ap.parse_args()
     if args.size is None:
         args.size = 10848 if args.workload == "tiled" else 5000
@@ -468,7 +485,10 @@ def main():
     v = torch.zeros(n, n, device=dev)
     plan = capi.Plan(n, n, 1, prm)
     tr = sorted(t for t in plan.placement_trials() if t > 0)
-    trials_ms = {"n": len(tr), "min": round(tr[0], 4), "median": round(tr[len(tr) // 2], 4), "max": round(tr[-1], 4)} if tr else None
+    trials_ms = {"n": len(tr), "min_ms": round(tr[0], 4), "median_ms": round(tr[len(tr) // 2], 4), "max_ms": round(tr[-1], 4),
+                 "what": "ms per trial PCG iteration of each candidate arena INCLUDING two small host-to-device copies per iteration "
+                         "(vof_plan.hip, placement trials): comparable among the candidates only; the kernel's own launch time is "
+                         "roofline.avg_launch_ms"} if tr else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -491,6 +511,12 @@ def main():
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev if backend == "nccl" else None)
     iters = plan.last_iterations()
     expect = args.kiters * 3 * args.liters * args.cgiters
+    if iters < 0 or (iters != expect and not args.allow_early_exit):
+        # -2: a persistent mid-level solve of the last timed step was abandoned (its flow is not valid); fewer than expected: solves
+        # stopped by the tolerance test, i.e. less work than the configuration names.  Either way the time is not a measurement.
+        print(f"bench.py: rank {rank}: the timed steps ran {iters} PCG iterations per pyramid, expected {expect}"
+              + (" (a persistent solve was abandoned: GPU shared with another process?)" if iters == -2 else ""), file=sys.stderr)
+        raise SystemExit(4)
     ms_per_step = elapsed * 1e3 / args.steps
     value = shard.whole_job_mpix(world * n * n, args.steps, elapsed)
 
@@ -616,8 +642,8 @@ def main():
                # the whole call on host buffers (H2D + all levels + D2H): SURVEY 8d's primary metric; `value` above is the
                # device-resident figure the bench contract asks for
                "value_with_transfers": transfers,
-               # the plan kept the fastest of these candidate arenas (ms per finest-level PCG iteration): best-of-n placement
-               "placement_trials_ms": trials_ms,
+               # the plan kept the fastest of these candidate arenas: best-of-n placement
+               "placement_trials": trials_ms,
                "device": device_state(torch, dev) if rank == 0 else None,
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)

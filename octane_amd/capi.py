@@ -328,6 +328,21 @@ def band_partition(rows: int, nbands: int):
     return list(e) if rc == 1 else None
 
 
+def band_devices(nbands: int):
+    """Device of every band for a row-band solve on THIS box: with two or more GPUs visible the bands go round-robin over
+    real devices (min(nbands, count) of them, so that peer reads, cross-device events and peer copies over xGMI are what
+    runs); on a one-GPU box every band is a virtual band on device 0.  `OCTANE_TEST_DEVICES` (e.g. "0,0,1,1") overrides."""
+    env = os.environ.get("OCTANE_TEST_DEVICES")
+    if env:
+        ids = [int(t) for t in env.split(",") if t.strip() != ""]
+        return [ids[b % len(ids)] for b in range(nbands)]
+    n = int(lib().octane_device_count())
+    if n < 2:
+        return [0] * nbands
+    use = min(n, nbands)
+    return [b % use for b in range(nbands)]
+
+
 class TiledPlan:
     """One frame solved by `nbands` row bands, band b on devices[b] (ids may repeat: virtual bands on one GPU).
     Levels below `min_band_pixels` are solved redundantly by every band (include/octane_vof.h)."""

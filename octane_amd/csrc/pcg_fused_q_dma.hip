@@ -25,6 +25,14 @@
 #define Q_VMN 1         // phase 0 waits for the DMA only (vmcnt = the own loads issued since), not for the tile's own loads too:
                         // 0.2947 -> 0.2910 ms per launch at 5000^2 with the a2 switch, 0.3044 -> 0.2930 without it
 #endif
+#ifndef Q_VMCNT_W
+#define Q_VMCNT_W 18    // own register loads of a tile issued after the DMA: 9 per slot (r_u r_v a1 a4 a2 wx wy wy-above wx-west) ...
+#endif
+#ifndef Q_VMCNT_U
+#define Q_VMCNT_U 10    // ... 5 per slot where the weights are the constant -1
+#endif
+#define Q_STR2(x) #x
+#define Q_STR(x) Q_STR2(x)
 #ifndef Q_ROT
 #define Q_ROT 1         // rotate the tile columns by the round number when the column count divides the grid
 #endif
@@ -331,8 +339,12 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
             // The DMA was issued before this tile's own loads and loads return in order: once no more than the own loads issued since
             // (5 or 9 per slot, all unconditional) are outstanding, the DMA has landed -- the ring groups, which need nothing else,
             // then run under the own loads' latency.  (Q_VMN 0: wait for everything.)
-            if (Q_VMN) { if (UNITW) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // `s_setprio 0` (the priority every wave has anyway) directly after the wait is the MARKER tools/check_dma_wait.py looks for:
+            // it proves on the built code object that on every path at least N vector-memory instructions lie between the last
+            // global_load_lds and this wait (tests/test_capi_cpu.py; the compiler does not track the inline-asm DMA).
+            if (Q_VMN) { if (UNITW) asm volatile("s_waitcnt vmcnt(" Q_STR(Q_VMCNT_U) ")\n\ts_setprio 0" ::: "memory");
+                         else asm volatile("s_waitcnt vmcnt(" Q_STR(Q_VMCNT_W) ")\n\ts_setprio 0" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_setprio 0" ::: "memory");
             __syncthreads();
         } else if (!first) {
             constexpr int GW = TX / 4 + 2;                        // groups per staged row: one left, one right of the tile

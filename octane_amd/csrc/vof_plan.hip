@@ -7,6 +7,7 @@
 // a pyramid: the PCG stop test, alpha and beta live on the device (pcg_kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -687,6 +688,11 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         (void)hipEventRecord(pl->ev_t0, s);
     }
     HIP_TRY(hipMemsetAsync(pl->d_iters, 0, sizeof(long long), s));
+    // the abort word of the persistent solves is per RUN: cleared here, on the stream, before the first of them (a caller that
+    // drives the plan with device buffers and its own synchronisation never reaches persist_check, which used to be the only
+    // place that cleared it: one abort then made every later solve that polled 128 times give up at once); this run's value
+    // is copied to the host at the end of the run
+    if (pl->d_mid) HIP_TRY(hipMemsetAsync(static_cast<char *>(pl->d_mid) + 8, 0, sizeof(unsigned), s));
     double setup_ms = 0.;
 
     for (int k = 0; k < nlev; k++) {
@@ -760,7 +766,7 @@ extern "C" int octane_vof_plan_get_profile(octane_vof_plan *pl, octane_vof_profi
 
 // A persistent solve gives up when its workgroups cannot all become resident (its grid barrier is bounded): the flow of that
 // run is not valid.  Reported by every call that has synchronised with the run; the word is cleared so that the plan stays usable.
-static int persist_check(octane_vof_plan *pl)
+int octane::persist_check(octane_vof_plan *pl)
 {
     if (!pl->h_mid_abort || *pl->h_mid_abort == 0) return OCTANE_OK;
     *pl->h_mid_abort = 0;
@@ -768,6 +774,19 @@ static int persist_check(octane_vof_plan *pl)
     g_last_error = "a persistent PCG solve could not get all its workgroups resident within 0.25 s (another process with the same kind of "
                    "kernel on this GPU?): the result of this run is not valid; OCTANE_TUNE_PERSIST=0 selects one launch per iteration";
     return OCTANE_E_HIP;
+}
+
+// The row-band paths (vof_tiled.hip) run plan_level_solve themselves, not run_on_stream: they clear the word at the start of a
+// solve and fetch it at its end with these two, on the band's stream.
+int octane::persist_begin_run(octane_vof_plan *pl, hipStream_t s)
+{
+    if (pl->d_mid) HIP_TRY(hipMemsetAsync(static_cast<char *>(pl->d_mid) + 8, 0, sizeof(unsigned), s));
+    return OCTANE_OK;
+}
+int octane::persist_end_run(octane_vof_plan *pl, hipStream_t s)
+{
+    if (pl->d_mid) HIP_TRY(hipMemcpyAsync(pl->h_mid_abort, static_cast<char *>(pl->d_mid) + 8, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    return OCTANE_OK;
 }
 
 extern "C" int octane_vof_plan_wait(octane_vof_plan *pl)
@@ -823,8 +842,17 @@ extern "C" int octane_vof_plan_run(octane_vof_plan *pl, const float *img1, const
     return octane_vof_plan_solve(pl, img1, img2, u, v, u, v, mem, hip_stream);
 }
 
+static int plan_solve_attempt(octane_vof_plan *pl, const float *img1, const float *img2, const float *u0, const float *v0,
+                              float *u, float *v, int mem, void *hip_stream, int attempt);
+
 extern "C" int octane_vof_plan_solve(octane_vof_plan *pl, const float *img1, const float *img2, const float *u0, const float *v0,
                                      float *u, float *v, int mem, void *hip_stream)
+{
+    return plan_solve_attempt(pl, img1, img2, u0, v0, u, v, mem, hip_stream, 0);
+}
+
+static int plan_solve_attempt(octane_vof_plan *pl, const float *img1, const float *img2, const float *u0, const float *v0,
+                              float *u, float *v, int mem, void *hip_stream, int attempt)
 {
     if (!pl || !img1 || !img2 || !u || !v || ((u0 == nullptr) != (v0 == nullptr)) || (mem != OCTANE_MEM_HOST && mem != OCTANE_MEM_DEVICE)) {
         g_last_error = "octane_vof_plan_solve: invalid argument";
@@ -877,10 +905,24 @@ extern "C" int octane_vof_plan_solve(octane_vof_plan *pl, const float *img1, con
         if (cur < 0) return cur;
     }
     if (mem == OCTANE_MEM_HOST) {   // ref .cu:1432-1438
+        HIP_TRY(hipStreamSynchronize(s));             // the abort word of this run is on the host now
+        if (int rc = persist_check(pl)) {
+            // A persistent solve gave up (its workgroups did not all become resident in time: another process with the same kind
+            // of kernel on this GPU, or a pre-empted queue).  The caller's buffers are still intact (u / v, which may be the first
+            // guess, are written below only after this check), so solve the pair again with one launch per iteration, once; the
+            // plan stays that way.
+            if (!pl->use_persist || attempt > 0) return rc;
+            static std::atomic<int> said{0};
+            if (said.fetch_add(1) == 0)
+                fprintf(stderr, "octane: a persistent PCG solve was abandoned (GPU shared with another process?); solving again with one "
+                                "launch per iteration (OCTANE_TUNE_PERSIST=0 selects that from the start)\n");
+            pl->use_persist = 0;
+            if (pl->graph_exec) { (void)hipGraphExecDestroy(pl->graph_exec); pl->graph_exec = nullptr; }
+            return plan_solve_attempt(pl, img1, img2, u0, v0, u, v, mem, hip_stream, 1);
+        }
         HIP_TRY(hipMemcpy2DAsync(u, dense_row, pl->U[cur], pitched_row, dense_row, ny, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpy2DAsync(v, dense_row, pl->V[cur], pitched_row, dense_row, ny, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (int rc = persist_check(pl)) return rc;
     } else {
         launch_copy2d(s, pl->U[cur], p0, u, nx, nx, ny);
         launch_copy2d(s, pl->V[cur], p0, v, nx, nx, ny);

@@ -91,5 +91,12 @@ int  plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur, const 
 void plan_fill_level_ptrs(octane_vof_plan *pl, int k, int cur, const LevelCtx &c, LevelPtrs &L);
 // Upload (host) or copy (device) the inputs into the plan's planes on stream s / copy the flow of U[cur],V[cur] out.
 int  plan_load_inputs(octane_vof_plan *pl, const float *img1, const float *img2, const float *u, const float *v, int mem, hipStream_t s);
+// The abort word of the persistent mid-level solves (pcg_persist.hip) is per run: persist_begin_run clears it on the stream before the
+// run's first solve, persist_end_run copies it to the host at the run's end (both stream-ordered), and persist_check -- after the
+// host has synchronised with the run -- turns a raised word into OCTANE_E_HIP + octane_last_error and clears it.  run_on_stream
+// does the first two itself; the row-band paths, which call plan_level_solve directly, use these.
+int  persist_begin_run(octane_vof_plan *pl, hipStream_t s);
+int  persist_end_run(octane_vof_plan *pl, hipStream_t s);
+int  persist_check(octane_vof_plan *pl);
 
 }  // namespace octane

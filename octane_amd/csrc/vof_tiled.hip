@@ -80,6 +80,7 @@ struct octane_vof_tiled {
     int last_cur = 0;
     int loaded = 0;
     long long copies = 0;                       // peer copies issued by the last solve (diagnostic)
+    bool aborted = false;                       // a persistent mid-level solve of the last solve gave up: its flow is not valid
 };
 
 static int round_to(int v, int m) { return (v + m / 2) / m * m; }
@@ -218,6 +219,9 @@ extern "C" int octane_vof_tiled_band_rows(const octane_vof_tiled *t, int level, 
 extern "C" long long octane_vof_tiled_last_iterations(octane_vof_tiled *t)
 {
     if (!t) return -1;
+    if (t->aborted) return -2;                 // a persistent solve of the last solve gave up: see octane_vof_tiled_wait
+    for (int b = 0; b < t->nbands; b++)
+        if (t->pl[b]->h_mid_abort && *t->pl[b]->h_mid_abort != 0) return -2;
     return *t->pl[0]->h_iters;
 }
 
@@ -474,6 +478,8 @@ static void band_worker(BandNet &N, int b)
     const int nlev = (int)pl->lev.size();
     BAND_HIP(hipSetDevice(pl->device));
     BAND_HIP(hipMemsetAsync(pl->d_iters, 0, sizeof(long long), pl->own_stream));
+    // replicated levels run the persistent mid-level solve through plan_level_solve: its abort word is per run (vof_plan.hpp)
+    if (persist_begin_run(pl, pl->own_stream) != OCTANE_OK) N.fail(b, OCTANE_E_HIP, "clearing the persistent solve's abort word failed");
     pl->evs_used = 0;
     int cur = 0;
     LevelCtx ctx;
@@ -495,6 +501,7 @@ static void band_worker(BandNet &N, int b)
         }
     }
     if (b == 0) BAND_HIP(hipMemcpyAsync(pl->h_iters, pl->d_iters, sizeof(long long), hipMemcpyDeviceToHost, pl->own_stream));
+    if (persist_end_run(pl, pl->own_stream) != OCTANE_OK) N.fail(b, OCTANE_E_HIP, "fetching the persistent solve's abort word failed");
     BAND_HIP(hipGetLastError());
     N.cur[b] = cur;
 }
@@ -590,6 +597,7 @@ extern "C" int octane_vof_tiled_solve(octane_vof_tiled *t)
 {
     if (!t || !t->loaded) { set_last_error("octane_vof_tiled_solve: no inputs loaded"); return OCTANE_E_INVALID; }
     const int nb = t->nbands;
+    t->aborted = false;
     ThreadNet N(t);
     if (nb == 1) {
         band_worker(N, 0);
@@ -617,7 +625,16 @@ extern "C" int octane_vof_tiled_wait(octane_vof_tiled *t)
         TILED_TRY(hipSetDevice(t->dev[b]));
         TILED_TRY(hipStreamSynchronize(t->pl[b]->own_stream));
     }
-    return OCTANE_OK;
+    // A persistent solve of a replicated level that gave up on ANY band (its workgroups return without applying the update) makes
+    // the whole frame invalid: the bands no longer hold the same bits.  Every band's word is checked and cleared.
+    int rc = OCTANE_OK;
+    for (int b = 0; b < t->nbands; b++) {
+        TILED_TRY(hipSetDevice(t->dev[b]));
+        if (persist_check(t->pl[b]) != OCTANE_OK) rc = OCTANE_E_HIP;      // sets octane_last_error
+    }
+    if (rc != OCTANE_OK) t->aborted = true;
+    (void)hipSetDevice(t->dev[0]);
+    return t->aborted ? OCTANE_E_HIP : OCTANE_OK;
 }
 
 extern "C" int octane_vof_tiled_fetch(octane_vof_tiled *t, float *u, float *v, int mem)
@@ -696,6 +713,7 @@ struct octane_vof_mp {
     MpShared *shm = nullptr;
     int last_cur = 0;
     long long copies = 0;
+    bool aborted = false;          // a persistent mid-level solve of the last run gave up (on any rank): its flow is not valid
 };
 
 struct MpHandles { hipIpcMemHandle_t arena, parts; };
@@ -926,7 +944,7 @@ extern "C" int octane_vof_mp_banded_levels(const octane_vof_mp *m)
     return n;
 }
 
-extern "C" long long octane_vof_mp_last_iterations(octane_vof_mp *m) { return m ? *m->pl->h_iters : -1; }
+extern "C" long long octane_vof_mp_last_iterations(octane_vof_mp *m) { return !m ? -1 : m->aborted ? -2 : *m->pl->h_iters; }
 
 // Every rank passes the whole pair (host buffers, or dense device buffers on its own device) and the first guess; the
 // flow arrives in u / v on rank 0 only (other ranks' u / v are left alone).  Collective: every rank must call it.
@@ -951,11 +969,20 @@ extern "C" int octane_vof_mp_run(octane_vof_mp *m, const float *img1, const floa
         if (rc) N.fail(m->rank, rc, "loading the inputs failed");
     }
     N.sync(m->rank);                      // nobody's halo rows are written before everybody has its inputs in place
+    m->aborted = false;
     band_worker(N, m->rank);
+    // a persistent solve of a replicated level that gave up on this rank invalidates the frame for every rank: raise the group's
+    // failure flag before the closing boundary, so that all ranks return the error together
+    if (hipStreamSynchronize(pl->own_stream) == hipSuccess && persist_check(pl) != OCTANE_OK) {
+        m->aborted = true;
+        N.fail(m->rank, OCTANE_E_HIP, "a persistent PCG solve was abandoned (GPU shared with another process?): the flow of this run is not valid; "
+                                      "OCTANE_TUNE_PERSIST=0 selects one launch per iteration");
+    }
     N.sync(m->rank);
     m->copies = N.copies[m->rank];
     m->last_cur = N.cur[m->rank];
     if (N.failed()) {
+        m->aborted = true;                        // whatever failed: this run's flow and iteration count are not valid
         set_last_error("octane_vof_mp_run (rank " + std::to_string(m->rank) + "): " + (N.error.empty() ? std::string("another rank failed") : N.error));
         if (N.dead()) {                           // a rank is gone: no more synchronisation of any kind, the group is finished
             m->dead = true;

@@ -34,3 +34,7 @@ extern "C" void oct_ref_patch_match(const float *img1, const float *img2, float 
     args.srad = srad;
     oct_patch_match_optical_flow(const_cast<float *>(img1), const_cast<float *>(img2), u_inout, v_inout, nx, ny, args);
 }
+
+void oct_bandminmax(int gb, float &maxch, float &minch);   // ref src/oct_normalize_geo.cc:9 (the ABI band range table; bands it does not know leave both untouched)
+
+extern "C" void oct_ref_bandminmax(int gb, float *maxch, float *minch) { oct_bandminmax(gb, *maxch, *minch); }

@@ -79,12 +79,16 @@ static float sqf(float x) { return x * x; } /* ref .cu:43-47 jsq */
 /* ref .cu:727-747: the warped sampling position (ii + u, jj + v), clamped into the level, and the cell it falls into
  * (the last cell is xi-2 .. xi-1: a position on the last pixel samples that cell's far edge). */
 typedef struct warp_cell { float xw, yw; int x0, y0, hitx, hity; } warp_cell;
+/* float -> int as the DEVICE converts (cvt.rzi.s32.f32 on the reference's GPU, v_cvt_i32_f32 on gfx950): NaN gives 0, not the
+ * INT_MIN a host cast returns.  Only a flow that has already diverged to NaN gets here (the clamp passes NaN through, ref
+ * .cu:27-41); the device then samples cell 0 and carries the NaN on, where a host cast would index out of bounds. */
+static int device_f2i(float x) { return x != x ? 0 : (int)x; }
 static warp_cell warp_position(float px, float py, int xi, int yi)
 {
     warp_cell w;
     w.xw = clamp_coord(px, xi, &w.hitx);
     w.yw = clamp_coord(py, yi, &w.hity);
-    w.x0 = (int)w.xw; w.y0 = (int)w.yw;
+    w.x0 = device_f2i(w.xw); w.y0 = device_f2i(w.yw);
     if (w.x0 == xi - 1) w.x0 = xi - 2;
     if (w.y0 == yi - 1) w.y0 = yi - 2;
     return w;

@@ -1,7 +1,9 @@
 """One frame solved as row bands (BASELINE.json configs[3], SURVEY.md 8e "spatial tiles of one frame"), through the
-C-ABI (octane_vof_tiled_*).  A one-GPU box runs the bands as virtual ranks on the same device: the kernels, the band
-bookkeeping, the halo / partial exchanges and their ordering are exactly the ones several devices would run; only
-the copies are device-local instead of peer copies.
+C-ABI (octane_vof_tiled_*).  Every test takes its devices from capi.band_devices(nbands): with two or more GPUs visible
+the bands go round-robin over REAL devices (adjacent bands on different devices: in-kernel peer reads, LDS-DMA from the
+neighbour's planes, cross-device events, peer copies over xGMI), no edit needed; a one-GPU box runs the bands as virtual
+ranks on device 0 -- the kernels, the band bookkeeping, the halo / partial exchanges and their ordering are exactly the
+ones several devices would run; only the copies are device-local instead of peer copies.
 
 The banded solve computes the same global PCG as the plain plan -- same operator, same recurrences, same stop test
 -- and differs only in the summation order of the dot products, so it must sit as close to the plain result as
@@ -28,7 +30,7 @@ def _plain(capi, a, b, prm, u0=None, v0=None):
 
 def _tiled(capi, a, b, prm, nbands, min_band_pixels=1, u0=None, v0=None, devices=None):
     nc, ny, nx = (1,) + a.shape if a.ndim == 2 else a.shape
-    tp = capi.TiledPlan(nx, ny, nc, capi.FlowParams(**prm), nbands=nbands, devices=devices or [0] * nbands,
+    tp = capi.TiledPlan(nx, ny, nc, capi.FlowParams(**prm), nbands=nbands, devices=devices or capi.band_devices(nbands),
                         min_band_pixels=min_band_pixels)
     u, v = tp.run_host(a, b, u0, v0)
     info = dict(its=tp.last_iterations(), banded=tp.banded_levels, copies=tp.last_copies(),
@@ -134,7 +136,7 @@ def test_device_resident_inputs_and_repeated_solves(capi):
     tu, tv = torch.zeros(ny, nx, device=dev), torch.zeros(ny, nx, device=dev)
     ou, ov = torch.empty(ny, nx, device=dev), torch.empty(ny, nx, device=dev)
     torch.cuda.synchronize()
-    tp = capi.TiledPlan(nx, ny, 1, capi.FlowParams(**prm), nbands=2, devices=[0, 0], min_band_pixels=1)
+    tp = capi.TiledPlan(nx, ny, 1, capi.FlowParams(**prm), nbands=2, devices=capi.band_devices(2), min_band_pixels=1)
     tp.load_device(ta.data_ptr(), tb.data_ptr(), tu.data_ptr(), tv.data_ptr())
     for _ in range(2):
         tp.solve()
@@ -161,7 +163,7 @@ def test_full_disk_quarter_scale_four_bands(capi):
     torch.cuda.synchronize()
     up, vp, ip = ou.cpu().numpy(), ov.cpu().numpy(), pl.last_iterations()
     pl.close()
-    tp = capi.TiledPlan(n, n, 1, prm, nbands=4, devices=[0, 0, 0, 0])
+    tp = capi.TiledPlan(n, n, 1, prm, nbands=4, devices=capi.band_devices(4))
     assert tp.banded_levels == 1
     banded, y0, y1 = tp.band_rows(5, 2)
     assert banded and (y0, y1) == (2720, 4064)
@@ -199,7 +201,7 @@ def test_config3_full_disk_10848_four_bands_equals_plain_plan(capi):
     up, vp, ip = ou.clone(), ov.clone(), pl.last_iterations()
     pl.close()
     assert ip == 8 * 3 * 3 * 30
-    tp = capi.TiledPlan(n, n, 1, prm, nbands=4, devices=[0, 0, 0, 0])
+    tp = capi.TiledPlan(n, n, 1, prm, nbands=4, devices=capi.band_devices(4))
     nbanded = tp.banded_levels
     assert nbanded == 2                                   # 10848^2 and 5424^2 are above the default 12 Mpixel threshold
     tp.load_device(a.data_ptr(), b.data_ptr(), z.data_ptr(), z.data_ptr())
@@ -269,3 +271,30 @@ def test_copy_transport_equals_in_place_reads_bit_for_bit(capi, nx, ny, nbands, 
     assert info_c["banded"] == info_i["banded"] >= 1 and info_c["its"] == info_i["its"]
     assert info_c["copies"] > info_i["copies"]
     assert np.array_equal(ui, uc) and np.array_equal(vi, vc)
+
+
+def test_two_real_peers_in_place_and_copy_transports_agree(capi):
+    """Needs two GPUs (skips on a one-GPU box): two bands on devices 0 and 1, both transports -- the consuming kernel
+    dereferencing the neighbour's memory over xGMI (peer global_load_lds included: bands of 4.4 Mpixel run the LDS-DMA
+    q-recomputing kernel) and the stream-ordered peer copies -- against each other bit for bit and against the plain
+    plan on device 0; then the same bands as virtual bands on device 0: real peers must not change a bit."""
+    import os
+    if capi.lib().octane_device_count() < 2:
+        pytest.skip("one GPU visible: the row bands of this box are virtual bands (covered by every other test here)")
+    nx, ny, prm = 2432, 3584, dict(kiters=2, liters=1, cgiters=9)
+    a, b = synth.lattice_scene(nx, ny, seed=29)
+    up, vp, ip = _plain(capi, a, b, prm)
+    ui, vi, info_i = _tiled(capi, a, b, prm, 2, devices=[0, 1])
+    os.environ["OCTANE_TILED_TRANSPORT"] = "copy"
+    try:
+        uc, vc, info_c = _tiled(capi, a, b, prm, 2, devices=[0, 1])
+    finally:
+        del os.environ["OCTANE_TILED_TRANSPORT"]
+    uv, vv, info_v = _tiled(capi, a, b, prm, 2, devices=[0, 0])
+    print(f"REAL-PEERS {nx}x{ny}: in place vs copy {int((ui != uc).sum() + (vi != vc).sum())} values differ, "
+          f"real vs virtual bands {int((ui != uv).sum() + (vi != vv).sum())}, vs plain relL2 {rel_l2(ui, vi, up, vp):.2e}, "
+          f"iterations {info_i['its']}/{info_c['its']}/{info_v['its']}/{ip}")
+    assert info_i["banded"] == info_c["banded"] == 2 and info_i["its"] == info_c["its"] == info_v["its"] == ip
+    assert np.array_equal(ui, uc) and np.array_equal(vi, vc)
+    assert np.array_equal(ui, uv) and np.array_equal(vi, vv)
+    assert rel_l2(ui, vi, up, vp) < ORDER_BAR

@@ -55,6 +55,17 @@ def test_one_band_per_process_with_the_copy_transport():
     assert line and "ok=True" in line[0], outs[0]
 
 
+def test_an_abandoned_persistent_solve_fails_every_rank():
+    """the process form runs its replicated levels through the persistent mid-level solve as well.  With the
+    test hook on in both ranks the 320 x 250 level's solve is abandoned; both ranks' octane_vof_mp_run must return the error
+    together, last_iterations() must say -2, and the following run (hook off) must give the flow of the first one bit for bit."""
+    codes, outs = _run(2, (640, 500, 2, 1, 10, 200000, "fault"))
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    for o in outs:
+        line = [l for l in o.splitlines() if l.startswith("MP_FAULT_RESULT")]
+        assert line and "ok=True" in line[0], o
+
+
 def test_a_dead_rank_does_not_leave_the_survivor_spinning():
     """a rank that dies mid-run.  Two ranks solve in a loop; rank 1 is killed (its exact PID) while they run.
     Rank 0 must come back from octane_vof_mp_run with an error within the barrier's time-out (4 s here, 120 s by default)

@@ -194,3 +194,46 @@ def test_reference_binterp_and_bc_goldens_are_current(oracle, golden_bil):
         v = R.oct_ref_binterp_coefs(float(golden_bil["bil_px"][k]), float(golden_bil["bil_py"][k]), x0, x0 + 1, y0, y0 + 1,
                                     *(float(t) for t in golden_bil["bil_f"][k]), buf)
         assert v == golden_bil["bil_val"][k]
+
+
+def test_band_range_table_equals_the_reference_table(capi):
+    """`octane_bandminmax` (the C-ABI) and the C++ shim `oct_bandminmax` (liboctane_host.so, the reference's
+    own signature, ref src/oct_normalize_geo.cc:9) against the WHOLE table dumped from the reference source itself
+    (tests/golden/ref_bandminmax.npz, made by tests/golden/make_ref_bandminmax_goldens.py from oracle/_ref): bands 1 .. 16 bit
+    for bit -- the reference assigns double literals to floats --, and every band number outside 1 .. 16 leaves the caller's
+    values untouched in the shim (the reference's if-chain has no else) and is an error code in the C-ABI.  No GPU involved."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_bandminmax.npz"))
+    sentinel = np.float32(g["sentinel"])
+    host = os.path.join(os.path.dirname(capi.LIB_PATH), "liboctane_host.so")
+    shim = None
+    if os.path.exists(host):
+        capi.lib()                                   # liboctane_vof.so first: the shim links against it
+        shim = C.CDLL(host)._Z14oct_bandminmaxiRfS_   # void oct_bandminmax(int, float &, float &)
+        shim.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        shim.restype = None
+    known = 0
+    for band, mx, mn in zip(g["bands"], g["maxch"], g["minch"]):
+        untouched = mx == sentinel and mn == sentinel
+        if untouched:
+            with pytest.raises(capi.OctaneError) as e:
+                capi.bandminmax(int(band))
+            assert e.value.code == capi.E_INVALID
+        else:
+            known += 1
+            got = capi.bandminmax(int(band))
+            assert np.float32(got[0]).tobytes() == np.float32(mx).tobytes() and np.float32(got[1]).tobytes() == np.float32(mn).tobytes(), (band, got, mx, mn)
+        if shim is not None:
+            a, b = C.c_float(float(sentinel)), C.c_float(float(sentinel))
+            shim(int(band), C.byref(a), C.byref(b))
+            assert np.float32(a.value).tobytes() == np.float32(mx).tobytes() and np.float32(b.value).tobytes() == np.float32(mn).tobytes(), (band, a.value, b.value)
+    assert known == 16 and [int(b) for b, m in zip(g["bands"], g["maxch"]) if m != sentinel] == list(range(1, 17))
+    # re-checked against the live reference build wherever /root/reference exists
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "liboct_ref_helpers.so")
+    if os.path.isdir("/root/reference/src") and os.path.exists(ref):
+        R = C.CDLL(ref)
+        R.oct_ref_bandminmax.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        R.oct_ref_bandminmax.restype = None
+        for band, mx, mn in zip(g["bands"], g["maxch"], g["minch"]):
+            a, b = C.c_float(float(sentinel)), C.c_float(float(sentinel))
+            R.oct_ref_bandminmax(int(band), C.byref(a), C.byref(b))
+            assert a.value == mx and b.value == mn
