@@ -126,22 +126,27 @@ int octane_vof_plan_get_profile(octane_vof_plan *plan, octane_vof_profile *out);
  * defer_x, small, unit_w, fused, fused_q, fused_rows}.  Results agree for every setting to the last bits of the PCG
  * scalars (the grouping of the fp64 partial sums follows the grid); only speed changes. */
 int octane_vof_tune(octane_vof_plan *plan, const char *key, int value);
-/* Diagnostic: where the waves of one launch of the q-recomputing PCG kernel spend their time at pyramid level `level`: shader
- * clock cycles summed over all waves, per seam of a tile (out16[0..6]), tiles walked ([7]), prologue ([8]), epilogue ([9]).
- * even != 0 stamps a launch that also updates x.  The planes are clobbered.  No reference counterpart. */
-int octane_vof_plan_probe_stamps(octane_vof_plan *plan, int level, int even, int unit_w, unsigned long long *out16);
 /* Self-test of the persistent PCG kernel's three-instruction reciprocal (hardware estimate + one fused Newton step) against the
  * IEEE division on every positive normal float whose reciprocal is normal: out3 = {patterns compared, mismatches, one
  * mismatching bit pattern}.  No reference counterpart (the reference divides, ref .cu:141-149). */
 int octane_selftest_rcp(int device, unsigned long long *out3);
-/* Diagnostic: cycles per seam of an iteration of the persistent mid-level solve (stamped build, octane_vof_tune "persist_diag"),
- * summed over workgroups and iterations since the last call: 32 values, [0..15] interior sub-domains, [16..31] the predicated ones,
- * [14] / [30] = workgroups x iterations.  Clears the counters. */
-int octane_vof_mid_stamps(int device, unsigned long long *out32);
 /* Diagnostic: time `iterations` (>= 2) PCG iterations of pyramid level `level` (0 = coarsest) in isolation, on
  * whatever the plan's planes hold (the stop test is held open, values are irrelevant, the planes are clobbered).
  * With the one-kernel iteration (the default) its time comes back in *pass_a_ms and *pass_b_ms is 0. */
 int octane_vof_plan_probe(octane_vof_plan *plan, int level, int iterations, double *pass_a_ms, double *pass_b_ms);
+
+#ifdef OCTANE_DIAG
+/* ---- Diagnostic library only (liboctane_vof_diag.so, `make -C octane_amd/csrc DIAG=1`): the product library does not export these, does
+ * not contain the stamped kernel copies behind them, and rejects the tune keys "q_diag" / "persist_diag".  No reference counterpart. ---- */
+/* Diagnostic: where the waves of one launch of the q-recomputing PCG kernel spend their time at pyramid level `level`: shader
+ * clock cycles summed over all waves, per seam of a tile (out16[0..6]), tiles walked ([7]), prologue ([8]), epilogue ([9]).
+ * even != 0 stamps a launch that also updates x.  The planes are clobbered.  No reference counterpart. */
+int octane_vof_plan_probe_stamps(octane_vof_plan *plan, int level, int even, int unit_w, unsigned long long *out16);
+/* Diagnostic: cycles per seam of an iteration of the persistent mid-level solve (stamped build, octane_vof_tune "persist_diag"),
+ * summed over workgroups and iterations since the last call: 32 values, [0..15] interior sub-domains, [16..31] the predicated ones,
+ * [14] / [30] = workgroups x iterations.  Clears the counters. */
+int octane_vof_mid_stamps(int device, unsigned long long *out32);
+#endif  /* OCTANE_DIAG */
 
 /* Independent pairs sharded over GPUs: pair b runs on devices[b % ndevices]; one host thread per
  * device; no collective.  Pointer arrays have npairs entries of host buffers laid out as above. */

@@ -12,17 +12,23 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboctane_vof.so")
+# OCTANE_LIB selects another build of the same library (tools/build_variants.sh + tools/time_variants.py: A/B timing of kernel variants)
+LIB_PATH = os.environ.get("OCTANE_LIB") or os.path.join(_HERE, "liboctane_vof.so")
 
 OK, E_INVALID, E_NODEVICE, E_HIP, E_TOOSMALL, E_NOMEM = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1
 NAV_GEOS, NAV_POLAR, NAV_MERC = 0, 1, 2
 
-# every symbol include/octane_vof.h declares
+# the diagnostic library (make -C octane_amd/csrc DIAG=1: stamped copies of two kernels for tools/probe_stamps.py / probe_mid_stamps.py and
+# one GPU test; never the product) and what it exports on top of EXPORTS
+DIAG_LIB_PATH = os.path.join(_HERE, "liboctane_vof_diag.so")
+DIAG_EXPORTS = ("octane_vof_plan_probe_stamps", "octane_vof_mid_stamps")
+
+# every symbol include/octane_vof.h declares (outside its OCTANE_DIAG section)
 EXPORTS = (
     "octane_vof_default_params", "octane_vof_run", "octane_vof_release_cache", "octane_vof_plan_create", "octane_vof_plan_destroy",
     "octane_vof_plan_device_bytes", "octane_vof_plan_placement_trials", "octane_vof_plan_run", "octane_vof_plan_solve", "octane_vof_plan_wait", "octane_vof_plan_last_iterations",
-    "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_probe", "octane_vof_tune", "octane_selftest_rcp", "octane_vof_plan_probe_stamps", "octane_vof_mid_stamps",
+    "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_probe", "octane_vof_tune", "octane_selftest_rcp",
     "octane_vof_batch_run",
     "octane_vof_tiled_create", "octane_vof_tiled_destroy", "octane_vof_tiled_load", "octane_vof_tiled_solve",
     "octane_vof_tiled_wait", "octane_vof_tiled_fetch", "octane_vof_tiled_run", "octane_vof_tiled_banded_levels",

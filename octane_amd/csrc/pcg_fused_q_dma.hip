@@ -31,6 +31,22 @@
 #ifndef Q_VMCNT_U
 #define Q_VMCNT_U 10    // ... 5 per slot where the weights are the constant -1
 #endif
+#ifndef Q_TOUCH
+#define Q_TOUCH 0       // "use" (an empty asm) every register the tile's own loads wrote on the COLD paths that never consume them: a slot
+                        // beyond the ragged edge, a launch past the stop test.  Otherwise the compiler carries those loads as pending
+                        // into the next trip of the tile loop and -- not counting the inline-asm DMAs issued in between -- puts a
+                        // near-full `s_waitcnt vmcnt` at the TOP of the loop, before the next tile's own loads are even issued, and
+                        // `vmcnt(0)` into both arms of the a2 load: the 18 own loads of a tile then go out in three round trips
+#endif
+#ifndef Q_ABL
+#define Q_ABL 0         // ablation builds for tools/time_variants.py (wrong results, same memory pattern): 1 = no arithmetic (every LDS
+                        // and global access kept, sums of the loaded values instead of the operator, the reciprocals and the seven
+                        // sums): the ceiling of this access pattern; 2 = no ring (neither its DMA nor its groups); 4 = no phase 2
+#endif
+// see Q_TOUCH: an empty asm that takes every register the own loads of a slot wrote as an input
+#define Q_TOUCH_SLOT(slot) asm volatile("" :: "v"(*(const f4v *)c3[slot].a1), "v"(*(const f4v *)c3[slot].a2), "v"(*(const f4v *)c3[slot].a4), \
+                                        "v"(*(const f4v *)c3[slot].wx), "v"(*(const f4v *)c3[slot].wy), "v"(*(const f4v *)c3[slot].wys), "v"(c3[slot].wxw), \
+                                        "v"(*(const f4v *)r3u[slot]), "v"(*(const f4v *)r3v[slot]))
 #define Q_STR2(x) #x
 #define Q_STR(x) Q_STR2(x)
 #ifndef Q_ROT
@@ -71,6 +87,7 @@ __device__ __forceinline__ void st4_if(float *p, float4 v, bool nt) { if (nt) st
 // instructions instead of the division's eleven: four reciprocals per pixel and launch, 32 of the kernel's 236 lane-instructions.
 __device__ __forceinline__ float direction(float r, float pold, float diag, float beta, bool first)
 {
+    if (Q_ABL & 1) return r + pold + diag;
     float z = rcp_exact(diag) * r;
     return first ? z : beta * pold + z;
 }
@@ -95,6 +112,14 @@ __device__ __forceinline__ void stencil_group(const float *s_u, const float *s_v
     *(float4 *)nu = ld4(&s_u[(lrow + 1) * kQCols + lcol]); *(float4 *)nv = ld4(&s_v[(lrow + 1) * kQCols + lcol]);
     const float uwest = s_u[lrow * kQCols + lcol - 1], vwest = s_v[lrow * kQCols + lcol - 1];
     const float ueast = s_u[lrow * kQCols + lcol + 4], veast = s_v[lrow * kQCols + lcol + 4];
+    if (Q_ABL & 1) {       // every value read above takes part, nothing else is computed
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            qu[e] = cu[e] + su[e] + nu[e] + c.a1[e] + c.a2[e] + c.wx[e] + c.wys[e] + (e == 0 ? uwest + c.wxw : 0.f) + (e == 3 ? ueast : 0.f);
+            qv[e] = cv[e] + sv[e] + nv[e] + c.a4[e] + c.wy[e] + (e == 0 ? vwest : 0.f) + (e == 3 ? veast : 0.f);
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int i = x0 + e;
@@ -302,7 +327,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
         dma_cur = tile_is_interior(ftx0, fty0, w, h, y1);
         if (dma_cur) {
             dma_p_tile<BANDED>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ftx0, fty0, pitch, lane, wv);
-            dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ftx0, fty0, pitch, lane, wv);
+            if (!(Q_ABL & 2)) dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ftx0, fty0, pitch, lane, wv);
         }
     }
     for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1, round++) {
@@ -391,13 +416,13 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
                 dma_next = tile_is_interior(ntx0, nty0, w, h, y1);
                 if (dma_next) {
                     dma_p_tile<BANDED>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);
-                    dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ntx0, nty0, pitch, lane, wv);
+                    if (!(Q_ABL & 2)) dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ntx0, nty0, pitch, lane, wv);
                 }
             }
             dma_cur = dma_next;
         }
         // ---- phase 2: q_k on the tile and the partial sums (q_k is not stored: the next launch forms it again)
-        if (active) {
+        if (active && !(Q_ABL & 4)) {
             if (Q_P2 && interior) {
 #define Q_INT true
 #include "pcg_fused_q_phase2.inc"
@@ -407,6 +432,9 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
 #include "pcg_fused_q_phase2.inc"
 #undef Q_INT
             }
+        } else if (Q_TOUCH) {
+            // (a launch past the stop test skips phase 2: the loads phase 1 did not use -- the weights, when k = 0 -- count as used here)
+            Q_TOUCH_SLOT(0); Q_TOUCH_SLOT(1);
         }
     }
     if (!active) return;

@@ -1611,15 +1611,19 @@ int pcg_fused_grid_size(int w, int rows, int unit_w, int q_form)
     return g;
 }
 
-static int g_q_diag = 0;              // diagnostics: route whole-level q-form launches to the copy in pcg_fused_q_diag.hip
+#ifdef OCTANE_DIAG
+static int g_q_diag = 0;              // diagnostic build only: route whole-level q-form launches to the copy in pcg_fused_q_diag.hip
 void set_q_diag(int v) { g_q_diag = v != 0; }
+#endif
 static int g_q_dma = 1;               // q-form launches by the LDS-DMA form (pcg_fused_q_dma.hip): same bits, 9 % faster
 void set_q_dma(int v) { g_q_dma = v != 0; }
 void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
     const bool small = fused_rows(L.w, L.y1 - L.y0) == 1;
     const bool whole = L.nbands == 1 && L.y0 == 0 && L.y1 == L.h;
+#ifdef OCTANE_DIAG
     if (g_q_diag && L.q_form && whole) { launch_pcg_fused_q_diag(s, L, k, nparts_prev, grid, tol); return; }
+#endif
     if (g_q_dma && L.q_form) { launch_pcg_fused_q_dma(s, L, k, nparts_prev, grid, tol); return; }      // whole levels and row bands
     if (L.q_form) {                                                    // q = A p is not stored but formed again
         if (whole) {

@@ -169,7 +169,7 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.;
     double ms_out = -1.;
     bool ok = true;
-    std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> ev, fev;
     const bool split = a_ms && b_ms;
     if (split) {
         ev.resize(3 * (size_t)reps);
@@ -181,7 +181,11 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
         ok = ok && hipMemcpyAsync(pl->d_parts, ones.data(), (fused ? 2 * (size_t)kPartBlock : 2 * (size_t)kMaxParts) * sizeof(double), hipMemcpyHostToDevice, s) == hipSuccess;
         ok = ok && hipMemcpyAsync(pl->d_state, st, sizeof(st), hipMemcpyHostToDevice, s) == hipSuccess;
         if (fused) {       // the kernel the solve actually runs: one block of partials -> rz = 4 - 2 + 1 > 0, rr likewise
+            // timed launch by launch (an event pair each): the two small copies above are not part of the figure
+            if (fev.empty()) { fev.resize(2 * (size_t)reps); for (auto &e : fev) ok = ok && hipEventCreate(&e) == hipSuccess; }
+            ok = ok && hipEventRecord(fev[2 * (it - 1)], s) == hipSuccess;
             launch_pcg_fused(s, L, it + 1, 1, g_f, 0.f);
+            ok = ok && hipEventRecord(fev[2 * (it - 1) + 1], s) == hipSuccess;
             continue;
         }
         if (split) ok = ok && hipEventRecord(ev[3 * (it - 1)], s) == hipSuccess;
@@ -194,6 +198,11 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
     if (ok) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ms_out = ms / (reps - 1);
+        if (!fev.empty()) {        // the fused kernel's own time: mean over the launches after the warm-up
+            double sum = 0.;
+            for (int it = 2; it <= reps; it++) { float x = 0.f; (void)hipEventElapsedTime(&x, fev[2 * (it - 1)], fev[2 * (it - 1) + 1]); sum += x; }
+            ms_out = sum / (reps - 1);
+        }
         if (split) {
             double sa = 0., sb = 0.;
             for (int it = 2; it <= reps; it++) {
@@ -207,6 +216,7 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
         (void)hipGetLastError();
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
+    for (auto &e : fev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms_out;
 }
@@ -274,7 +284,9 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     }
     pcg_small_configure();
     pcg_mid_configure();
+#ifdef OCTANE_DIAG
     pcg_mid_configure_diag();
+#endif
     set_grid_multiple(pl->xcd_bands == 1 ? 8 : 1);
     memset(&pl->prof, 0, sizeof(pl->prof));
 
@@ -565,7 +577,9 @@ int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur
 // and everything one workgroup can hold goes to the single-workgroup solve, whose launches overlap freely.
 static void plan_lane_mode(octane_vof_plan *pl) { pl->persist_max_g = 16; pl->small_max_pixels = 6144; }
 static std::mutex g_persist_mu;
-static int g_persist_diag = 0;      // octane_vof_tune(plan, "persist_diag", 1): the stamped build of the persistent solve (diagnostic)
+#ifdef OCTANE_DIAG
+static int g_persist_diag = 0;      // octane_vof_tune(plan, "persist_diag", 1): the stamped build of the persistent solve (diagnostic library only)
+#endif
 static hipEvent_t g_persist_ev[64] = {nullptr};
 static int persist_launch(octane_vof_plan *pl, hipStream_t s, const LevelPtrs &L, const MidGeom &mg, unsigned seq, int k0, int k1, int kcap, int nparts_asm)
 {
@@ -576,7 +590,11 @@ static int persist_launch(octane_vof_plan *pl, hipStream_t s, const LevelPtrs &L
     } else if (hipStreamWaitEvent(s, g_persist_ev[d], 0) != hipSuccess) {
         g_last_error = "persistent solve: hipStreamWaitEvent failed"; return OCTANE_E_HIP;
     }
+#ifdef OCTANE_DIAG
     hipError_t e = (g_persist_diag ? launch_pcg_solve_mid_diag : launch_pcg_solve_mid)(s, L, mg, pl->d_mid, seq, k0, k1, kcap, nparts_asm, pl->tol);
+#else
+    hipError_t e = launch_pcg_solve_mid(s, L, mg, pl->d_mid, seq, k0, k1, kcap, nparts_asm, pl->tol);
+#endif
     if (e == hipSuccess) e = hipEventRecord(g_persist_ev[d], s);
     if (e != hipSuccess) { g_last_error = std::string("persistent solve: ") + hipGetErrorString(e); return OCTANE_E_HIP; }
     return OCTANE_OK;
@@ -1403,6 +1421,7 @@ extern "C" int octane_vof_plan_probe(octane_vof_plan *pl, int level, int iterati
     return OCTANE_OK;
 }
 
+#ifdef OCTANE_DIAG
 // Diagnostic: where the waves of one launch of the q-recomputing PCG kernel spend their time at pyramid level `level` (shader
 // clock cycles summed over all waves, per seam of a tile: pcg_kernels.hip, g_q_stamps).  even != 0 times a launch that also
 // updates x.  The planes are clobbered, values are irrelevant (stop test held open).
@@ -1435,8 +1454,11 @@ extern "C" int octane_vof_plan_probe_stamps(octane_vof_plan *pl, int level, int 
     return rc == 0 ? OCTANE_OK : OCTANE_E_HIP;
 }
 
+#endif  // OCTANE_DIAG
+
 // Self-test: the three-instruction reciprocal of pcg_persist.hip against the IEEE division on every positive normal float whose
 // reciprocal is normal.  out3 = {patterns compared, mismatches, a mismatching bit pattern}.
+#ifdef OCTANE_DIAG
 // Diagnostic: where thread 0 of the persistent solve's workgroups spent its shader-clock cycles since the last call (seams of an
 // iteration, pcg_persist.hip MID_STAMP; only launches made under octane_vof_tune(plan, "persist_diag", 1) count): 32 values, [0..15] the
 // sub-domains on the fast path, [16..31] the predicated ones; [14] / [30] = workgroups x iterations.  Clears the counters.
@@ -1447,6 +1469,8 @@ extern "C" int octane_vof_mid_stamps(int device, unsigned long long *out16)
     if (hipDeviceSynchronize() != hipSuccess) return OCTANE_E_HIP;
     return pcg_mid_stamps(nullptr, out16) == 0 ? OCTANE_OK : OCTANE_E_HIP;
 }
+
+#endif  // OCTANE_DIAG
 
 extern "C" int octane_selftest_rcp(int device, unsigned long long *out3)
 {
@@ -1472,13 +1496,15 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "unit_w") pl->use_unit_w = value != 0;
     else if (k == "fused") pl->use_fused = value != 0;
     else if (k == "fused_q") set_fused_q(value);
+#ifdef OCTANE_DIAG
     else if (k == "q_diag") set_q_diag(value);
+    else if (k == "persist_diag") g_persist_diag = value != 0;
+#endif
     else if (k == "q_dma") set_q_dma(value);
     else if (k == "persist") pl->use_persist = value != 0;
     else if (k == "persist_step") pl->persist_step = value;
     else if (k == "persist_p") pl->persist_p = value;
     else if (k == "persist_fault") set_mid_fault(value);
-    else if (k == "persist_diag") g_persist_diag = value != 0;
     else if (k == "persist_max_g") pl->persist_max_g = value;
     else if (k == "lane_mode") { if (value) plan_lane_mode(pl); else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 3072; } }
     else if (k == "fused_rows") set_fused_rows(value);

@@ -10,9 +10,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
+def _declared_symbols(diag=False):
+    """Functions include/octane_vof.h declares: outside its `#ifdef OCTANE_DIAG` section (the product library), or inside it."""
     text = open(os.path.join(ROOT, "include", "octane_vof.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    m = re.search(r"#ifdef OCTANE_DIAG(.*?)#endif", text, flags=re.S)
+    assert m, "include/octane_vof.h has lost its OCTANE_DIAG section"
+    text = m.group(1) if diag else text[:m.start()] + text[m.end():]
     return sorted(set(re.findall(r"\b(octane_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -23,6 +27,24 @@ def test_library_exports_every_declared_symbol(capi):
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/octane_vof.h but not exported"
     assert sorted(capi.EXPORTS) == declared
+
+
+def test_product_library_carries_no_diagnostics(capi):
+    """the stamped diagnostic copies of two kernels, their exports and their tune keys live in a library of their
+    own (liboctane_vof_diag.so, `make DIAG=1`); the product library has none of them -- no symbol, no kernel, no switch."""
+    import subprocess
+    L = capi.lib()
+    diag = _declared_symbols(diag=True)
+    assert sorted(capi.DIAG_EXPORTS) == diag and len(diag) == 2
+    for name in diag:
+        assert not hasattr(L, name), f"{name} is a diagnostic export and must not be in the product library"
+    syms = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    for needle in ("q_diag", "solve_mid_diag", "q_stamps", "mid_stamps"):
+        assert needle not in syms, needle
+    if os.path.exists(capi.DIAG_LIB_PATH):
+        D = C.CDLL(capi.DIAG_LIB_PATH)
+        for name in tuple(capi.EXPORTS) + tuple(capi.DIAG_EXPORTS):
+            assert hasattr(D, name), f"{name} missing from the diagnostic library"
 
 
 def test_default_params_are_the_reference_cli_defaults(capi):

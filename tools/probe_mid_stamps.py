@@ -1,6 +1,8 @@
 """Where thread 0 of the persistent mid-level solve's workgroups spends an iteration (shader-clock stamps at the seams,
 pcg_persist_diag.hip), next to the time per iteration of the production kernel.
 usage: probe_mid_stamps.py [size ...]"""
+import os as _os  # the stamped kernels live in the diagnostic library (make -C octane_amd/csrc DIAG=1), never in the product
+_os.environ.setdefault('OCTANE_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'octane_amd', 'liboctane_vof_diag.so'))
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,7 @@
 """A/B of tile walks / cache-policy hints of the q-recomputing PCG kernel (timing only: octane_vof_plan_probe holds the stop
 test open).  usage: probe_q.py size "xcd:nt,xcd:nt,..." [level]   e.g.  probe_q.py 5000 4:15,8:15,8:527"""
+import os as _os  # the stamped kernels live in the diagnostic library (make -C octane_amd/csrc DIAG=1), never in the product
+_os.environ.setdefault('OCTANE_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'octane_amd', 'liboctane_vof_diag.so'))
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from octane_amd import capi

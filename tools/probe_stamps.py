@@ -1,5 +1,7 @@
 """Where the waves of one launch of k_pcg_fused_q spend their time (shader-clock stamps at the seams of a tile).
 usage: probe_stamps.py [size]"""
+import os as _os  # the stamped kernels live in the diagnostic library (make -C octane_amd/csrc DIAG=1), never in the product
+_os.environ.setdefault('OCTANE_LIB', _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'octane_amd', 'liboctane_vof_diag.so'))
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from octane_amd import capi
