@@ -130,6 +130,15 @@ int octane_vof_tune(octane_vof_plan *plan, const char *key, int value);
  * IEEE division on every positive normal float whose reciprocal is normal: out3 = {patterns compared, mismatches, one
  * mismatching bit pattern}.  No reference counterpart (the reference divides, ref .cu:141-149). */
 int octane_selftest_rcp(int device, unsigned long long *out3);
+/* Self-test of the assembly kernel's fast exact forms for one alpha (ref assembly .cu:611-1097): the reference divides by alpha five
+ * or six times per pixel, takes 1 / (s + 1) three times per channel (Zimmer's normalisation) and 1 / sqrt(x + 1e-6) twice, all in double
+ * and rounded to float afterwards.  The library uses cheaper instruction sequences for these where -- and only where -- the
+ * sequence reproduces the IEEE result on EVERY float input for that alpha; this runs the comparison: out8 = {patterns, mismatches}
+ * x {x / alpha, all finite floats; 1 / (s + 1), all floats s >= 0; 1 / sqrt(x + 1e-6), all floats x >= 0}, [6] = a mismatching bit pattern,
+ * [7] = its test.  octane_selftest_assembly_math_bits: which forms (bit 0, 1, 2 in that order) plans with this alpha use; runs the
+ * self-test the first time an alpha is seen (~10 ms), exactly as plan creation does. */
+int octane_selftest_assembly_math(int device, double alpha, unsigned long long *out8);
+int octane_selftest_assembly_math_bits(int device, double alpha);
 /* Diagnostic: time `iterations` (>= 2) PCG iterations of pyramid level `level` (0 = coarsest) in isolation, on
  * whatever the plan's planes hold (the stop test is held open, values are irrelevant, the planes are clobbered).
  * With the one-kernel iteration (the default) its time comes back in *pass_a_ms and *pass_b_ms is 0. */

@@ -8,6 +8,10 @@
 // operator is kept as five coefficient planes instead of a CSR matrix.
 #include "vof_kernels.hpp"
 #include "device_util.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 
 namespace octane {
 
@@ -214,13 +218,49 @@ void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpi
 // ---------------------------------------------------------------------------------------
 constexpr int kAsmTX = 64, kAsmTY = 4;
 
+// psi'_s (ref .cu:73-80): (float)(1. / (double)y) with y = sqrtf(...) a float is the correctly rounded float reciprocal of y (see
+// jacobi_inv in device_util.hpp: double rounding is innocuous for a quotient of floats), which rcp_exact gives in three instructions
+// instead of an fp64 division; y >= 1e-3 is normal and so is its reciprocal.  (y = +inf -- a flow that has already diverged -- gives
+// NaN here and 0 there.)
 __device__ __forceinline__ float psi_smooth(float x)
 {
-    return (float)(1. / (double)sqrtf((float)((double)x + 1E-6)));
+    return rcp_exact(sqrtf((float)((double)x + 1E-6)));
 }
-__device__ __forceinline__ float psi_data(float x)
+// psi'_d (ref .cu:96-103) as the reference's expression compiles: IEEE square root, IEEE division, in double
+__device__ __forceinline__ float psi_data_ieee(float x)
 {
     return (float)(1. / sqrt((double)x + 1E-6));
+}
+// the same value from the hardware's reciprocal-square-root estimate and two Newton steps (7 fp64 instructions instead of ~30); used
+// only where assemble_math_selftest has found it equal to psi_data_ieee on every float x >= 0 (AssembleParams::fast_math bit 2)
+__device__ __forceinline__ float psi_data_fast(float x)
+{
+    const double d = (double)x + 1E-6;
+    double y = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d;
+    y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+    return (float)y;
+}
+// 1 / (s + 1) in double, rounded to float (the Zimmer normalisations, ref .cu:795-803), the reference's way ...
+__device__ __forceinline__ float rcp1p_ieee(float s) { return (float)(1. / ((double)s + 1.)); }
+// ... and from v_rcp_f64 + two Newton steps (5 fp64 instructions instead of ~14; fast_math bit 1, same proviso)
+__device__ __forceinline__ float rcp1p_fast(float s)
+{
+    const double d = (double)s + 1.;
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.), r, r);
+    return (float)r;
+}
+// x / alpha, correctly rounded, from the correctly rounded reciprocal of alpha: q = x * ralpha, then one step on the exact residual
+// x - alpha * q (Markstein).  Three fp64 instructions instead of ~14; fast_math bit 0: only after the self-test has compared it with
+// the division on every finite float x for THIS alpha.
+__device__ __forceinline__ double div_alpha_fast(double x, double alpha, double ralpha)
+{
+    const double q = x * ralpha;
+    // (a zero keeps its sign as the quotient does: the residual step would turn -0 into +0)
+    return q == 0. ? q : __builtin_fma(__builtin_fma(-alpha, q, x), ralpha, q);
 }
 __device__ __forceinline__ float sq(float x) { return x * x; }
 
@@ -236,6 +276,9 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
     const double al1 = P.al1, alpha = P.alpha, loa = P.loa;
     const float lambdac = P.lambdac;
     const bool quad_only = (al1 == 1.0), robust_only = (al1 == 0.0);
+    const double ralpha = P.ralpha;
+    const bool fdiv = (P.fast_math & 1) != 0, frcp = (P.fast_math & 2) != 0, frsq = (P.fast_math & 4) != 0;   // uniform
+    auto over_alpha = [&](float x) { return fdiv ? div_alpha_fast((double)x, alpha, ralpha) : (double)x / alpha; };
     double acc_rr = 0., acc_rz = 0.;
 
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -316,9 +359,8 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
             float IxIx = Ix * Ix, IyIy = Iy * Iy, IxxIxx = Ixx * Ixx, IxyIxy = Ixy * Ixy, IyyIyy = Iyy * Iyy;
             float na, nb, ncc;
             if (P.dozim) {
-                na = (float)(1. / ((double)(IxIx + IyIy) + 1.));
-                nb = (float)(1. / ((double)(IxxIxx + IxyIxy) + 1.));
-                ncc = (float)(1. / ((double)(IxyIxy + IyyIyy) + 1.));
+                if (frcp) { na = rcp1p_fast(IxIx + IyIy); nb = rcp1p_fast(IxxIxx + IxyIxy); ncc = rcp1p_fast(IxyIxy + IyyIyy); }
+                else { na = rcp1p_ieee(IxIx + IyIy); nb = rcp1p_ieee(IxxIxx + IxyIxy); ncc = rcp1p_ieee(IxyIxy + IyyIyy); }
             } else {
                 na = 1.f; nb = 1.f; ncc = 1.f;
             }
@@ -345,16 +387,16 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
         }
         float pd = 0.f, pd2 = 0.f;
         if (!quad_only) {
-            pd = (float)((double)psi_data(e1) / alpha);
-            pd2 = (float)(loa * (double)psi_data(e2));
+            pd = (float)over_alpha(frsq ? psi_data_fast(e1) : psi_data_ieee(e1));
+            pd2 = (float)(loa * (double)(frsq ? psi_data_fast(e2) : psi_data_ieee(e2)));
         }
         double qa1 = 0., qa2 = 0., qa4 = 0., qbu = 0., qbv = 0.;          // the quadratic terms
         if (!robust_only) {
-            qa1 = (double)t1 / alpha + loa * (double)g1 + (double)lambdac + (double)pstotq;
-            qa2 = (double)t2 / alpha + loa * (double)g2s;
-            qa4 = (double)t4 / alpha + loa * (double)g4 + (double)lambdac + (double)pstotq;
-            qbu = (double)t5 / alpha + loa * (double)g5 - (double)hint_u + (double)snuq - (double)(pstotq * uc);
-            qbv = (double)t6 / alpha + loa * (double)g6 - (double)hint_v + (double)snvq - (double)(pstotq * vc);
+            qa1 = over_alpha(t1) + loa * (double)g1 + (double)lambdac + (double)pstotq;
+            qa2 = over_alpha(t2) + loa * (double)g2s;
+            qa4 = over_alpha(t4) + loa * (double)g4 + (double)lambdac + (double)pstotq;
+            qbu = over_alpha(t5) + loa * (double)g5 - (double)hint_u + (double)snuq - (double)(pstotq * uc);
+            qbv = over_alpha(t6) + loa * (double)g6 - (double)hint_v + (double)snvq - (double)(pstotq * vc);
         }
         float a1, a2, a4, a7, a8, bu, bv;
         if (quad_only) {                    // 1 * q + 0 * r
@@ -439,6 +481,65 @@ int assemble_grid_size(int w, int h)
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid)
 {
     hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(256), 0, s, L, P);
+}
+
+// ---------------------------------------------------------------------------------------
+// Self-test of the assembly's fast exact forms (AssembleParams::fast_math): every float input, bit for bit against the IEEE sequence.
+// ---------------------------------------------------------------------------------------
+__global__ void k_selftest_asm_math(double alpha, double ralpha, unsigned long long *out)
+{
+    unsigned long long n0 = 0, b0 = 0, n1 = 0, b1 = 0, n2 = 0, b2 = 0, first = 0, which = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; b < 0x100000000ull; b += stride) {
+        const unsigned u = (unsigned)b;
+        const float x = __uint_as_float(u);
+        if ((u & 0x7F800000u) != 0x7F800000u) {          // x / alpha: every finite float, both signs, zeros and denormals included
+            const double want = (double)x / alpha, got = div_alpha_fast((double)x, alpha, ralpha);
+            n0++;
+            if (__double_as_longlong(want) != __double_as_longlong(got)) { if (!(b0 + b1 + b2)) { first = b; which = 0; } b0++; }
+        }
+        if (u < 0x7F800000u) {                           // s >= 0 finite: 1 / (s + 1) and 1 / sqrt(x + 1e-6)
+            n1++;
+            if (__float_as_uint(rcp1p_ieee(x)) != __float_as_uint(rcp1p_fast(x))) { if (!(b0 + b1 + b2)) { first = b; which = 1; } b1++; }
+            n2++;
+            if (__float_as_uint(psi_data_ieee(x)) != __float_as_uint(psi_data_fast(x))) { if (!(b0 + b1 + b2)) { first = b; which = 2; } b2++; }
+        }
+    }
+    atomicAdd(&out[0], n0); atomicAdd(&out[1], b0); atomicAdd(&out[2], n1); atomicAdd(&out[3], b1); atomicAdd(&out[4], n2); atomicAdd(&out[5], b2);
+    if (b0 + b1 + b2) { atomicMax(&out[6], first); atomicMax(&out[7], which); }
+}
+
+int assemble_fast_math_bits(double alpha)
+{
+    static std::mutex mu;
+    static std::map<double, int> known;
+    if (const char *e = getenv("OCTANE_TUNE_ASM_FAST")) { if (atoi(e) == 0) return 0; }
+    if (!(alpha > 0.) || !std::isfinite(alpha)) return 0;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = known.find(alpha);
+    if (it != known.end()) return it->second;
+    unsigned long long r[8] = {0};
+    int bits = 0;
+    if (assemble_math_selftest(nullptr, alpha, r) == 0) {
+        if (r[0] == 0xFF000000ull && r[1] == 0) bits |= 1;       // 2 x (2^31 - 2^23) finite floats
+        if (r[2] == 0x7F800000ull && r[3] == 0) bits |= 2;
+        if (r[4] == 0x7F800000ull && r[5] == 0) bits |= 4;
+    }
+    known[alpha] = bits;
+    return bits;
+}
+
+int assemble_math_selftest(hipStream_t s, double alpha, unsigned long long *out8)
+{
+    unsigned long long *d = nullptr;
+    if (hipMalloc((void **)&d, 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    int rc = -1;
+    if (hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), s) == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest_asm_math, dim3(8192), dim3(256), 0, s, alpha, 1. / alpha, d);
+        if (hipMemcpyAsync(out8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) rc = 0;
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 }  // namespace octane

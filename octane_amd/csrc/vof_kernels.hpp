@@ -88,9 +88,20 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
 
 struct AssembleParams {
     double al1, alpha, loa;   // GNC weight, alpha, lambda/alpha
+    double ralpha;            // the correctly rounded 1 / alpha (host division), for the three-instruction division by alpha
     float lambdac;
     int dozim;
+    int fast_math;            // bit 0: x / alpha as x * ralpha + one exact residual step; bit 1: 1 / (s + 1) by v_rcp_f64 + two Newton
+                              // steps; bit 2: 1 / sqrt(x + 1e-6) by v_rsq_f64 + two Newton steps.  Each bit is set only after the
+                              // form has reproduced the IEEE sequence of the reference on EVERY float input (assemble_math_selftest)
 };
+// Exhaustive device self-test of the three fast forms above against the divisions / square roots the reference's expressions compile
+// to, for this alpha: out8 = {patterns, mismatches} x {x / alpha over all finite floats x; 1 / (s + 1) over all floats s >= 0;
+// 1 / sqrt(x + 1e-6) over all floats x >= 0}, [6] = a mismatching bit pattern, [7] = its test.  Returns 0 when it ran.
+int  assemble_math_selftest(hipStream_t s, double alpha, unsigned long long *out8);
+// the bits of AssembleParams::fast_math that are safe for this alpha on the current device (runs the self-test once per process and
+// alpha; OCTANE_TUNE_ASM_FAST=0 turns all of them off)
+int  assemble_fast_math_bits(double alpha);
 
 void launch_copy2d(hipStream_t s, const float *src, int spitch, float *dst, int dpitch, int w, int h);
 void launch_scale_copy2d(hipStream_t s, const float *src, int spitch, float *dst, int dpitch, int w, int h, float scale);

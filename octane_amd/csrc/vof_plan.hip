@@ -288,6 +288,9 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     pcg_mid_configure_diag();
 #endif
     set_grid_multiple(pl->xcd_bands == 1 ? 8 : 1);
+    // the assembly's fast exact forms (three-instruction division by alpha etc.): each is used only if it reproduces the reference's
+    // IEEE sequence on every float input for THIS alpha -- a ~10 ms device self-test, once per process and alpha (vof_kernels.hip)
+    pl->asm_fast = assemble_fast_math_bits(p->alpha);
     memset(&pl->prof, 0, sizeof(pl->prof));
 
     const float scale = (float)p->scaleF;
@@ -631,6 +634,8 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
         ap.loa = prm.lambda / prm.alpha;                // ref .cu:1230
         ap.lambdac = li.lambdac;
         ap.dozim = prm.dozim != 0;
+        ap.ralpha = 1. / prm.alpha;                     // correctly rounded (host division)
+        ap.fast_math = pl->asm_fast;
         L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;   // al1 == 1: all neighbour weights are exactly -1
         L.lean = (pl->use_fused && !small && !pl->trace) ? 1 : 0;
         const int g_a = L.unit_w ? g_a_unit : g_a_plain;
@@ -1471,6 +1476,22 @@ extern "C" int octane_vof_mid_stamps(int device, unsigned long long *out16)
 }
 
 #endif  // OCTANE_DIAG
+
+// Self-test of the assembly's fast exact forms for `alpha` (vof_kernels.hip, assemble_math_selftest): out8 = {patterns, mismatches} of
+// x / alpha on every finite float x, of 1 / (s + 1) on every float s >= 0, of 1 / sqrt(x + 1e-6) on every float x >= 0 -- each against the
+// IEEE division / square root the reference's expression compiles to --, [6] a mismatching bit pattern, [7] which test it belongs to.
+// A form with a mismatch is not used by plans with that alpha (octane_selftest_assembly_math_bits says which are).
+extern "C" int octane_selftest_assembly_math(int device, double alpha, unsigned long long *out8)
+{
+    if (!out8) return OCTANE_E_INVALID;
+    HIP_TRY(hipSetDevice(device));
+    return assemble_math_selftest(nullptr, alpha, out8) == 0 ? OCTANE_OK : OCTANE_E_HIP;
+}
+extern "C" int octane_selftest_assembly_math_bits(int device, double alpha)
+{
+    if (hipSetDevice(device) != hipSuccess) return OCTANE_E_HIP;
+    return assemble_fast_math_bits(alpha);
+}
 
 extern "C" int octane_selftest_rcp(int device, unsigned long long *out3)
 {

@@ -398,6 +398,8 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
         ap.loa = prm.lambda / prm.alpha;                // ref .cu:1230
         ap.lambdac = li.lambdac;
         ap.dozim = prm.dozim != 0;
+        ap.ralpha = 1. / prm.alpha;                     // correctly rounded (host division)
+        ap.fast_math = pl->asm_fast;
         L.unit_w = (pl->use_unit_w && gnc == 0) ? 1 : 0;
         L.lean = fused ? 1 : 0;
         const int g_f = pcg_fused_grid_size(li.w, maxrows, L.unit_w, L.q_form);

@@ -754,3 +754,34 @@ int oct_oracle_vof(const float *img1, const float *img2, int nx, int ny, int nc,
     free(W.z); free(W.p); free(W.rk); free(W.tmp); free(W.ident); free(x);
     return (int)(total_cg > 2000000000L ? 2000000000L : total_cg);
 }
+
+/* Test hook: is (float)(1. / (double)y) -- how the reference forms 1 / M (ref .cu:141-149) and the psi' functions (.cu:80) -- the
+ * correctly rounded float reciprocal 1.0f / y?  Compared on every positive normal float; returns the number of mismatches (0: rounding
+ * a quotient of two 24-bit numbers to 53 bits first cannot change its rounding to 24).  This is what lets the HIP path use a float
+ * reciprocal (rcp_exact, checked equal to 1.0f / y on the device) where the reference goes through double. */
+/* (volatile, not inlined: gcc knows the theorem too -- it narrows (float)(1. / (double)y) to a float division by itself and would then
+ * compare the float division with itself; the double quotient has to exist as a double) */
+__attribute__((noinline)) static unsigned int reciprocal_bits_via_double(unsigned int u)
+{
+    float y, a; memcpy(&y, &u, 4);
+    volatile double d = (double)y;
+    volatile double q = 1. / d;
+    a = (float)q; memcpy(&u, &a, 4); return u;
+}
+__attribute__((noinline)) static unsigned int reciprocal_bits_in_float(unsigned int u)
+{
+    float y; memcpy(&y, &u, 4);
+    volatile float a = 1.0f / y;
+    float r = a; memcpy(&u, &r, 4); return u;
+}
+long long oct_oracle_check_reciprocal_double_rounding(long long *compared)
+{
+    long long bad = 0, n = 0;
+    #pragma omp parallel for reduction(+:bad,n) schedule(static)
+    for (long long b = 0x00800000LL; b < 0x7F800000LL; b++) {
+        n++;
+        if (reciprocal_bits_via_double((unsigned int)b) != reciprocal_bits_in_float((unsigned int)b)) bad++;
+    }
+    if (compared) *compared = n;
+    return bad;
+}

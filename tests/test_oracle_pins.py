@@ -237,3 +237,19 @@ def test_band_range_table_equals_the_reference_table(capi):
             a, b = C.c_float(float(sentinel)), C.c_float(float(sentinel))
             R.oct_ref_bandminmax(int(band), C.byref(a), C.byref(b))
             assert a.value == mx and b.value == mn
+
+
+def test_float_reciprocal_through_double_is_the_float_division(oracle):
+    """The reference forms 1 / M and the psi' functions as (float)(1. / (double)y) (ref .cu:80,141-149); the HIP path uses a float
+    reciprocal (rcp_exact: v_rcp_f32 + one fused Newton step, compared with 1.0f / y on every float by octane_selftest_rcp).  The two
+    are the same number for EVERY positive normal float: a quotient of two 24-bit significands rounded to 53 bits and then to 24
+    rounds as it would at once (53 >= 2 * 24 + 2).  Checked here by brute force on the host -- all 2 130 706 432 of them, a few
+    seconds with OpenMP -- with the non-inlined C of oracle/vof_oracle.c, so round 2's "1 ulp with probability 2^-29" caveat
+    about the preconditioner is gone: the probability is zero."""
+    L = oracle.lib("omp")
+    L.oct_oracle_check_reciprocal_double_rounding.restype = C.c_longlong
+    L.oct_oracle_check_reciprocal_double_rounding.argtypes = [C.POINTER(C.c_longlong)]
+    n = C.c_longlong()
+    bad = L.oct_oracle_check_reciprocal_double_rounding(C.byref(n))
+    print(f"(float)(1. / (double)y) vs 1.0f / y on {n.value} positive normal floats: {bad} mismatches")
+    assert n.value == 0x7F800000 - 0x00800000 and bad == 0
