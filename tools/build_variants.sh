@@ -11,7 +11,7 @@ one() {
   occ=$(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -Wall -Wno-unused-function $f \
         -Rpass-analysis=kernel-resource-usage -c pcg_fused_q_dma.hip -o /tmp/octane_vb/$n.o 2>&1 |
         grep -E " VGPRs:|Occupancy|AGPRs:" | sed 's/.*remark: *//; s/\[-Rpass.*//' | tr -s ' ' | tr '\n' ' ')
-  objs=$(ls *.o | grep -v pcg_fused_q_dma.o | tr '\n' ' ')
+  objs=$(ls *.o | grep -v "pcg_fused_q_dma.o\|\.diag\.o" | tr '\n' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/$n.so $objs /tmp/octane_vb/$n.o -lpthread
   echo "$n [$f] $occ"
 }
