@@ -41,7 +41,8 @@
 #ifndef Q_ABL
 #define Q_ABL 0         // ablation builds for tools/time_variants.py (wrong results, same memory pattern): 1 = no arithmetic (every LDS
                         // and global access kept, sums of the loaded values instead of the operator, the reciprocals and the seven
-                        // sums): the ceiling of this access pattern; 2 = no ring (neither its DMA nor its groups); 4 = no phase 2
+                        // sums): the ceiling of this access pattern; 2 = no ring (neither its DMA nor its groups); 4 = no phase 2; 8 = no tiles at
+                        // all (what a launch costs before and after its tile loop: the fold of the partial sums, the final reduction)
 #endif
 // see Q_TOUCH: an empty asm that takes every register the own loads of a slot wrote as an input
 #define Q_TOUCH_SLOT(slot) asm volatile("" :: "v"(*(const f4v *)c3[slot].a1), "v"(*(const f4v *)c3[slot].a2), "v"(*(const f4v *)c3[slot].a4), \
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     __shared__ __attribute__((aligned(16))) float s_ring[kRingOps * kRingGroups * 4];
     const int tid = threadIdx.x;
     const bool first = (k == 0);
+    if (Q_ABL & 16) return;                                   // (ablation: what an empty launch of this grid costs)
 
     const PcgState prev = L.st[k & 1];
     if (prev.stopped) {
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
         rz_new = (float)t[0]; rr = (float)t[1];
     } else {
         double t[kPartKinds];
-        fold_band_partials_multi_256<kPartKinds>(L.band_parts, pin_off, kMaxParts, nparts_prev, L.nbands, s_red, t);
+        if (Q_ABL & 32) { t[0] = 4.; t[1] = 4.; t[2] = 1.; t[3] = 1.; t[4] = 1.; t[5] = 1.; t[6] = 1.; }      // (ablation: no fold)
+        else fold_band_partials_multi_256<kPartKinds>(L.band_parts, pin_off, kMaxParts, nparts_prev, L.nbands, s_red, t);
         const double rzd = t[0], rrd = t[1], pq = t[2], qz = t[3], qmq = t[4], rq = t[5], qq = t[6];
         alpha = prev.rz / (float)pq;                 // ref .cu:1169
         nalpha = (float)(-1. * (double)alpha);       // ref .cu:1174
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
             if (!(Q_ABL & 2)) dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ftx0, fty0, pitch, lane, wv);
         }
     }
-    for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1, round++) {
+    for (int t = (Q_ABL & 8) ? tr.end : tr.first; t < tr.end; t += tr.step, parity ^= 1, round++) {
         float *const s_nu = s_nu2 + parity * NSZ, *const s_nv = s_nv2 + parity * NSZ;
         const int tx0 = ((t % tiles_x + (rotate ? round : 0)) % tiles_x) * TX, ty0 = y0 + (t / tiles_x) * TY;
         // ---- loads of the thread's two tile groups first (r_{k-1} and the operator; addresses of groups beyond a ragged

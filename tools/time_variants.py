@@ -87,7 +87,7 @@ def main():
             d = json.loads(line[0][7:])
             res[n].append(d)
             print(f"{args.size} rep {rep} {n:10s} probe {d['probe_us']:7.2f} us" + (f"  solve {d['solve_us']:7.2f} us ({d['launches']} launches, {d['iters']} iterations, flow {d['hash']})" if "solve_us" in d else "")
-                  + f"  placement trials min {min(d['trials_ms']):.4f} ms", flush=True)
+                  + (f"  placement trials min {min(d['trials_ms']):.4f} ms" if d['trials_ms'] else ""), flush=True)
     ref = None
     print(f"--- summary at {args.size}^2 (best of {args.reps})")
     for n in names:
