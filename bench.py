@@ -17,8 +17,8 @@ The JSON line also carries
   value_with_transfers -- SURVEY 8d's primary metric: one oct_variational_optical_flow-shaped call on HOST buffers
                    (H2D + all levels + D2H through octane_vof_run), pageable and pinned; never `value`;
   placement_trials -- min / median / max over the candidate arenas the plan timed when it was created (the headline is a
-                   best-of-n-placements figure).  A trial is a few PCG iterations driven from the host WITH two
-                   small H2D copies each: comparable among the candidates only, NOT with roofline.avg_launch_ms;
+                   best-of-n-placements figure).  A trial is a few PCG launches with the stop test held open
+                   (varying weights, x work every second launch: 64 B/pixel), each timed by an event pair;
   roofline      -- dominant kernel (the fused, q-recomputing PCG iteration at the finest level, k_pcg_fused_q_dma): its
                    algorithmic bytes per launch (r p a1 a2 a4 wx wy read, r p written = 52 B/pixel; every second launch
                    + x and the p before last read, x written = 76; mean 64, and 8 less in the first GNC step, whose
@@ -486,9 +486,9 @@ def main():
     plan = capi.Plan(n, n, 1, prm)
     tr = sorted(t for t in plan.placement_trials() if t > 0)
     trials_ms = {"n": len(tr), "min_ms": round(tr[0], 4), "median_ms": round(tr[len(tr) // 2], 4), "max_ms": round(tr[-1], 4),
-                 "what": "ms per trial PCG iteration of each candidate arena INCLUDING two small host-to-device copies per iteration "
-                         "(vof_plan.hip, placement trials): comparable among the candidates only; the kernel's own launch time is "
-                         "roofline.avg_launch_ms"} if tr else None
+                 "what": "ms per launch of the trial PCG iterations on each candidate arena (stop test held open, varying weights, x work "
+                         "in every second launch: 64 B/pixel against 61.3 in a solve's mix; an event pair per launch since round 3): "
+                         "comparable among the candidates; the solve's own mean launch time is roofline.avg_launch_ms"} if tr else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -629,6 +629,13 @@ def main():
                "sample": f"{m}x{m} lattice pair, kiters={ck} liters={args.liters} cgiters={args.cgiters} "
                          f"({cits} PCG iterations) in {ct:.1f} s on {cores} host cores (OpenMP); Mpix/s scaled by {scale:.4f} "
                          f"(level-pixel sums of {ck} vs {args.kiters} levels)"}
+        # the same oracle on the WHOLE configuration, measured once on a GPU box's host cores (too long for every bench run): the sample
+        # above flatters the CPU -- at 5000^2 its CSR matrix (284 B/pixel, 7 GB) no longer fits the caches the 3072^2 sample enjoys
+        try:
+            if (n, args.kiters, args.liters, args.cgiters) == (5000, 8, 3, 30):
+                cpu["full_config_measured_once"] = json.load(open(os.path.join(ROOT, "profiles", "r3_cpu_baseline_r1.json")))
+        except (OSError, ValueError):
+            pass
 
     if rank == 0:
         out = {"metric": "Mpix/s (full pyramid) at %dx%d" % (n, n), "value": round(value, 3), "unit": "Mpix/s",
