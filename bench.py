@@ -562,12 +562,29 @@ def main():
                                  "kernel; NOT measured in this run)" % tj.get("commit", tj[tk].get("commit", "unknown commit"))
         except (OSError, ValueError):
             pass
+        # the four kinds of finest-level launch, each priced on its own bytes (q-recomputing kernel; launch k of a solve: k = 0 forms no
+        # q and reads no p; even k > 0 applies two x updates -- x and the p before last in, x out; the first GNC step reads no weights)
+        by_kind = None
+        lt = plan.launch_times()
+        per_solve = args.cgiters
+        if fused and qform and per_solve >= 4 and len(lt) == 3 * args.liters * per_solve:
+            acc = {}
+            for i, ms_i in enumerate(lt):
+                k, gnc0 = i % per_solve, (i // per_solve) // args.liters == 0
+                if k == 0:
+                    continue                                   # the first launch of a solve is a kind of its own (no stencil, no p)
+                xwork = (k % 2 == 0)
+                b_px = (52 + (24 if xwork else 0)) - (8 if (gnc0 and unit_w) else 0)
+                key = ("first GNC step (weights -1, not read)" if (gnc0 and unit_w) else "varying weights") + (", with x work" if xwork else ", without x work")
+                a = acc.setdefault(key, [0.0, 0, b_px]); a[0] += ms_i; a[1] += 1
+            by_kind = {key: {"launches": c, "bytes_per_pixel": b_px, "avg_launch_ms": round(t / c, 4),
+                             "frac": round(b_px * n * n / (t / c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for key, (t, c, b_px) in acc.items()}
         achieved = bpp * n * n / (dms * 1e-3) / 1e9
         iter_gbs = 116 * n * n / (iter_ms * 1e-3) / 1e9
         survey_bpp = 116 if fused else (60 if dom == "k_pcg_pass_a" else 56)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "avg_launch_ms": round(dms, 4), "bytes_per_launch": int(round(bpp * n * n)),
+                "avg_launch_ms": round(dms, 4), "bytes_per_launch": int(round(bpp * n * n)), "by_kind_of_launch": by_kind,
                 "pcg_iteration_ms": round(iter_ms, 4),
                 # one whole PCG iteration on SURVEY 8(d)'s accounting (116 B/px: pass A with seven coefficient planes + pass B).
                 # This implementation moves 64 (fused kernel, five planes, x every second launch, q formed twice instead of stored;

@@ -122,6 +122,11 @@ typedef struct octane_vof_profile {
 } octane_vof_profile;
 int octane_vof_plan_set_profiling(octane_vof_plan *plan, int enable);
 int octane_vof_plan_get_profile(octane_vof_plan *plan, octane_vof_profile *out);
+/* The finest-level PCG launches of the last profiled run, one duration (ms) each, in launch order: solve after solve (3 GNC steps x
+ * liters solves), cgiters launches per solve.  Launch k of a solve moves other bytes than launch k + 1 (x is updated by every second
+ * launch, the first GNC step's weights are the constant -1 and are not read): bench.py prices each kind on its own bytes.  Returns
+ * the number of launches recorded; writes min(that, cap) values. */
+int octane_vof_plan_get_launch_times(octane_vof_plan *plan, float *ms, int cap);
 /* Developer knob (what the OCTANE_TUNE_* environment variables set): key in {pass_a, max_blocks, reverse_b, xcd, nt,
  * defer_x, small, unit_w, fused, fused_q, fused_rows}.  Results agree for every setting to the last bits of the PCG
  * scalars (the grouping of the fp64 partial sums follows the grid); only speed changes. */

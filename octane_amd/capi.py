@@ -28,7 +28,7 @@ DIAG_EXPORTS = ("octane_vof_plan_probe_stamps", "octane_vof_mid_stamps")
 EXPORTS = (
     "octane_vof_default_params", "octane_vof_run", "octane_vof_release_cache", "octane_vof_plan_create", "octane_vof_plan_destroy",
     "octane_vof_plan_device_bytes", "octane_vof_plan_placement_trials", "octane_vof_plan_run", "octane_vof_plan_solve", "octane_vof_plan_wait", "octane_vof_plan_last_iterations",
-    "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_probe", "octane_vof_tune", "octane_selftest_rcp", "octane_selftest_assembly_math", "octane_selftest_assembly_math_bits",
+    "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_get_launch_times", "octane_vof_plan_probe", "octane_vof_tune", "octane_selftest_rcp", "octane_selftest_assembly_math", "octane_selftest_assembly_math_bits",
     "octane_vof_batch_run",
     "octane_vof_tiled_create", "octane_vof_tiled_destroy", "octane_vof_tiled_load", "octane_vof_tiled_solve",
     "octane_vof_tiled_wait", "octane_vof_tiled_fetch", "octane_vof_tiled_run", "octane_vof_tiled_banded_levels",
@@ -144,6 +144,7 @@ def lib() -> C.CDLL:
     L.octane_vof_plan_set_trace.argtypes = [vp, TRACE_FN, vp]
     L.octane_vof_plan_set_profiling.argtypes = [vp, C.c_int]
     L.octane_vof_plan_get_profile.argtypes = [vp, C.POINTER(VofProfile)]
+    L.octane_vof_plan_get_launch_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.octane_vof_tune.argtypes = [vp, C.c_char_p, C.c_int]
     L.octane_vof_plan_probe.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.octane_selftest_assembly_math.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_ulonglong)]
@@ -320,6 +321,15 @@ class Plan:
         if rc != OK:
             raise OctaneError(rc, "octane_vof_plan_probe")
         return a.value, b.value
+
+    def launch_times(self):
+        """ms of every finest-level PCG launch of the last profiled run, in launch order."""
+        n = lib().octane_vof_plan_get_launch_times(self._h, None, 0)
+        if n <= 0:
+            return []
+        buf = (C.c_float * n)()
+        lib().octane_vof_plan_get_launch_times(self._h, buf, n)
+        return list(buf)
 
     def profile(self) -> VofProfile:
         p = VofProfile()

@@ -764,10 +764,11 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         (void)hipEventElapsedTime(&ms, pl->ev_t0, pl->ev_t1);
         pr.total_ms = ms; pr.setup_ms = setup_ms;
         pr.finest_pixels = (long long)pl->nx * pl->ny;
+        pl->pcg_launch_ms.clear();
         for (size_t i = 0; i < pl->evs_used; i++) {
             (void)hipEventElapsedTime(&ms, pl->evs[i].a, pl->evs[i].b);
             switch (pl->evs[i].kind) {
-            case EV_PASS_A: pr.pass_a_ms += ms; pr.pass_a_launches++; break;
+            case EV_PASS_A: pr.pass_a_ms += ms; pr.pass_a_launches++; pl->pcg_launch_ms.push_back(ms); break;
             case EV_PASS_B: pr.pass_b_ms += ms; pr.pass_b_launches++; break;
             case EV_ASM: pr.assemble_ms += ms; pr.assemble_launches++; break;
             default: pr.update_ms += ms; pr.update_launches++; break;
@@ -785,6 +786,16 @@ extern "C" int octane_vof_plan_get_profile(octane_vof_plan *pl, octane_vof_profi
     if (!pl || !out) return OCTANE_E_INVALID;
     *out = pl->prof;
     return OCTANE_OK;
+}
+
+// The finest-level PCG launches of the last profiled run, one duration each, in launch order (solve after solve: 3 GNC steps x liters
+// solves of cgiters launches); returns how many there are and writes the first min(count, cap) into ms.
+extern "C" int octane_vof_plan_get_launch_times(octane_vof_plan *pl, float *ms, int cap)
+{
+    if (!pl || (cap > 0 && !ms)) return OCTANE_E_INVALID;
+    const int n = (int)pl->pcg_launch_ms.size();
+    for (int i = 0; i < n && i < cap; i++) ms[i] = pl->pcg_launch_ms[i];
+    return n;
 }
 
 // A persistent solve gives up when its workgroups cannot all become resident (its grid barrier is bounded): the flow of that

@@ -71,6 +71,7 @@ struct octane_vof_plan {
     void *d_mid = nullptr;         // workspace of the persistent solve (abort word, granules of partial sums and edge pixels)
     unsigned mid_seq = 1;          // solves issued on that workspace: part of the granules' tags
     unsigned *h_mid_abort = nullptr;   // pinned copy of the abort word, refreshed at the end of every run
+    std::vector<float> pcg_launch_ms;   // the finest-level PCG launches of the last profiled run, in launch order
     int asm_fast = 0;    // AssembleParams::fast_math: the fast exact forms the device self-test has cleared for this plan's alpha
     int ntrials = 0;     // placement trials made when the plan was created, and what each candidate arena measured
     double trial_ms[8] = {0};
