@@ -242,6 +242,13 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         return OCTANE_E_INVALID;
     }
     *out = nullptr;
+    // the kernels address a plane with 32-bit byte offsets (one VGPR of offset shared by all planes): a plane has to stay below 4 GiB,
+    // i.e. below 2^30 pixels incl. the row padding (32768 x 32752 would be the first frame too large; the reference's int indices
+    // (.cu:613) give out at 2^31 / 12 CSR entries per pixel, 13377 x 13377, long before)
+    if ((unsigned long long)round_up(nx, 64) * (unsigned long long)ny >= (1ull << 30)) {
+        g_last_error = "octane_vof_plan_create: frame too large (a plane of round_up(nx, 64) x ny floats has to stay below 4 GiB)";
+        return OCTANE_E_INVALID;
+    }
     int ndev = octane_device_count();
     if (ndev == 0) { g_last_error = "No gpus available for use"; return OCTANE_E_NODEVICE; }
     int dev = p->device;

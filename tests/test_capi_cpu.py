@@ -68,6 +68,11 @@ def test_invalid_arguments_are_rejected(capi):
     assert L.octane_vof_plan_create(C.byref(h), 64, 64, 1, C.byref(p)) == capi.E_INVALID
     assert L.octane_vof_plan_create(None, 64, 64, 1, C.byref(p)) == capi.E_INVALID
     assert b"invalid" in L.octane_last_error()
+    # a plane addressed with 32-bit byte offsets has to stay below 4 GiB: 32768 x 32768 is refused (before any device is touched),
+    # not left to write out of bounds
+    p = capi.FlowParams().c()
+    assert L.octane_vof_plan_create(C.byref(h), 32768, 32768, 1, C.byref(p)) == capi.E_INVALID
+    assert b"too large" in L.octane_last_error()
 
 
 def test_multi_gpu_entries_validate_before_touching_a_device(capi):

@@ -5,7 +5,9 @@ the plain and the banded solve agree, both of which run the same persistent kern
 the same pair through (1) the default plan, (2) a plan with the persistent mid-level solve OFF (one launch per iteration, other
 kernels) and (3) the CPU ORACLE (oracle/vof_oracle.c, OpenMP, launch-geometry sums), with the flow's size and its distance from the
 analytic truth for each, and the distances between them.  ~6 minutes of oracle at 10848^2 on 16 cores; a heartbeat file keeps the
-GPU box's watchdog quiet.  usage: runaway_check.py [n] [seed]"""
+GPU box's watchdog quiet.  With a third argument the frame is also solved as that many row bands -- with the converging seed 20240615
+this is BASELINE configs[3] at FULL size against the oracle, once, as a record (too long for the test suite).
+usage: runaway_check.py [n] [seed] [bands]"""
 import os
 import sys
 import threading
@@ -47,6 +49,14 @@ def main():
         describe(name, u, v, tu, tv, pl.last_iterations(), time.time() - t)
         pl.close()
         res[name] = (u, v)
+    if len(sys.argv) > 3:                      # the same frame as row bands (virtual bands on a one-GPU box): configs[3]'s mechanism
+        nb = int(sys.argv[3])
+        tp = capi.TiledPlan(n, n, 1, capi.FlowParams(**prm), nbands=nb, devices=capi.band_devices(nb))
+        t = time.time()
+        u, v = tp.run_host(a, b)
+        describe(f"HIP, {nb} row bands ({tp.banded_levels} banded levels)", u, v, tu, tv, tp.last_iterations(), time.time() - t)
+        tp.close()
+        res[f"HIP, {nb} row bands"] = (u, v)
     stop = threading.Event()
 
     def heart():
@@ -64,7 +74,8 @@ def main():
     for name, (u, v) in res.items():
         print(f"relative L2 of '{name}' from the oracle: {rel(u, v, uo, vo):.3e}", flush=True)
     names = list(res)
-    print(f"relative L2 between the two HIP runs: {rel(*res[names[0]], *res[names[1]]):.3e}", flush=True)
+    for other in names[1:]:
+        print(f"relative L2 of '{other}' from '{names[0]}': {rel(*res[other], *res[names[0]]):.3e}", flush=True)
 
 
 if __name__ == "__main__":
