@@ -264,6 +264,8 @@ __device__ __forceinline__ double div_alpha_fast(double x, double alpha, double 
 }
 __device__ __forceinline__ float sq(float x) { return x * x; }
 
+// NC: the channel count as a compile-time constant (1: the usual single-channel pair), 0: taken from L.nc at run time
+template <int NC>
 __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
 {
     __shared__ double s_red[8];
@@ -341,7 +343,8 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
 
         float t1 = 0, t2 = 0, t4 = 0, t5 = 0, t6 = 0, e1 = 0;
         float g1 = 0, g2s = 0, g4 = 0, g5 = 0, g6 = 0, e2 = 0;
-        for (int c = 0; c < L.nc; c++) {
+        const int nchan = NC > 0 ? NC : L.nc;
+        for (int c = 0; c < nchan; c++) {
             const size_t cb = L.cstride * c;
 #define OCT_BIL(F) (p3 * ((p1) * (F)[cb + c1] + (p2) * (F)[cb + c1 + 1]) + p4 * ((p1) * (F)[cb + c3] + (p2) * (F)[cb + c3 + 1]))
             float w2 = OCT_BIL(L.img2);
@@ -480,7 +483,8 @@ int assemble_grid_size(int w, int h)
 
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid)
 {
-    hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(256), 0, s, L, P);
+    if (L.nc == 1) hipLaunchKernelGGL(k_assemble<1>, dim3(grid), dim3(256), 0, s, L, P);
+    else hipLaunchKernelGGL(k_assemble<0>, dim3(grid), dim3(256), 0, s, L, P);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -21,6 +21,8 @@ def norm(short):
         return "k_pcg_fused"
     if short.startswith("k_flow_update"):
         return "k_flow_update"
+    if short.startswith("k_assemble"):
+        return "k_assemble"
     return short
 
 
