@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     float *__restrict__ pout_u = L.pf_u[k % 3];
     float *__restrict__ pout_v = L.pf_v[k % 3];
     const bool defer = L.defer_x != 0;
-    const bool x_two = defer && !first && (k & 1) == 0;
-    const bool x_one = !first && (!defer || ((k & 1) == 1 && !active));
+    const bool x_two = !(Q_ABL & 64) && defer && !first && (k & 1) == 0;            // (ablation 64: the x work compiled out)
+    const bool x_one = !(Q_ABL & 64) && !first && (!defer || ((k & 1) == 1 && !active));
     const bool x_read = x_two ? (k > 2) : (defer ? (k >= 3) : (k > 1));
     const float alpha2 = x_two ? L.alpha[(k - 2) & 1] : 0.f;
     double acc_pq = 0., acc_qz = 0., acc_qmq = 0., acc_rq = 0., acc_qq = 0., acc_rz = 0., acc_rr = 0.;
