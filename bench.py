@@ -576,7 +576,7 @@ def main():
                 xwork = (k % 2 == 0)
                 b_px = (52 + (24 if xwork else 0)) - (8 if (gnc0 and unit_w) else 0)
                 key = ("first GNC step (weights -1, not read)" if (gnc0 and unit_w) else "varying weights") + (", with x work" if xwork else ", without x work")
-                a = acc.setdefault(key, [0.0, 0, b_px]); a[0] += ms_i; a[1] += 1
+                ent = acc.setdefault(key, [0.0, 0, b_px]); ent[0] += ms_i; ent[1] += 1
             by_kind = {key: {"launches": c, "bytes_per_pixel": b_px, "avg_launch_ms": round(t / c, 4),
                              "frac": round(b_px * n * n / (t / c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for key, (t, c, b_px) in acc.items()}
         achieved = bpp * n * n / (dms * 1e-3) / 1e9
