@@ -1,3 +1,5 @@
+"""Mean us per finest-level PCG launch of a real one-level 5000^2 solve, by kind: first GNC step (unit weights) / varying weights, with / without
+x work (every launch of the profiled run is timed by its own event pair: octane_vof_plan_get_launch_times).  OCTANE_LIB selects a variant build."""
 import sys, os, json
 sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/octane_amd") else os.getcwd())
 import torch
