@@ -70,9 +70,17 @@ def main():
         # is as valid an answer as the first, and on large, heavily truncated solves the two can be further apart than
         # the bar -- the HIP path (fp64 sums) has to match one of them
         us = vs = None
+        others = []
         if nx * ny <= 100_000:                      # small frames: the one-thread schedule the survey's answers were recorded with
             us, vs, _ = oo.flow(a, b, P, u0=u0, v0=v0, flavour="omp")
             floor = max(floor, rel_l2(us, vs, uo, vo))
+            # three variants undersample the spread: case 128 of seed 17 (372x237x3) has them within 4.8e-6 of each other while five
+            # further launch geometries of the same code land 2.8e-5 ... 4.1e-5 away (profiles/r3_fuzz_parity_150.txt) -- two clusters,
+            # one rounding apart.  The frame is small, so the further schedules cost milliseconds.
+            for fl, dt in (("omp", 128), ("omp", 512), ("omp", 8192), ("fma", 0), ("fma", 2048)):
+                x, y, _ = oo.flow(a, b, P, u0=u0, v0=v0, flavour=fl, dot_threads=dt)
+                others.append((x, y))
+                floor = max(floor, rel_l2(x, y, uo, vo))
         u2 = v2 = None
         if nx * ny > 1_000_000:
             u2, v2, _ = oo.flow(a, b, P, u0=u0, v0=v0, flavour="omp", dot_threads=8 * g)
@@ -86,7 +94,7 @@ def main():
         # set on which the truncated solve amplifies single roundings (the oracle's own variants are then as far apart): the latter
         # kind is what the tests' allow-list is for, and is reported as CHAOTIC with the oracle's spread, never silently passed.
         d = rel_l2(ug, vg, uo, vo)
-        d_other = min([rel_l2(ug, vg, x, y) for x, y in ((u2, v2), (us, vs)) if x is not None] or [float("nan")])
+        d_other = min([rel_l2(ug, vg, x, y) for x, y in [(u2, v2), (us, vs)] + others if x is not None] or [float("nan")])
         bar = 2e-5
         fine = bool(np.isfinite(ug).all()) and its_g == its_o
         verdict = "ok " if (fine and d < bar) else ("CHAOTIC" if (fine and floor > bar / 2) else "BAD")
