@@ -59,6 +59,14 @@ constexpr int kMidW = 64;               // columns of a sub-domain: one wavefron
 constexpr int kMidRG = kMidT / kMidW;   // rows one slot of all threads covers
 constexpr int kMidLP = kMidW + 2;       // LDS row of the p tile: west ring pixel, 64 columns, east ring pixel
 constexpr int kMidEdge = 128;           // longest edge of a sub-domain (rows: 16 slots x 8)
+// The partial sums are an all-to-all: every workgroup reads every workgroup's 14 granules, G x G x 14 reads of the same 28 KB per
+// iteration, and at G = 128 .. 256 the few memory channels behind those lines serialise them (the wait for the sums grew linearly with
+// G: 0.9 us at 2 workgroups, 3.4 us at 128).  So every workgroup publishes its sums MID_REPS times, into copies an odd number of 4 KB
+// pages apart, and reads the copy (workgroup index mod MID_REPS): MID_REPS times fewer readers per line.
+#ifndef MID_REPS
+#define MID_REPS 8
+#endif
+constexpr unsigned kMidRepStride = (2u * 2u * kPartKinds * kMidMaxG * 8u) + 4096u;      // bytes between two copies: 57344 + 4096 = 15 pages
 constexpr unsigned long long kMidTimeoutTicks = 25000000ull;   // 0.25 s of the 100 MHz wall clock
 
 // plane base + 32-bit byte offset: the scalar-base addressing form (one VGPR of offset for every plane instead of a 64-bit
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         } else {
             const unsigned want = A.tag0 + (unsigned)k;                      // tag of iteration k - 1
             const bool sweeper = wv < kPartKinds, ringer = r_lds >= 0;
-            const unsigned po = (unsigned)((((k + 1) & 1) * 2 * kPartKinds + 2 * wv) * kMidMaxG + lane) * 8u;
+            const unsigned po = (unsigned)((((k + 1) & 1) * 2 * kPartKinds + 2 * wv) * kMidMaxG + lane) * 8u + (unsigned)(wg % MID_REPS) * kMidRepStride;
             const unsigned eo = e_nb_off + (unsigned)(((((k + 1) & 1) * 4 + r_side) * 6) * kMidEdge + r_idx) * 8u;
             unsigned long long g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             unsigned spins = 0; unsigned long long t0 = 0ull;
@@ -443,9 +451,11 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
 #pragma unroll
             for (int i = 0; i < kMidT / 64; i++) v += (double)s_acc[wv * kMidT + lane + 64 * i];
             v = wave_sum(v);
-            if (lane < 2) {                                    // lane 0 / 1: low / high half of sum wv
+            if (lane < 2 * MID_REPS) {                         // even / odd lane: low / high half of sum wv, lane / 2: the copy
                 const unsigned long long b64 = (unsigned long long)__double_as_longlong(v);
-                st_granule(gat(A.parts, (unsigned)((par * 2 * kPartKinds + 2 * wv + lane) * kMidMaxG + wg) * 8u), tag, lane ? (unsigned)(b64 >> 32) : (unsigned)b64);
+                const int half = lane & 1;
+                st_granule(gat(A.parts, (unsigned)((par * 2 * kPartKinds + 2 * wv + half) * kMidMaxG + wg) * 8u + (unsigned)(lane >> 1) * kMidRepStride), tag,
+                           half ? (unsigned)(b64 >> 32) : (unsigned)b64);
             }
         }
         // ---- publish the edges: side 0 / 1 = first / last row, 2 / 3 = west / east column; arrays r_u r_v q_u q_v p_u p_v
@@ -510,20 +520,27 @@ static size_t mid_lds_bytes(int P)
 }
 
 #ifndef MID_DIAG
+static int g_mid_min_p = 1;
+void set_mid_min_p(int p) { g_mid_min_p = p < 1 ? 1 : p; }
 // Sub-domain grid of a w x h level on a device with `ncu` CUs: 64-column strips, as many rows of sub-domains as keep every
-// workgroup on a CU of its own, P (slots of 8 rows) from {4, 6, .. 16}.  0 = the level does not fit.
+// workgroup on a CU of its own, P (slots of 8 rows) from {1, 2, 4, 6, .. 16}.  0 = the level does not fit.
 int pcg_mid_config(int w, int h, int ncu, int force_p, MidGeom *g)
 {
     if (ncu > kMidMaxG) ncu = kMidMaxG;
     const int gx = (w + kMidW - 1) / kMidW;
     if (gx > ncu || (long)w * h <= 0) return 0;
-    static const int kP[7] = {4, 6, 8, 10, 12, 14, 16};
-    for (int i = 0; i < 7; i++) {
+    static const int kP[9] = {1, 2, 4, 6, 8, 10, 12, 14, 16};
+    for (int i = 0; i < 9; i++) {
         const int P = kP[i];
-        if (force_p && P != force_p) continue;
+        if (force_p > 0 && P != force_p) continue;
+        if (force_p <= 0 && P < (force_p < 0 ? -force_p : g_mid_min_p)) continue;        // force_p < 0: at least that many slots
         const int rows = P * kMidRG;
         int gy = (h + rows - 1) / rows;
         if (gx * gy > ncu) continue;
+        // An iteration costs ~3.4 us of exchange and reductions plus ~0.45 us per slot; the exchange grows with the number of workgroups
+        // (+2 us from 8 to 128), so sub-domains of one or two slots pay only up to 128 workgroups (tools/mid_minp.py, round 3:
+        // 63^2 1.20 -> 0.93 ms per 270 iterations, 250^2 1.34 -> 1.15, 313^2 with two slots 1.38 -> 1.24; 500^2 is faster with four)
+        if (P < 4 && gx * gy > 128) continue;
         // balance: equal shares of rows, in whole slots
         int bh = (h + gy - 1) / gy;
         bh = (bh + kMidRG - 1) / kMidRG * kMidRG;
@@ -540,6 +557,7 @@ int pcg_mid_config(int w, int h, int ncu, int force_p, MidGeom *g)
 void pcg_mid_configure()
 {
 #define MID_ATTR(P, U) (void)hipFuncSetAttribute((const void *)k_pcg_solve_mid<P, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds_bytes(P))
+    MID_ATTR(1, false); MID_ATTR(1, true); MID_ATTR(2, false); MID_ATTR(2, true);
     MID_ATTR(4, false); MID_ATTR(4, true); MID_ATTR(6, false); MID_ATTR(6, true); MID_ATTR(8, false); MID_ATTR(8, true);
     MID_ATTR(10, false); MID_ATTR(10, true); MID_ATTR(12, false); MID_ATTR(12, true); MID_ATTR(14, false); MID_ATTR(14, true);
     MID_ATTR(16, false); MID_ATTR(16, true);
@@ -549,8 +567,8 @@ void pcg_mid_configure()
 #ifndef MID_DIAG
 size_t pcg_mid_workspace_bytes()
 {
-    // [abort word] [partial sums: 2 parities x 14 granules x G] [edge pixels: G x 2 parities x 4 sides x 6 arrays x 128 granules]
-    return 256 + (size_t)2 * 2 * kPartKinds * kMidMaxG * 8 + (size_t)kMidMaxG * 2 * 4 * 6 * kMidEdge * 8;
+    // [abort word] [MID_REPS copies of the partial sums: 2 parities x 14 granules x G, + one page] [edge pixels: G x 2 parities x 4 sides x 6 arrays x 128 granules]
+    return 256 + (size_t)MID_REPS * kMidRepStride + (size_t)kMidMaxG * 2 * 4 * 6 * kMidEdge * 8;
 }
 
 #endif
@@ -572,13 +590,15 @@ hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom
     char *ws = static_cast<char *>(workspace);
     A.abort_word = reinterpret_cast<unsigned int *>(ws + 8);
     A.parts = reinterpret_cast<unsigned long long *>(ws + 256);
-    A.edges = reinterpret_cast<unsigned long long *>(ws + 256 + (size_t)2 * 2 * kPartKinds * kMidMaxG * 8);
+    A.edges = reinterpret_cast<unsigned long long *>(ws + 256 + (size_t)MID_REPS * kMidRepStride);
     A.tag0 = seq * (unsigned)(kcap + 2);                   // granule tags of this solve: tag0 + 1 .. tag0 + kcap
     const size_t lds = mid_lds_bytes(g.P);
 #define MID_LAUNCH(P) \
     do { if (L.unit_w) hipLaunchKernelGGL((k_pcg_solve_mid<P, true>), dim3(g.G), dim3(kMidT), lds, s, L, A); \
          else hipLaunchKernelGGL((k_pcg_solve_mid<P, false>), dim3(g.G), dim3(kMidT), lds, s, L, A); } while (0)
     switch (g.P) {
+    case 1: MID_LAUNCH(1); break;
+    case 2: MID_LAUNCH(2); break;
     case 4: MID_LAUNCH(4); break;
     case 6: MID_LAUNCH(6); break;
     case 8: MID_LAUNCH(8); break;

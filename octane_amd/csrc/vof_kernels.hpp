@@ -156,6 +156,7 @@ struct MidArgs {
     unsigned long long *edges;       // [G][2 parities][4 sides][6 arrays][128] granules
 };
 int  pcg_mid_config(int w, int h, int ncu, int force_p, MidGeom *g);
+void set_mid_min_p(int p);          // smallest slot count pcg_mid_config may choose (developer knob OCTANE_TUNE_PERSIST_MINP)
 void set_mid_fault(int v);               // test hook, see MidArgs::fault
 void pcg_mid_configure();
 size_t pcg_mid_workspace_bytes();

@@ -278,6 +278,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_PERSIST")) pl->use_persist = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_STEP")) pl->persist_step = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_P")) pl->persist_p = atoi(e);
+    if (const char *e = getenv("OCTANE_TUNE_PERSIST_MINP")) set_mid_min_p(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_MAX")) pl->persist_max_pixels = atol(e);
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_MAXG")) pl->persist_max_g = atoi(e);
     {
@@ -627,10 +628,10 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
     MidGeom mg;
     const bool mid_ok = pl->use_persist && pl->use_fused && !pl->use_graph && pl->d_mid && (long)li.w * li.h <= pl->persist_max_pixels &&
                         pcg_mid_config(li.w, li.h, pl->ncu < pl->persist_max_g ? pl->ncu : pl->persist_max_g, pl->persist_p, &mg) == 1;
-    // the coarsest levels: one workgroup holds the whole level (k_pcg_solve_small, <= 6144 pixels).  Above ~3000 pixels a handful of
-    // persistent sub-domains is faster than one workgroup with 8-12 pixels per thread (63^2: 424 against 536 us for three solves,
-    // 78^2: 449 against 667; 50^2: 416 against 373), so the single workgroup keeps only what is smaller, or everything if the
-    // persistent solve is not available
+    // the coarsest levels: one workgroup holds the whole level (k_pcg_solve_small, <= 6144 pixels).  With up to three pixels per thread
+    // (<= 1536 pixels) nothing beats it (39^2: 2.9 us per iteration against 3.4 for five one-slot persistent sub-domains); with 6 or 12
+    // pixels per thread the persistent sub-domains are faster (45^2: 3.4 against 3.6, 55^2: 3.4 against 4.2, 63^2: 3.4 against 6.0;
+    // tools/small_vs_mid.py), so the single workgroup keeps only what is smaller, or everything if the persistent solve is not available
     const bool small = pl->use_small && pcg_small_applicable(li.w, li.h) && (!mid_ok || (long)li.w * li.h <= pl->small_max_pixels);
     const bool mid = !small && mid_ok;
 
@@ -1545,7 +1546,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "persist_p") pl->persist_p = value;
     else if (k == "persist_fault") set_mid_fault(value);
     else if (k == "persist_max_g") pl->persist_max_g = value;
-    else if (k == "lane_mode") { if (value) plan_lane_mode(pl); else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 3072; } }
+    else if (k == "lane_mode") { if (value) plan_lane_mode(pl); else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 1536; } }
     else if (k == "fused_rows") set_fused_rows(value);
     else return OCTANE_E_INVALID;
     return OCTANE_OK;

@@ -64,7 +64,7 @@ struct octane_vof_plan {
     // level resident on chip (pcg_persist.hip).  persist_step > 0 runs that many iterations per launch with the state in the
     // level's planes instead (the per-launch form the persistent one is checked against); persist_p forces the slot count.
     int use_persist = 1, persist_step = 0, persist_p = 0;
-    long small_max_pixels = 3072;           // levels of up to this many pixels run the single-workgroup solve (larger ones, up to the 6144 it can hold, only when the persistent solve is off)
+    long small_max_pixels = 1536;           // levels of up to this many pixels (three per thread) run the single-workgroup solve; larger ones, up to the 6144 it can hold, only when the persistent solve is off
     int persist_max_g = 1 << 20;   // cap on the workgroups (= CUs held for a whole solve) of one persistent launch: lanes of a batch lower it
     long persist_max_pixels = 2L << 20;
     int ncu = 0;                   // compute units of the device
