@@ -7,11 +7,40 @@ namespace octane {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Sum over the 64 lanes of a wavefront; every lane ends with the total, and the order of
-// additions is fixed (butterfly), so the result is run-to-run deterministic.
+// additions is fixed (butterfly: lane i adds lane i ^ 32, then ^ 16, 8, 4, 2, 1), so the result is run-to-run deterministic.
+// The exchange steps are register moves, not trips through the LDS crossbar (`__shfl_xor` = two ds_bpermute_b32 per step and double,
+// ~100 cycles a step): gfx950's v_permlane32_swap / v_permlane16_swap for the steps across rows, DPP moves within a row of 16 lanes.
+// row_ror:4 stands for "lane ^ 4" because after the steps 32, 16, 8 the lanes i and i + 8 of a row hold the same value.  Same pairs,
+// same order, same bits as the __shfl_xor loop (checked on the device over 2^18 random inputs, round 3).
+template <int CTRL>
+__device__ __forceinline__ double wave_dpp_f64(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const unsigned lane = __lane_id();
+    {   // lane ^ 32: the swap exchanges the upper half of its first operand with the lower half of its second
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        const bool low = lane < 32;
+        v += __longlong_as_double((long long)(((unsigned long long)(low ? r1[1] : r1[0]) << 32) | (low ? r0[1] : r0[0])));
+    }
+    {   // lane ^ 16: the same between the odd rows of the first and the even rows of the second operand
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const auto r0 = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        const bool low = (lane & 16) == 0;
+        v += __longlong_as_double((long long)(((unsigned long long)(low ? r1[1] : r1[0]) << 32) | (low ? r0[1] : r0[0])));
+    }
+    v += wave_dpp_f64<0x128>(v);     // row_ror:8
+    v += wave_dpp_f64<0x124>(v);     // row_ror:4
+    v += wave_dpp_f64<0x4E>(v);      // quad_perm:[2,3,0,1]
+    v += wave_dpp_f64<0xB1>(v);      // quad_perm:[1,0,3,2]
     return v;
 }
 
