@@ -1707,8 +1707,13 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_solve_small(LevelPtrs L, 
             t = 0.f; t += ru[s] * ru[s]; t += rv[s] * rv[s]; d_rr += (double)t;
         }
     }
-    float rz = (float)block_sum_1024(d_rz, s_red);
-    float rr = (float)block_sum_1024(d_rr, s_red);
+    float rz, rr;
+    {   // both sums with one pair of barriers (each in the order block_sum_1024 takes)
+        const double two[2] = {d_rz, d_rr};
+        double tot[2];
+        block_sum_multi<2, kSmallThreads>(two, s_red, tot);
+        rz = (float)tot[0]; rr = (float)tot[1];
+    }
     float rz_old = 0.f;
     int it = 0;
     while (rr > tol && it < maxit) {                                   // ref .cu:1131
@@ -1763,8 +1768,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_solve_small(LevelPtrs L, 
             }
         }
         rz_old = rz;
-        rz = (float)block_sum_1024(d_rz, s_red);
-        rr = (float)block_sum_1024(d_rr, s_red);
+        {
+            const double two[2] = {d_rz, d_rr};
+            double tot[2];
+            block_sum_multi<2, kSmallThreads>(two, s_red, tot);
+            rz = (float)tot[0]; rr = (float)tot[1];
+        }
         it++;
     }
     if (it > 0) {                                                      // ref .cu:1185-1195
