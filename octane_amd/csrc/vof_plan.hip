@@ -73,6 +73,9 @@ extern "C" int octane_vof_plan_destroy(octane_vof_plan *pl)
     if (!pl) return OCTANE_OK;
     (void)hipSetDevice(pl->device);
     if (pl->own_stream) (void)hipStreamSynchronize(pl->own_stream);
+    if (pl->side_stream) { (void)hipStreamSynchronize(pl->side_stream); (void)hipStreamDestroy(pl->side_stream); }
+    if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
+    for (int i = 0; i < 2; i++) { if (pl->ev_img[i]) (void)hipEventDestroy(pl->ev_img[i]); if (pl->ev_solved[i]) (void)hipEventDestroy(pl->ev_solved[i]); }
     for (auto &e : pl->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (pl->ev_t0) (void)hipEventDestroy(pl->ev_t0);
     if (pl->ev_t1) (void)hipEventDestroy(pl->ev_t1);
@@ -93,14 +96,13 @@ extern "C" int octane_vof_plan_destroy(octane_vof_plan *pl)
     return OCTANE_OK;
 }
 
-static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, const float *lev1, const float *lev2,
-                            const float *ut, const float *vt, LevelPtrs &L)
+static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, const LevelCtx &c, LevelPtrs &L)
 {
     L.w = li.w; L.h = li.h; L.pitch = li.pitch; L.nc = pl->nc; L.cstride = pl->plane0;
-    L.img1 = lev1; L.img2 = lev2;
-    L.gx1 = pl->gx1; L.gy1 = pl->gy1; L.gx2 = pl->gx2; L.gy2 = pl->gy2;
-    L.gxx = pl->gxx; L.gxy = pl->gxy; L.gyy = pl->gyy;
-    L.u = pl->U[cur]; L.v = pl->V[cur]; L.ut = ut; L.vt = vt;
+    L.img1 = c.lev1; L.img2 = c.lev2;
+    L.gx1 = c.gx1; L.gy1 = c.gy1; L.gx2 = c.gx2; L.gy2 = c.gy2;
+    L.gxx = c.gxx; L.gxy = c.gxy; L.gyy = c.gyy;
+    L.u = pl->U[cur]; L.v = pl->V[cur]; L.ut = c.ut; L.vt = c.vt;
     L.a1 = pl->a1; L.a2 = pl->a2; L.a4 = pl->a4; L.wx = pl->wx; L.wy = pl->wy; L.mu = pl->mu; L.mv = pl->mv;
     L.ru = pl->ru; L.rv = pl->rv;
     L.pu[0] = pl->pu[0]; L.pu[1] = pl->pu[1]; L.pv[0] = pl->pv[0]; L.pv[1] = pl->pv[1];
@@ -129,7 +131,7 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
 
 void octane::plan_fill_level_ptrs(octane_vof_plan *pl, int k, int cur, const LevelCtx &c, LevelPtrs &L)
 {
-    fill_level_ptrs(pl, pl->lev[k], cur, c.lev1, c.lev2, c.ut, c.vt, L);
+    fill_level_ptrs(pl, pl->lev[k], cur, c, L);
 }
 
 // Times a few PCG iterations of the finest level on whatever the arena holds (the values do not matter, only
@@ -148,7 +150,8 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
 {
     const LevelInfo &li = pl->lev[level];
     LevelPtrs L;
-    fill_level_ptrs(pl, li, 0, pl->img1p, pl->img2p, pl->uh, pl->vh, L);
+    const LevelCtx pc = {pl->img1p, pl->img2p, pl->uh, pl->vh, pl->gx1, pl->gy1, pl->gx2, pl->gy2, pl->gxx, pl->gxy, pl->gyy};
+    fill_level_ptrs(pl, li, 0, pc, L);
     const int g_a = pcg_grid_size(li.w, li.h), g_b = pcg_b_grid_size(li.w, li.h);
     L.q_form = pcg_fused_q_form(li.w, li.h, li.h);
     const int g_f = pcg_fused_grid_size(li.w, li.h, 0, L.q_form);
@@ -279,6 +282,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_STEP")) pl->persist_step = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_P")) pl->persist_p = atoi(e);
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_MINP")) set_mid_min_p(atoi(e));
+    if (const char *e = getenv("OCTANE_TUNE_OVERLAP")) pl->use_overlap = atoi(e) != 0;
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_MAX")) pl->persist_max_pixels = atol(e);
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_MAXG")) pl->persist_max_g = atoi(e);
     {
@@ -330,7 +334,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     }
 
     const int nc = nchan;
-    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 17 + 1 + 6;
+    const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 17 + 1 + 6 + (9 * nc + 2);
     size_t skew = 0;                              // developer knob: stagger the planes' base addresses (floats)
     if (const char *e = getenv("OCTANE_TUNE_SKEW")) skew = (size_t)atol(e) / 64 * 64;
     size_t align_f = 0;                           // developer knob: round the plane stride up to a multiple (bytes)
@@ -372,6 +376,10 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         pl->tmp = take(1);
         pl->ru2 = take(1); pl->rv2 = take(1); pl->qu2 = take(1); pl->qv2 = take(1);
         pl->pu3 = take(1); pl->pv3 = take(1);
+        // (new planes go here, at the end: the offsets of the ones above are what row bands address each other's arenas by)
+        pl->lev1b = take(nc); pl->lev2b = take(nc); pl->utb = take(1); pl->vtb = take(1);
+        pl->gx1b = take(nc); pl->gy1b = take(nc); pl->gx2b = take(nc); pl->gy2b = take(nc);
+        pl->gxxb = take(nc); pl->gxyb = take(nc); pl->gyyb = take(nc);
     };
     carve(pl->arena);
 
@@ -395,6 +403,13 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         if (hipMemset(pl->d_parts, 0, 2 * kPartBlock * sizeof(double)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMemset(pl->d_state, 0, 2 * sizeof(PcgState)) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipStreamCreateWithFlags(&pl->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        if (hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess) { rc = OCTANE_E_HIP; break; }
+        for (int i = 0; i < 2 && rc == OCTANE_OK; i++) {
+            if (hipEventCreateWithFlags(&pl->ev_img[i], hipEventDisableTiming) != hipSuccess) rc = OCTANE_E_HIP;
+            else if (hipEventCreateWithFlags(&pl->ev_solved[i], hipEventDisableTiming) != hipSuccess) rc = OCTANE_E_HIP;
+        }
+        if (rc != OCTANE_OK) break;
     } while (0);
     if (rc != OCTANE_OK) {
         g_last_error = "octane_vof_plan_create: device allocation failed";
@@ -531,7 +546,7 @@ static EvPair *ev_begin(octane_vof_plan *pl, hipStream_t s, int kind, bool on)
 }
 static void ev_end(EvPair *p, hipStream_t s) { if (p) (void)hipEventRecord(p->b, s); }
 
-int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur, LevelCtx &c)
+int octane::plan_level_images(octane_vof_plan *pl, hipStream_t s, int k, int which, LevelCtx &c)
 {
     const octane_vof_params &prm = pl->prm;
     const int nc = pl->nc;
@@ -539,42 +554,65 @@ int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur
     const bool hint = (prm.lambdac != 0.);
     const LevelInfo &li = pl->lev[k];
     const bool finest = (k == nlev - 1);
-    if (k > 0) {   // ref .cu:498-503: bicubic up-sample of the previous level's flow, divided by scaleF
-        const LevelInfo &lo = pl->lev[k - 1];
-        launch_upsample(s, pl->U[cur], lo.w, lo.h, lo.pitch, pl->U[cur ^ 1], li.w, li.h, li.pitch, (float)prm.scaleF);
-        launch_upsample(s, pl->V[cur], lo.w, lo.h, lo.pitch, pl->V[cur ^ 1], li.w, li.h, li.pitch, (float)prm.scaleF);
-        cur ^= 1;
-    }
+    float *lev1 = which ? pl->lev1b : pl->lev1, *lev2 = which ? pl->lev2b : pl->lev2;
+    // without the hint term only level 0 forms the decimated first guess (and nothing reads it afterwards): one pair of planes will do
+    float *ut = (which && hint) ? pl->utb : pl->ut, *vt = (which && hint) ? pl->vtb : pl->vt;
+    c.gx1 = which ? pl->gx1b : pl->gx1; c.gy1 = which ? pl->gy1b : pl->gy1; c.gx2 = which ? pl->gx2b : pl->gx2; c.gy2 = which ? pl->gy2b : pl->gy2;
+    c.gxx = which ? pl->gxxb : pl->gxx; c.gxy = which ? pl->gxyb : pl->gxy; c.gyy = which ? pl->gyyb : pl->gyy;
     if (finest) {  // ref .cu:504-517: the finest level uses the inputs themselves
         c.lev1 = pl->img1p; c.lev2 = pl->img2p; c.ut = pl->uh; c.vt = pl->vh;
     } else {       // ref .cu:519-563
         const float *gk = pl->d_taps + li.tap_off;
         // channel 0 only: the reference's zoom_out samples channel 0 for every channel (.cu:406)
         launch_blur_rows_sampled(s, pl->img1p, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
-        launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->lev1, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
+        launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, lev1, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
         launch_blur_rows_sampled(s, pl->img2p, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
-        launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->lev2, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
+        launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, lev2, li.h, li.pitch, gk, li.fs, li.factor, 1.f, 0);
         for (int ch = 1; ch < nc; ch++) {
-            launch_copy2d(s, pl->lev1, li.pitch, pl->lev1 + ch * pl->plane0, li.pitch, li.w, li.h);
-            launch_copy2d(s, pl->lev2, li.pitch, pl->lev2 + ch * pl->plane0, li.pitch, li.w, li.h);
+            launch_copy2d(s, lev1, li.pitch, lev1 + ch * pl->plane0, li.pitch, li.w, li.h);
+            launch_copy2d(s, lev2, li.pitch, lev2 + ch * pl->plane0, li.pitch, li.w, li.h);
         }
         if (hint || k == 0) {   // decimated first guess, scaled to this level's pixel size
             launch_blur_rows_sampled(s, pl->uh, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
-            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->ut, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
+            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, ut, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
             launch_blur_rows_sampled(s, pl->vh, pl->nx, pl->ny, pl->pitch0, pl->tmp, li.w, li.pitch, gk, li.fs, li.factor);
-            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, pl->vt, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
+            launch_blur_cols_sampled(s, pl->tmp, li.w, pl->ny, li.pitch, vt, li.h, li.pitch, gk, li.fs, li.factor, li.factor, 1);
         }
-        c.lev1 = pl->lev1; c.lev2 = pl->lev2; c.ut = pl->ut; c.vt = pl->vt;
-    }
-    if (k == 0) {  // ref .cu:576-585
-        launch_copy2d(s, c.ut, li.pitch, pl->U[cur], li.pitch, li.w, li.h);
-        launch_copy2d(s, c.vt, li.pitch, pl->V[cur], li.pitch, li.w, li.h);
+        c.lev1 = lev1; c.lev2 = lev2; c.ut = ut; c.vt = vt;
     }
     // ref .cu:587-595; d/dy of gx2 is dead (overwritten by the fourth call), so it is not stored
-    launch_gradient(s, c.lev1, pl->gx1, pl->gy1, li.w, li.h, li.pitch, nc, pl->plane0);
-    launch_gradient(s, c.lev2, pl->gx2, pl->gy2, li.w, li.h, li.pitch, nc, pl->plane0);
-    launch_gradient(s, pl->gx2, pl->gxx, nullptr, li.w, li.h, li.pitch, nc, pl->plane0);
-    launch_gradient(s, pl->gy2, pl->gxy, pl->gyy, li.w, li.h, li.pitch, nc, pl->plane0);
+    launch_gradient(s, c.lev1, c.gx1, c.gy1, li.w, li.h, li.pitch, nc, pl->plane0);
+    launch_gradient(s, c.lev2, c.gx2, c.gy2, li.w, li.h, li.pitch, nc, pl->plane0);
+    launch_gradient(s, c.gx2, c.gxx, nullptr, li.w, li.h, li.pitch, nc, pl->plane0);
+    launch_gradient(s, c.gy2, c.gxy, c.gyy, li.w, li.h, li.pitch, nc, pl->plane0);
+    return OCTANE_OK;
+}
+
+// ref .cu:498-503: bicubic up-sample of the previous level's flow, divided by scaleF (flips `cur`)
+static void plan_level_upsample(octane_vof_plan *pl, hipStream_t s, int k, int &cur)
+{
+    if (k == 0) return;
+    const LevelInfo &li = pl->lev[k], &lo = pl->lev[k - 1];
+    launch_upsample(s, pl->U[cur], lo.w, lo.h, lo.pitch, pl->U[cur ^ 1], li.w, li.h, li.pitch, (float)pl->prm.scaleF);
+    launch_upsample(s, pl->V[cur], lo.w, lo.h, lo.pitch, pl->V[cur ^ 1], li.w, li.h, li.pitch, (float)pl->prm.scaleF);
+    cur ^= 1;
+}
+
+// ref .cu:576-585: the coarsest level starts from the decimated first guess
+static void plan_level_first_guess(octane_vof_plan *pl, hipStream_t s, int k, int cur, const LevelCtx &c)
+{
+    if (k != 0) return;
+    const LevelInfo &li = pl->lev[0];
+    launch_copy2d(s, c.ut, li.pitch, pl->U[cur], li.pitch, li.w, li.h);
+    launch_copy2d(s, c.vt, li.pitch, pl->V[cur], li.pitch, li.w, li.h);
+}
+
+int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur, LevelCtx &c)
+{
+    plan_level_upsample(pl, s, k, cur);
+    const int rc = plan_level_images(pl, s, k, 0, c);
+    if (rc) return rc;
+    plan_level_first_guess(pl, s, k, cur, c);
     return OCTANE_OK;
 }
 
@@ -616,7 +654,7 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
     const octane_vof_params &prm = pl->prm;
     const LevelInfo &li = pl->lev[k];
     LevelPtrs L;
-    fill_level_ptrs(pl, li, cur, c.lev1, c.lev2, c.ut, c.vt, L);
+    fill_level_ptrs(pl, li, cur, c, L);
 
     const int g_asm = assemble_grid_size(li.w, li.h);
     L.q_form = pcg_fused_q_form(li.w, li.h, li.h);
@@ -726,10 +764,44 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
     if (pl->d_mid) HIP_TRY(hipMemsetAsync(static_cast<char *>(pl->d_mid) + 8, 0, sizeof(unsigned), s));
     double setup_ms = 0.;
 
+    // Everything a level needs apart from the flow -- its pyramid images, the decimated first guess, seven gradient fields -- depends on
+    // the inputs alone.  The coarse levels' solves are latency-bound launches that leave the GPU idle (R1: 11 of 120 ms), so a side
+    // stream prepares level k + 1 in the second set of planes while level k is solved out of the first, and so on alternately; the
+    // solve of level k waits for the event of its images, the side stream waits for the solve that last read the set it overwrites.
+    const bool overlap = pl->use_overlap && !prof && !pl->trace && pl->side_stream && nlev > 1 && !pl->use_graph;
+    LevelCtx next_c;
+    if (overlap) {
+        hipStream_t side = pl->side_stream;
+        HIP_TRY(hipEventRecord(pl->ev_fork, s));                 // the inputs are in place (and the previous run on this stream is over)
+        HIP_TRY(hipStreamWaitEvent(side, pl->ev_fork, 0));
+        int rc = plan_level_images(pl, side, 0, 0, next_c);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(pl->ev_img[0], side));
+    }
+
     for (int k = 0; k < nlev; k++) {
         const LevelInfo &li = pl->lev[k];
         const bool finest = (k == nlev - 1);
         LevelCtx c;
+        if (overlap) {
+            c = next_c;
+            if (k + 1 < nlev) {                                  // level k + 1 into the other set, once the solve of level k - 1 has left it
+                hipStream_t side = pl->side_stream;
+                if (k >= 1) HIP_TRY(hipStreamWaitEvent(side, pl->ev_solved[(k + 1) & 1], 0));
+                int rc = plan_level_images(pl, side, k + 1, (k + 1) & 1, next_c);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(pl->ev_img[(k + 1) & 1], side));
+            }
+            plan_level_upsample(pl, s, k, cur);
+            // (ev_img[k & 1] was recorded for level k before the call above re-recorded the OTHER event; a wait takes the event's
+            // latest record at the time of the call, so it has to come after that record and before the next one of the same event)
+            HIP_TRY(hipStreamWaitEvent(s, pl->ev_img[k & 1], 0));
+            plan_level_first_guess(pl, s, k, cur, c);
+            int rc = plan_level_solve(pl, s, k, cur, c, false);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(pl->ev_solved[k & 1], s));
+            continue;
+        }
         if (prof) (void)hipEventRecord(pl->ev_s0, s);
         int rc = plan_level_setup(pl, s, k, cur, c);
         if (rc) return rc;
@@ -743,13 +815,13 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
         if (pl->trace) {
             if ((rc = emit_chan(pl, s, "img1", k, c.lev1, li.w, li.h, li.pitch))) return rc;
             if ((rc = emit_chan(pl, s, "img2", k, c.lev2, li.w, li.h, li.pitch))) return rc;
-            if ((rc = emit_chan(pl, s, "gx1", k, pl->gx1, li.w, li.h, li.pitch))) return rc;
-            if ((rc = emit_chan(pl, s, "gy1", k, pl->gy1, li.w, li.h, li.pitch))) return rc;
-            if ((rc = emit_chan(pl, s, "gx2", k, pl->gx2, li.w, li.h, li.pitch))) return rc;
-            if ((rc = emit_chan(pl, s, "gy2", k, pl->gy2, li.w, li.h, li.pitch))) return rc;
-            if ((rc = emit_chan(pl, s, "gxx", k, pl->gxx, li.w, li.h, li.pitch))) return rc;
-            if ((rc = emit_chan(pl, s, "gxy", k, pl->gxy, li.w, li.h, li.pitch))) return rc;
-            if ((rc = emit_chan(pl, s, "gyy", k, pl->gyy, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gx1", k, c.gx1, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gy1", k, c.gy1, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gx2", k, c.gx2, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gy2", k, c.gy2, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gxx", k, c.gxx, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gxy", k, c.gxy, li.w, li.h, li.pitch))) return rc;
+            if ((rc = emit_chan(pl, s, "gyy", k, c.gyy, li.w, li.h, li.pitch))) return rc;
             if ((rc = emit(pl, s, "u0", k, -1, -1, {pl->U[cur]}, li.w, li.h, li.pitch))) return rc;
             if ((rc = emit(pl, s, "v0", k, -1, -1, {pl->V[cur]}, li.w, li.h, li.pitch))) return rc;
         }
@@ -1455,7 +1527,8 @@ extern "C" int octane_vof_plan_probe_stamps(octane_vof_plan *pl, int level, int 
     HIP_TRY(hipSetDevice(pl->device));
     const LevelInfo &li = pl->lev[level];
     LevelPtrs L;
-    fill_level_ptrs(pl, li, 0, pl->img1p, pl->img2p, pl->uh, pl->vh, L);
+    const LevelCtx pc = {pl->img1p, pl->img2p, pl->uh, pl->vh, pl->gx1, pl->gy1, pl->gx2, pl->gy2, pl->gxx, pl->gxy, pl->gyy};
+    fill_level_ptrs(pl, li, 0, pc, L);
     L.q_form = pcg_fused_q_form(li.w, li.h, li.h);
     if (!L.q_form) { g_last_error = "octane_vof_plan_probe_stamps: the level does not run the q-recomputing kernel"; return OCTANE_E_INVALID; }
     L.unit_w = unit_w ? 1 : 0;

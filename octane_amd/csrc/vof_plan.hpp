@@ -34,6 +34,9 @@ struct octane_vof_plan {
     float *a1, *a2, *a4, *wx, *wy, *mu, *mv, *ru, *rv, *pu[2], *pv[2], *qu, *qv, *xu, *xv, *tmp;
     float *ru2, *rv2, *qu2, *qv2;  // second halves of the r / q double buffers of the fused PCG kernel
     float *pu3, *pv3;              // third p buffer of the fused kernel (deferred x update)
+    // Second set of a level's flow-independent planes (pyramid images, first-guess hint, the seven gradient fields): while level k
+    // is being solved out of one set, the side stream prepares level k + 1 in the other (run_on_stream)
+    float *lev1b, *lev2b, *utb, *vtb, *gx1b, *gy1b, *gx2b, *gy2b, *gxxb, *gxyb, *gyyb;
     float *d_taps = nullptr;
     double *d_parts = nullptr;     // 2 * kPartBlock
     octane::PcgState *d_state = nullptr;   // 2
@@ -41,6 +44,9 @@ struct octane_vof_plan {
     long long *d_iters = nullptr;
     long long *h_iters = nullptr;  // pinned
     hipStream_t own_stream = nullptr;
+    hipStream_t side_stream = nullptr;      // prepares the next level's images and gradients beside the current level's solve
+    hipEvent_t ev_fork = nullptr, ev_img[2] = {nullptr, nullptr}, ev_solved[2] = {nullptr, nullptr};
+    int use_overlap = 1;                    // OCTANE_TUNE_OVERLAP=0: everything on one stream, level by level
     octane_vof_trace_fn trace = nullptr;
     void *trace_user = nullptr;
     int profiling = 0;
@@ -80,7 +86,8 @@ struct octane_vof_plan {
 
 namespace octane {
 
-struct LevelCtx { const float *lev1, *lev2, *ut, *vt; };   // where level k's images and first-guess hint live
+// where level k's images, first-guess hint and gradient fields live
+struct LevelCtx { const float *lev1, *lev2, *ut, *vt; float *gx1, *gy1, *gx2, *gy2, *gxx, *gxy, *gyy; };
 
 void set_last_error(const std::string &msg);
 // Plan without the placement trials (several bands may share one device, and the trials allocate 4 arenas).
@@ -88,6 +95,8 @@ int  plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, const octa
 // Level k up to the point where the solve starts: flow up-sampling (flips `cur`), pyramid images, gradients.
 // Everything is computed for the whole level -- bands replicate this work instead of exchanging halos for it.
 int  plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur, LevelCtx &c);
+// The part of it that does not depend on the flow (pyramid images, hint, gradients), into plane set `which` (0 or 1).
+int  plan_level_images(octane_vof_plan *pl, hipStream_t s, int k, int which, LevelCtx &c);
 // The three GNC steps x liters linearisations x cgiters PCG iterations of level k over the whole level.
 int  plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur, const LevelCtx &c, bool profile_kernels);
 void plan_fill_level_ptrs(octane_vof_plan *pl, int k, int cur, const LevelCtx &c, LevelPtrs &L);
