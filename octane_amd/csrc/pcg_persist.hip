@@ -51,6 +51,14 @@ __device__ unsigned long long g_mid_stamps[32];     // [0..15] sub-domains on th
 #ifndef MID_KEEP_RCP_P
 #define MID_KEEP_RCP_P 10  // ... and up to this many keep the reciprocals of the diagonal (two registers per slot) instead of forming them twice per iteration
 #endif
+// Sub-domains of more than MID_WREG_P slots do not have the registers for the whole operator (11 values per pixel: 154 registers at
+// 14 slots, and the compiler spilled 36-468 bytes per lane into scratch, reloaded in the middle of the stencil loop: 1250^2 ran at
+// 20.5 us per iteration, 2.4 times the time per slot of 1000^2).  Their four merged neighbour weights live in a workspace instead,
+// laid out [workgroup][slot][weight][thread] -- every thread reads back exactly what it wrote, whole wavefronts of consecutive
+// floats, out of its XCD's L2 (3.4 MB per XCD at 1250^2) -- and are requested two slots before they are used.
+#ifndef MID_WREG_P
+#define MID_WREG_P 10
+#endif
 #ifndef MID_HOIST_P
 #define MID_HOIST_P 6     // sub-domains of up to this many slots per thread have the registers to keep what is invariant over the iterations
 #endif
@@ -188,7 +196,10 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
     // row / column of sub-domains) holds r = q = 0, a unit diagonal and zero weights: it computes along and stays zero.
     v2f r2[P], q2[P];                                      // p of the own pixels lives in the LDS tile only
     float a1[P], a2[P], a4[P];
-    float wS[P], wW[P], wE[P], wN[P];                      // merged neighbour weights (ref .cu:929-1001); 0 where the level has no such neighbour
+    constexpr bool WL2 = P > MID_WREG_P;                   // the weights live in the workspace, not in registers
+    constexpr int PW = WL2 ? 1 : P;
+    float wS[PW], wW[PW], wE[PW], wN[PW];                  // merged neighbour weights (ref .cu:929-1001); 0 where the level has no such neighbour
+    float *const wsp = A.wspill + (size_t)wg * (16 * 4 * kMidT) + tid;   // + (slot * 4 + weight) * kMidT
     for (int i = tid; i < (ROWS + 2) * kMidLP; i += kMidT) s_p[i] = mk2(0.f, 0.f);
     if (tid == 0) *s_flag = 0;
     __syncthreads();
@@ -203,22 +214,22 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
             r2[s] = mk2(0.f, 0.f); q2[s] = mk2(0.f, 0.f);
             v2f p0 = mk2(0.f, 0.f), xx0 = mk2(0.f, 0.f);
             a1[s] = a4[s] = 1.f; a2[s] = 0.f;
-            wS[s] = wW[s] = wE[s] = wN[s] = 0.f;
+            float ws_ = 0.f, ww_ = 0.f, we_ = 0.f, wn_ = 0.f;
             if (ok) {
                 const unsigned o = (unsigned)(y * pitch + x) * 4u;
                 a1[s] = *at(L.a1, o); a2[s] = *at(L.a2, o); a4[s] = *at(L.a4, o);
                 if (UNITW) {                               // al1 == 1: every weight is exactly -1 (ref .cu:837-864), merged border weights -2
-                    wS[s] = (y > 0) ? ((y == h - 1) ? -2.f : -1.f) : 0.f;
-                    wW[s] = (x > 0) ? ((x == w - 1) ? -2.f : -1.f) : 0.f;
-                    wE[s] = (x < w - 1) ? ((x == 0) ? -2.f : -1.f) : 0.f;
-                    wN[s] = (y < h - 1) ? ((y == 0) ? -2.f : -1.f) : 0.f;
+                    ws_ = (y > 0) ? ((y == h - 1) ? -2.f : -1.f) : 0.f;
+                    ww_ = (x > 0) ? ((x == w - 1) ? -2.f : -1.f) : 0.f;
+                    we_ = (x < w - 1) ? ((x == 0) ? -2.f : -1.f) : 0.f;
+                    wn_ = (y < h - 1) ? ((y == 0) ? -2.f : -1.f) : 0.f;
                 } else {
                     const float wxc = *at(L.wx, o), wyc = *at(L.wy, o);
                     const float wys = (y > 0) ? *at(L.wy, o - 4u * (unsigned)pitch) : 0.f, wxw = (x > 0) ? *at(L.wx, o - 4u) : 0.f;
-                    wS[s] = (y > 0) ? ((y == h - 1) ? wys + wyc : wys) : 0.f;
-                    wW[s] = (x > 0) ? ((x == w - 1) ? wxw + wxc : wxw) : 0.f;
-                    wE[s] = (x < w - 1) ? ((x == 0) ? wxc + wxc : wxc) : 0.f;
-                    wN[s] = (y < h - 1) ? ((y == 0) ? wyc + wyc : wyc) : 0.f;
+                    ws_ = (y > 0) ? ((y == h - 1) ? wys + wyc : wys) : 0.f;
+                    ww_ = (x > 0) ? ((x == w - 1) ? wxw + wxc : wxw) : 0.f;
+                    we_ = (x < w - 1) ? ((x == 0) ? wxc + wxc : wxc) : 0.f;
+                    wn_ = (y < h - 1) ? ((y == 0) ? wyc + wyc : wyc) : 0.f;
                 }
                 if (A.k0 == 0) {
                     r2[s] = mk2(*at(L.rb_u[0], o), *at(L.rb_v[0], o));      // r_0 = the right-hand side the assembly wrote
@@ -228,6 +239,11 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
                     q2[s] = mk2(*at(L.qb_u[par0], o), *at(L.qb_v[par0], o));
                     xx0 = mk2(*at(L.xu, o), *at(L.xv, o));
                 }
+            }
+            if (WL2) {
+                if (!(UNITW && fast)) { wsp[(s * 4 + 0) * kMidT] = ws_; wsp[(s * 4 + 1) * kMidT] = ww_; wsp[(s * 4 + 2) * kMidT] = we_; wsp[(s * 4 + 3) * kMidT] = wn_; }
+            } else {
+                wS[WL2 ? 0 : s] = ws_; wW[WL2 ? 0 : s] = ww_; wE[WL2 ? 0 : s] = we_; wN[WL2 ? 0 : s] = wn_;
             }
             s_x[ly * kMidW + c] = xx0;
             if (ok) s_p[(ly + 1) * kMidLP + c + 1] = p0;       // p_{k0-1} (zero at k0 = 0)
@@ -399,16 +415,26 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         MID_STAMP(3);
         // ---- q = A p and the sums that carry q (the reciprocals of the diagonal and z are formed again rather than kept across the barrier)
 #pragma unroll
-        for (int s = 0; s < P; s++) { if (P > MID_HOIST_P) asm volatile("" : "+v"(a1[s]), "+v"(a2[s]), "+v"(a4[s]), "+v"(wS[s]), "+v"(wW[s]), "+v"(wE[s]), "+v"(wN[s])); }
+        for (int s = 0; s < P; s++) {
+            if (P > MID_HOIST_P && !WL2) asm volatile("" : "+v"(a1[s]), "+v"(a2[s]), "+v"(a4[s]), "+v"(wS[WL2 ? 0 : s]), "+v"(wW[WL2 ? 0 : s]), "+v"(wE[WL2 ? 0 : s]), "+v"(wN[WL2 ? 0 : s]));
+            if (WL2) asm volatile("" : "+v"(a1[s]), "+v"(a2[s]), "+v"(a4[s]));
+        }
         if (P > MID_HOIST_P) asm volatile("" : "+v"(c), "+v"(rg));
         const int par = k & 1;
+#define MID_WLOAD(dst, s_) do { if (WL2 && (s_) < P) { dst[0] = wp[((s_) * 4 + 0) * kMidT]; dst[1] = wp[((s_) * 4 + 1) * kMidT];            \
+                                                     dst[2] = wp[((s_) * 4 + 2) * kMidT]; dst[3] = wp[((s_) * 4 + 3) * kMidT]; } } while (0)
+        const float *wp = wsp;                               // (opaque once per iteration: these loads are not to be hoisted out of the k loop)
+        if (WL2) asm volatile("" : "+v"(wp));
 #define MID_STENCIL_LOOP(FAST)                                                                                                         \
+        float wq[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};    /* the weights of slot s, s + 1, s + 2 in turn */ \
+        if (!(FAST && UNITW)) { MID_WLOAD(wq[0], 0); MID_WLOAD(wq[1], 1); }                                                            \
         _Pragma("unroll") for (int s = 0; s < P; s++) {                                                                                \
+            if (!(FAST && UNITW)) MID_WLOAD(wq[(s + 2) % 3], s + 2);                                                                   \
             const int ly = s * kMidRG + rg, y = y0 + ly;                                                                               \
             const bool ok = FAST || (colok && ly < sh);                                                                                \
             const int li = (ly + 1) * kMidLP + c + 1;                                                                                  \
-            const float ws = (FAST && UNITW) ? -1.f : wS[s], ww = (FAST && UNITW) ? -1.f : wW[s];                                      \
-            const float we = (FAST && UNITW) ? -1.f : wE[s], wn = (FAST && UNITW) ? -1.f : wN[s];                                      \
+            const float ws = (FAST && UNITW) ? -1.f : (WL2 ? wq[s % 3][0] : wS[WL2 ? 0 : s]), ww = (FAST && UNITW) ? -1.f : (WL2 ? wq[s % 3][1] : wW[WL2 ? 0 : s]); \
+            const float we = (FAST && UNITW) ? -1.f : (WL2 ? wq[s % 3][2] : wE[WL2 ? 0 : s]), wn = (FAST && UNITW) ? -1.f : (WL2 ? wq[s % 3][3] : wN[WL2 ? 0 : s]); \
             v2f sum = mk2(0.f, 0.f);                                                                                                   \
             sum += ws * s_p[li - kMidLP];                                                                                              \
             sum += ww * s_p[li - 1];                                                                                                   \
@@ -438,6 +464,7 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
         }
         if (fast) { MID_STENCIL_LOOP(true) } else { MID_STENCIL_LOOP(false) }
 #undef MID_STENCIL_LOOP
+#undef MID_WLOAD
         MID_STAMP(4);                                        // stencil loop
         // ---- the workgroup's seven sums: every thread's subtotal through LDS, then wave j adds up sum j over the 512 threads in a
         // fixed order, in double
@@ -575,8 +602,8 @@ void pcg_mid_configure()
 #ifndef MID_DIAG
 size_t pcg_mid_workspace_bytes()
 {
-    // [abort word] [MID_REPS copies of the partial sums: 2 parities x 14 granules x G, + one page] [edge pixels: G x 2 parities x 4 sides x 6 arrays x 128 granules]
-    return 256 + (size_t)MID_REPS * kMidRepStride + (size_t)kMidMaxG * 2 * 4 * 6 * kMidEdge * 8;
+    // [abort word] [MID_REPS copies of the partial sums: 2 parities x 14 granules x G, + one page] [edge pixels: G x 2 parities x 4 sides x 6 arrays x 128 granules] [weights of the 12-16-slot sub-domains: G x 16 slots x 4 x 512 floats]
+    return 256 + (size_t)MID_REPS * kMidRepStride + (size_t)kMidMaxG * 2 * 4 * 6 * kMidEdge * 8 + (size_t)kMidMaxG * 16 * 4 * kMidT * sizeof(float);
 }
 
 #endif
@@ -599,6 +626,7 @@ hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom
     A.abort_word = reinterpret_cast<unsigned int *>(ws + 8);
     A.parts = reinterpret_cast<unsigned long long *>(ws + 256);
     A.edges = reinterpret_cast<unsigned long long *>(ws + 256 + (size_t)MID_REPS * kMidRepStride);
+    A.wspill = reinterpret_cast<float *>(ws + 256 + (size_t)MID_REPS * kMidRepStride + (size_t)kMidMaxG * 2 * 4 * 6 * kMidEdge * 8);
     A.tag0 = seq * (unsigned)(kcap + 2);                   // granule tags of this solve: tag0 + 1 .. tag0 + kcap
     const size_t lds = mid_lds_bytes(g.P);
 #define MID_LAUNCH(P) \

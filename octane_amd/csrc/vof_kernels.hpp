@@ -154,6 +154,7 @@ struct MidArgs {
     unsigned int *abort_word;        // raised when a wait timed out
     unsigned long long *parts;       // [2 parities][14 = 7 sums x low / high half][kMidMaxG] granules
     unsigned long long *edges;       // [G][2 parities][4 sides][6 arrays][128] granules
+    float *wspill;                   // sub-domains of more than 10 slots: the four merged neighbour weights, [G][slot][4][512 threads]
 };
 int  pcg_mid_config(int w, int h, int ncu, int force_p, MidGeom *g);
 void set_mid_min_p(int p);          // smallest slot count pcg_mid_config may choose (developer knob OCTANE_TUNE_PERSIST_MINP)
