@@ -63,11 +63,12 @@ def test_persistent_solve_equals_one_launch_per_iteration(capi, nx, ny, nc, prm)
     assert d < 1e-5          # two groupings of the fp64 partial sums over hundreds of iterations (measured 3e-6)
 
 
-@pytest.mark.parametrize("slots", [4, 8, 12, 16])
+@pytest.mark.parametrize("slots", [1, 2, 4, 6, 8, 10, 12, 14, 16])
 def test_every_slot_count_of_the_persistent_solve(capi, oracle, slots):
-    """The kernel is built for 4, 8, 12 and 16 slots of 8 rows per thread; a 448 x 300 level fits all of them (7 x 10, 7 x 5,
-    7 x 4 and 7 x 3 sub-domains).  Each against the oracle."""
-    nx, ny = 448, 300
+    """The kernel is built for 1, 2, 4, 6 ... 16 slots of 8 rows per thread; a 448 x 300 level fits those from 4 on (7 x 10 ... 7 x 3
+    sub-domains), a 320 x 200 level the one- and two-slot forms (5 x 25 and 5 x 13: they are limited to 128 workgroups).  From 12
+    slots on the neighbour weights come from the L2 workspace instead of registers.  Each against the oracle."""
+    nx, ny = (448, 300) if slots >= 4 else (320, 200)
     a, b = synth.lattice_scene(nx, ny, seed=71)
     prm = dict(kiters=1, liters=2, cgiters=14)
     uo, vo, io = oracle.flow(a, b, oracle.FlowParams(**prm), dot_threads=oracle.REF_GRID_THREADS)
