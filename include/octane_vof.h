@@ -131,6 +131,12 @@ int octane_vof_plan_get_launch_times(octane_vof_plan *plan, float *ms, int cap);
  * defer_x, small, unit_w, fused, fused_q, fused_rows}.  Results agree for every setting to the last bits of the PCG
  * scalars (the grouping of the fp64 partial sums follows the grid); only speed changes. */
 int octane_vof_tune(octane_vof_plan *plan, const char *key, int value);
+/* Which sub-domain grid the persistent mid-level solve (pcg_persist.hip) takes for a level of w x h pixels on a device with `ncu`
+ * compute units: out5 = {columns of sub-domains, rows of sub-domains, rows per sub-domain, slots of 8 rows per thread, workgroups}.
+ * Returns 1, or 0 when the level does not fit the device (such levels run one launch per PCG iteration).  Host arithmetic only: no
+ * GPU is touched.  (The plan additionally keeps levels of <= 1536 pixels for the single-workgroup solve and levels above 2 Mi pixels
+ * for the streaming kernel.) */
+int octane_vof_mid_geometry(int w, int h, int ncu, int *out5);
 /* Self-test of the persistent PCG kernel's three-instruction reciprocal (hardware estimate + one fused Newton step) against the
  * IEEE division on every positive normal float whose reciprocal is normal: out3 = {patterns compared, mismatches, one
  * mismatching bit pattern}.  No reference counterpart (the reference divides, ref .cu:141-149). */

@@ -1593,6 +1593,15 @@ extern "C" int octane_selftest_rcp(int device, unsigned long long *out3)
 }
 
 // Developer knob setter (the same knobs the OCTANE_TUNE_* environment variables set at plan creation).
+extern "C" int octane_vof_mid_geometry(int w, int h, int ncu, int *out5)
+{
+    if (!out5 || w < 1 || h < 1 || ncu < 1) { g_last_error = "octane_vof_mid_geometry: invalid argument"; return OCTANE_E_INVALID; }
+    MidGeom g;
+    if (pcg_mid_config(w, h, ncu, 0, &g) != 1) return 0;
+    out5[0] = g.gx; out5[1] = g.gy; out5[2] = g.bh; out5[3] = g.P; out5[4] = g.G;
+    return 1;
+}
+
 extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
 {
     if (!key) return OCTANE_E_INVALID;

@@ -47,6 +47,35 @@ def test_product_library_carries_no_diagnostics(capi):
             assert hasattr(D, name), f"{name} missing from the diagnostic library"
 
 
+def test_sub_domain_grid_of_the_persistent_solve(capi):
+    """Host arithmetic only (no GPU): which grid of 64-column sub-domains the persistent mid-level solve takes on a 256-CU device.
+    The smallest slot count that fits; one- and two-slot sub-domains only up to 128 workgroups."""
+    L = capi.lib()
+    L.octane_vof_mid_geometry.restype = C.c_int
+    L.octane_vof_mid_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+
+    def geo(w, h, ncu=256):
+        out = (C.c_int * 5)()
+        rc = L.octane_vof_mid_geometry(w, h, ncu, out)
+        return (rc,) + tuple(out)
+
+    # (fits, columns, rows of sub-domains, rows per sub-domain, slots, workgroups) for the mid-size levels of configs[1] and of R1
+    assert geo(63, 63) == (1, 1, 8, 8, 1, 8)
+    assert geo(125, 125) == (1, 2, 16, 8, 1, 32)
+    assert geo(250, 250) == (1, 4, 32, 8, 1, 128)
+    assert geo(313, 313) == (1, 5, 20, 16, 2, 100)          # one slot would need 200 workgroups
+    assert geo(500, 500) == (1, 8, 16, 32, 4, 128)          # two slots 256
+    assert geo(625, 625) == (1, 10, 20, 32, 4, 200)
+    assert geo(1000, 1000) == (1, 16, 16, 64, 8, 256)
+    assert geo(1250, 1250) == (1, 20, 12, 112, 14, 240)
+    for w, h in ((63, 63), (313, 313), (1250, 1250), (700, 90), (64, 2000)):      # the grid covers the level
+        rc, gx, gy, bh, p, g = geo(w, h)
+        assert rc == 1 and gx * gy == g and gx * 64 >= w and gy * bh >= h and (gy - 1) * bh < h and bh <= 8 * p and bh % 8 == 0
+    assert geo(2000, 2000)[0] == 0 and geo(20000, 50)[0] == 0   # do not fit 256 CUs at 16 slots / 256 columns of sub-domains
+    assert geo(250, 250, 16)[:1] + geo(250, 250, 16)[4:] == (1, 8, 16)   # a lane of a batch (16 CUs): 4 x 4 sub-domains of 8 slots
+    assert L.octane_vof_mid_geometry(0, 5, 256, (C.c_int * 5)()) < 0
+
+
 def test_default_params_are_the_reference_cli_defaults(capi):
     p = capi.default_params()      # ref src/main.cc:78-96
     assert (p.alpha, p.lambda_, p.lambdac, p.scaleF) == (5.0, 1.0, 0.0, 0.5)
