@@ -7,8 +7,9 @@
 // Why: between the levels one workgroup can hold (k_pcg_solve_small, <= 6144 pixels) and the levels that stream from HBM
 // (>= 2 Mpixel) lie the levels whose PCG iteration is pure latency: 10-15 us per launch at 156^2 .. 625^2 and 33 us at
 // 1250^2 for a working set that fits the chip's registers and LDS several times over (256 CUs x (512 KB + 160 KB)).  Here
-// the level is cut into sub-domains of 64 columns x up to 128 rows, one 512-thread workgroup (one CU) each; r, p, q and the
-// operator of a pixel stay in its thread's registers and x in LDS for the whole solve.  Per iteration a workgroup
+// the level is cut into sub-domains of 64 columns x 8 .. 128 rows (1 .. 16 slots of 8 rows per thread: the fewest that fit the
+// CUs, pcg_mid_config), one 512-thread workgroup (one CU) each; r, q and the operator of a pixel stay in its thread's registers
+// (from 12 slots on the four neighbour weights in an L2 workspace, MID_WREG_P), p and x in LDS for the whole solve.  Per iteration a workgroup
 //   * folds the G x 7 partial sums of the previous iteration (every workgroup folds all of them in the same order, so all
 //     take the same alpha, beta and stop decision),
 //   * recomputes p_k on its one-pixel ring from r, q, p of the neighbouring sub-domains' edge pixels (published by their
