@@ -127,7 +127,7 @@ int octane_vof_plan_get_profile(octane_vof_plan *plan, octane_vof_profile *out);
  * launch, the first GNC step's weights are the constant -1 and are not read): bench.py prices each kind on its own bytes.  Returns
  * the number of launches recorded; writes min(that, cap) values. */
 int octane_vof_plan_get_launch_times(octane_vof_plan *plan, float *ms, int cap);
-/* Developer knob (what the OCTANE_TUNE_* environment variables set): key in {pass_a, max_blocks, reverse_b, xcd, nt,
+/* Developer knob (what the OCTANE_TUNE_* environment variables set): key in {overlap, persist, persist_p, small_max, pass_a, max_blocks, reverse_b, xcd, nt,
  * defer_x, small, unit_w, fused, fused_q, fused_rows}.  Results agree for every setting to the last bits of the PCG
  * scalars (the grouping of the fp64 partial sums follows the grid); only speed changes. */
 int octane_vof_tune(octane_vof_plan *plan, const char *key, int value);

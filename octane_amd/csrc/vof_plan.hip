@@ -1626,6 +1626,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "persist") pl->use_persist = value != 0;
     else if (k == "persist_step") pl->persist_step = value;
     else if (k == "persist_p") pl->persist_p = value;
+    else if (k == "overlap") pl->use_overlap = value != 0;
     else if (k == "persist_fault") set_mid_fault(value);
     else if (k == "persist_max_g") pl->persist_max_g = value;
     else if (k == "lane_mode") { if (value) plan_lane_mode(pl); else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 1536; } }

@@ -254,6 +254,34 @@ def test_runs_are_bitwise_reproducible(capi):
     assert np.array_equal(u1, u3) and np.array_equal(v1, v3)
 
 
+@pytest.mark.parametrize("nx,ny,nc,prm,guess", [
+    (333, 217, 1, dict(kiters=4), False),
+    (300, 260, 3, dict(kiters=3, lambdac=0.5), True),      # the hint term: every level has its own decimated first guess
+    (2200, 1100, 1, dict(kiters=3, liters=1, cgiters=5), False),
+])
+def test_level_setup_on_the_side_stream_changes_no_bit(capi, nx, ny, nc, prm, guess):
+    """Round 3: the pyramid images, the first-guess hint and the gradient fields of level k + 1 are prepared on the plan's side stream,
+    in a second set of planes, while level k is solved.  Placement in time only: the flow must have the bits of the one-stream run,
+    also when the same plan runs repeatedly (the sets alternate by level parity; a run reuses what the previous one left)."""
+    a, b = synth.lattice_scene(nx, ny, seed=nx + 7 * ny, nchan=nc)
+    rng = np.random.RandomState(3)
+    u0 = (1.5 * rng.randn(ny, nx)).astype(np.float32) if guess else None
+    v0 = (1.5 * rng.randn(ny, nx)).astype(np.float32) if guess else None
+    pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm))
+    try:
+        pl.tune("overlap", 0)
+        ur, vr = pl.run_host(a, b, u0, v0)
+        its = pl.last_iterations()
+        pl.tune("overlap", 1)
+        for rep in range(3):
+            u, v = pl.run_host(a, b, u0, v0)
+            assert pl.last_iterations() == its
+            assert np.array_equal(u, ur) and np.array_equal(v, vr), f"run {rep} with the side stream differs from the one-stream run"
+    finally:
+        pl.close()
+    assert np.isfinite(ur).all()
+
+
 @pytest.mark.parametrize("cgiters", [1, 2, 7, 30])
 def test_deferred_x_update_is_bitwise_identical(capi, cgiters):
     """Pass B applies x += alpha p for two iterations at once (every second launch) in the reference's order of
