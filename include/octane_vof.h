@@ -230,6 +230,63 @@ int octane_vof_mp_banded_levels(const octane_vof_mp *m);
 long long octane_vof_mp_last_iterations(octane_vof_mp *m);
 int octane_vof_mp_destroy(octane_vof_mp *m);
 
+/* ---- transports of the row-band solve, the collective one, and the first-contact self-check (round 4) ----------------
+ * What crosses bands (per PCG iteration the seven partial sums of every workgroup and a few rows per inner edge; per
+ * linearisation two rows of the flow; per level the bands of the flow) can travel three ways.  All three run the same kernels in
+ * the same order on the same values -- one global PCG per linearisation, ref .cu:1105-1195 -- and give the same bits:
+ *   INPLACE     the consuming kernel reads the neighbouring band's memory through peer / IPC mappings (LDS-DMA included)
+ *   COPY        stream-ordered runtime copies (hipMemcpyPeerAsync, hipMemcpyAsync on IPC mappings) pull the same bytes into the
+ *               band's own planes / a local mirror; kernels read local memory only
+ *   COLLECTIVE  (one band per process only) the HOST PROGRAM'S collective library moves them: an all-gather of the partial blocks
+ *               and point-to-point sends / receives of the rows, through the callbacks below -- torch.distributed in this
+ *               repository (octane_amd/exchange.py: backend nccl = RCCL over xGMI on a node, gloo staged through the host);
+ *               needs neither peer access nor HIP IPC.  north_star: "RCCL over xGMI only for halo exchange / result gather".
+ * OCTANE_TILED_TRANSPORT=inplace|copy|collective in the environment forces one.  Otherwise creation runs a FIRST-CONTACT
+ * SELF-CHECK on the devices / ranks it was given: a small two-level frame (bands of 2 Mpixel when the real plan's bands run the
+ * q-recomputing LDS-DMA kernel) is solved by the plain single-device plan and as row bands under each candidate in the order
+ * inplace -> inplace with register staging instead of LDS-DMA from the neighbour -> copy -> collective, and the first candidate whose
+ * flow is within 2e-5 of the plain plan's with equal iteration counts is what the plan uses (one line on stderr when that is not the
+ * first).  No peer access / an IPC mapping that cannot be opened removes the candidates that need it instead of failing creation.
+ * OCTANE_TILED_SELFCHECK=0 skips the check (inplace where possible).  No reference counterpart (the reference is single-GPU). */
+#define OCTANE_TRANSPORT_INPLACE    0
+#define OCTANE_TRANSPORT_COPY       1
+#define OCTANE_TRANSPORT_COLLECTIVE 2
+typedef struct octane_vof_transport_info {
+    int transport;            /* OCTANE_TRANSPORT_* the plan uses */
+    int q_dma;                /* 1: q-form band launches fetch the neighbour's rows by LDS-DMA; 0: register-staged kernel */
+    int selfcheck;            /* 0 not run (one band, forced, switched off); 1 the first candidate passed; 2 downgraded; -1 none passed */
+    int candidates_tried;
+    int forced;               /* OCTANE_TILED_TRANSPORT named the transport */
+    int peer_ok;              /* every pair of distinct devices has peer access (thread form) / every IPC mapping opened (process form) */
+    int ndevices;             /* distinct devices among the bands (process form: ranks on distinct GPUs) */
+    int nbands;
+    double check_rel_l2[4];   /* distance to the plain plan of candidate i of the self-check (-1: not tried) */
+    char exchange[48];        /* name of the host program's collective library when one was registered, else "" */
+} octane_vof_transport_info;
+int octane_vof_tiled_transport_info(const octane_vof_tiled *t, octane_vof_transport_info *out);
+int octane_vof_mp_transport_info(const octane_vof_mp *m, octane_vof_transport_info *out);
+const char *octane_vof_transport_name(int transport);
+/* The collective transport's callbacks.  Every buffer is device memory of the calling rank's GPU; the library has drained its
+ * stream before a call and a call returns when its data is in place (host-synchronous).  Both are collective over the ranks:
+ *   all_gather  every rank contributes `bytes` bytes at `send`; rank c's contribution has to arrive at recv[c] (c != own rank;
+ *               recv[own] is NULL)
+ *   sendrecv    n transfers, all posted before any is waited for; ops[i] sends (send = 1) or receives `bytes` bytes to / from rank
+ *               `peer`.  Between a pair of ranks the k-th send of one matches the k-th receive of the other.
+ * Return 0 on success. */
+typedef struct octane_vof_xfer { int peer; int send; void *buf; size_t bytes; } octane_vof_xfer;
+typedef struct octane_vof_exchange {
+    void *user;
+    int (*all_gather)(void *user, const void *send, void *const *recv, size_t bytes);
+    int (*sendrecv)(void *user, int n, const octane_vof_xfer *ops);
+    char name[48];            /* e.g. "torch.distributed/nccl"; reported by octane_vof_mp_transport_info */
+} octane_vof_exchange;
+/* Between octane_vof_mp_create and octane_vof_mp_connect, on every rank or on none. */
+int octane_vof_mp_set_exchange(octane_vof_mp *m, const octane_vof_exchange *ex);
+/* The self-check of the process form: collective, after octane_vof_mp_connect.  `ag` all-gathers bytes_per_rank bytes per rank in
+ * rank order (the host program's all-gather that also carried the IPC handles); the check builds a small group of its own with it. */
+typedef int (*octane_allgather_bytes_fn)(void *user, const void *mine, void *all, size_t bytes_per_rank);
+int octane_vof_mp_selfcheck(octane_vof_mp *m, octane_allgather_bytes_fn ag, void *user);
+
 /* ---- patch matching (-sosm): the second flow method behind the reference's dispatch wrapper -------------------------
  * Per pixel: centre the search at the truncated, clamped first guess (u/v in), visit the (2 srad + 1)^2 displacements
  * in the reference's spiral order, keep the first strict minimum of the (2 rad + 1)^2 sum of squared differences (fp64),

@@ -36,6 +36,8 @@ EXPORTS = (
     "octane_vof_tiled_device_bytes", "octane_vof_band_partition",
     "octane_vof_mp_create", "octane_vof_mp_handles", "octane_vof_mp_connect", "octane_vof_mp_run", "octane_vof_mp_banded_levels",
     "octane_vof_mp_last_iterations", "octane_vof_mp_destroy",
+    "octane_vof_tiled_transport_info", "octane_vof_mp_transport_info", "octane_vof_transport_name", "octane_vof_mp_set_exchange",
+    "octane_vof_mp_selfcheck",
     "octane_pix2uv_run", "octane_navcal_run", "octane_bandminmax",
     "octane_proj_navcal_run", "octane_uv2pix_run", "octane_srsal_run", "octane_sosm_run",
     "octane_last_error", "octane_device_count",
@@ -71,6 +73,34 @@ class NavcalParams(C.Structure):
 
 
 CAL_RAW, CAL_TEMP, CAL_REF, CAL_BRIT = 0, 1, 2, 3
+TRANSPORT_INPLACE, TRANSPORT_COPY, TRANSPORT_COLLECTIVE = 0, 1, 2
+TRANSPORT_NAMES = ("inplace", "copy", "collective")
+
+
+class TransportInfo(C.Structure):
+    """octane_vof_transport_info: what the first-contact self-check of a row-band plan decided (include/octane_vof.h)."""
+    _fields_ = [("transport", C.c_int), ("q_dma", C.c_int), ("selfcheck", C.c_int), ("candidates_tried", C.c_int), ("forced", C.c_int),
+                ("peer_ok", C.c_int), ("ndevices", C.c_int), ("nbands", C.c_int), ("check_rel_l2", C.c_double * 4), ("exchange", C.c_char * 48)]
+
+    def as_dict(self):
+        return {"transport_used": TRANSPORT_NAMES[self.transport] if 0 <= self.transport < 3 else str(self.transport),
+                "q_dma": bool(self.q_dma), "selfcheck": {0: "not run", 1: "first candidate passed", 2: "downgraded", -1: "failed"}.get(self.selfcheck, self.selfcheck),
+                "candidates_tried": self.candidates_tried, "forced": bool(self.forced), "peer_ok": bool(self.peer_ok),
+                "devices": self.ndevices, "bands": self.nbands, "check_rel_l2": [x for x in self.check_rel_l2 if x >= 0],
+                "exchange": self.exchange.decode() or None}
+
+
+class Xfer(C.Structure):
+    _fields_ = [("peer", C.c_int), ("send", C.c_int), ("buf", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+XCHG_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t)
+XCHG_SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Xfer))
+ALLGATHER_BYTES_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class Exchange(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", XCHG_ALL_GATHER_FN), ("sendrecv", XCHG_SENDRECV_FN), ("name", C.c_char * 48)]
 
 TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                        C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int)
@@ -177,6 +207,12 @@ def lib() -> C.CDLL:
     L.octane_vof_mp_last_iterations.argtypes = [vp]
     L.octane_vof_mp_last_iterations.restype = C.c_longlong
     L.octane_vof_mp_destroy.argtypes = [vp]
+    L.octane_vof_tiled_transport_info.argtypes = [vp, C.POINTER(TransportInfo)]
+    L.octane_vof_mp_transport_info.argtypes = [vp, C.POINTER(TransportInfo)]
+    L.octane_vof_transport_name.argtypes = [C.c_int]
+    L.octane_vof_transport_name.restype = C.c_char_p
+    L.octane_vof_mp_set_exchange.argtypes = [vp, C.POINTER(Exchange)]
+    L.octane_vof_mp_selfcheck.argtypes = [vp, ALLGATHER_BYTES_FN, vp]
     L.octane_pix2uv_run.argtypes = [C.POINTER(Nav), C.c_double, C.c_double, vp, vp, C.c_int, C.c_int,
                                     vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
     L.octane_navcal_run.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(NavcalParams), vp, vp, vp, vp, vp, vp, C.c_int]
@@ -443,6 +479,14 @@ class TiledPlan:
     def last_copies(self) -> int:
         return int(lib().octane_vof_tiled_last_copies(self._h))
 
+    def transport_info(self) -> dict:
+        """Which transport the bands use and what the first-contact self-check found (octane_vof_transport_info)."""
+        ti = TransportInfo()
+        rc = lib().octane_vof_tiled_transport_info(self._h, C.byref(ti))
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_tiled_transport_info")
+        return ti.as_dict()
+
 
 MP_HANDLE_BYTES = 128
 
@@ -450,16 +494,23 @@ MP_HANDLE_BYTES = 128
 class MpPlan:
     """One band of a row-band solve with one band per process (octane_vof_mp_*).  Every method is collective over the
     `world` ranks.  `all_gather` is a callable taking this rank's bytes and returning the list of every rank's bytes in
-    rank order (e.g. a wrapper of torch.distributed.all_gather_object)."""
+    rank order (e.g. a wrapper of torch.distributed.all_gather_object).  `exchange` (optional; octane_amd.exchange.TorchExchange)
+    is the host program's collective library for the collective transport: with it the bands still solve the frame where HIP IPC
+    is not available, and the first-contact self-check (run here unless selfcheck=False) may fall back to it."""
 
     def __init__(self, nx: int, ny: int, nchan: int, params: FlowParams, rank: int, world: int, shm_name: str, all_gather,
-                 min_band_pixels: int = 0):
+                 min_band_pixels: int = 0, exchange=None, selfcheck: bool = True):
         self.nx, self.ny, self.nchan, self.rank, self.world = nx, ny, nchan, rank, world
         self._h = C.c_void_p()
+        self._exchange = exchange
         p = params.c()
         rc = lib().octane_vof_mp_create(C.byref(self._h), nx, ny, nchan, C.byref(p), rank, world, min_band_pixels, shm_name.encode())
         if rc != OK:
             raise OctaneError(rc, "octane_vof_mp_create")
+        if exchange is not None:
+            rc = lib().octane_vof_mp_set_exchange(self._h, C.byref(exchange.c_struct()))
+            if rc != OK:
+                raise OctaneError(rc, "octane_vof_mp_set_exchange")
         buf = C.create_string_buffer(MP_HANDLE_BYTES)
         rc = lib().octane_vof_mp_handles(self._h, buf)
         if rc != OK:
@@ -469,6 +520,27 @@ class MpPlan:
         rc = lib().octane_vof_mp_connect(self._h, C.create_string_buffer(b"".join(blobs), MP_HANDLE_BYTES * world))
         if rc != OK:
             raise OctaneError(rc, "octane_vof_mp_connect")
+
+        def _ag(user, mine, allp, nbytes):          # the library's byte all-gather, carried by the host program's
+            try:
+                got = all_gather(C.string_at(mine, nbytes))
+                C.memmove(allp, b"".join(got), nbytes * world)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print(f"octane MpPlan: all-gather callback failed: {e!r}", flush=True)
+                return 1
+        self._ag = ALLGATHER_BYTES_FN(_ag)
+        if selfcheck:
+            rc = lib().octane_vof_mp_selfcheck(self._h, self._ag, None)
+            if rc != OK:
+                raise OctaneError(rc, "octane_vof_mp_selfcheck")
+
+    def transport_info(self) -> dict:
+        ti = TransportInfo()
+        rc = lib().octane_vof_mp_transport_info(self._h, C.byref(ti))
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_mp_transport_info")
+        return ti.as_dict()
 
     def close(self):
         if self._h:

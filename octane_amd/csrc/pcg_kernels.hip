@@ -1624,7 +1624,7 @@ void launch_pcg_fused(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev,
 #ifdef OCTANE_DIAG
     if (g_q_diag && L.q_form && whole) { launch_pcg_fused_q_diag(s, L, k, nparts_prev, grid, tol); return; }
 #endif
-    if (g_q_dma && L.q_form) { launch_pcg_fused_q_dma(s, L, k, nparts_prev, grid, tol); return; }      // whole levels and row bands
+    if (g_q_dma && !L.no_dma && L.q_form) { launch_pcg_fused_q_dma(s, L, k, nparts_prev, grid, tol); return; }      // whole levels and row bands
     if (L.q_form) {                                                    // q = A p is not stored but formed again
         if (whole) {
             if (L.unit_w) hipLaunchKernelGGL((k_pcg_fused_q<true, false>), dim3(grid), dim3(256), 0, s, L, k, nparts_prev, tol);

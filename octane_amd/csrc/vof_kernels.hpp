@@ -84,6 +84,8 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     int unit_w;                     // this linearisation has al1 == 1: wx == wy == -1 everywhere, pass A need not read them
     int lean;                       // the fused kernels are the only readers: the assembly skips the planes they never read
                                     // (mu, mv; wx, wy while unit_w) and the flow update does not write x back
+    int no_dma;                     // row bands whose first-contact self-check (vof_tiled.hip) found LDS-DMA from the neighbouring band's
+                                    // memory wanting: q-form launches take the register-staged kernel (host-side dispatch only)
 };
 
 struct AssembleParams {

@@ -127,6 +127,7 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
     L.nt_hints = pl->nt_hints;
     L.unit_w = 0;
     L.lean = 0;
+    L.no_dma = 0;
 }
 
 void octane::plan_fill_level_ptrs(octane_vof_plan *pl, int k, int cur, const LevelCtx &c, LevelPtrs &L)
@@ -506,7 +507,7 @@ extern "C" int octane_vof_plan_set_profiling(octane_vof_plan *pl, int enable)
 static int emit(octane_vof_plan *pl, hipStream_t s, const char *tag, int k, int gnc, int l,
                 std::initializer_list<const float *> planes, int w, int h, int pitch)
 {
-    if (!pl->trace) return OCTANE_OK;
+    if (!pl->trace || (pl->trace_levels > 0 && k >= pl->trace_levels)) return OCTANE_OK;
     std::vector<float> host((size_t)w * h * planes.size());
     HIP_TRY(hipStreamSynchronize(s));
     size_t i = 0;
@@ -1627,6 +1628,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "persist_step") pl->persist_step = value;
     else if (k == "persist_p") pl->persist_p = value;
     else if (k == "overlap") pl->use_overlap = value != 0;
+    else if (k == "trace_levels") pl->trace_levels = value;          // the debug tap reports the `value` coarsest levels only (0: all)
     else if (k == "persist_fault") set_mid_fault(value);
     else if (k == "persist_max_g") pl->persist_max_g = value;
     else if (k == "lane_mode") { if (value) plan_lane_mode(pl); else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 1536; } }

@@ -49,6 +49,7 @@ struct octane_vof_plan {
     int use_overlap = 1;                    // OCTANE_TUNE_OVERLAP=0: everything on one stream, level by level
     octane_vof_trace_fn trace = nullptr;
     void *trace_user = nullptr;
+    int trace_levels = 0;                   // > 0: the debug tap reports only that many coarsest levels (tune key "trace_levels")
     int profiling = 0;
     std::vector<EvPair> evs;
     size_t evs_used = 0;

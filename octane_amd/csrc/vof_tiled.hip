@@ -40,8 +40,10 @@
 // devices, plain device copies between bands that share a device).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +69,38 @@ using namespace octane;
 
 struct BandRows { int y0, y1; };
 
+extern "C" const char *octane_vof_transport_name(int transport)
+{
+    return transport == OCTANE_TRANSPORT_INPLACE ? "inplace" : transport == OCTANE_TRANSPORT_COPY ? "copy" :
+           transport == OCTANE_TRANSPORT_COLLECTIVE ? "collective" : "unknown";
+}
+// OCTANE_TILED_TRANSPORT=inplace|copy|collective forces a transport (-1: not set, -2: set to something else)
+static int forced_transport()
+{
+    const char *e = getenv("OCTANE_TILED_TRANSPORT");
+    if (!e || !*e || std::string(e) == "auto") return -1;
+    for (int t = 0; t < 3; t++) if (std::string(e) == octane_vof_transport_name(t)) return t;
+    return -2;
+}
+static bool selfcheck_enabled()
+{
+    const char *e = getenv("OCTANE_TILED_SELFCHECK");
+    return !(e && std::string(e) == "0");
+}
+static int test_break_bits()
+{
+#ifdef OCTANE_DIAG
+    if (const char *e = getenv("OCTANE_TEST_BREAK_TRANSPORT")) return atoi(e);
+#endif
+    return 0;
+}
+static void info_reset(octane_vof_transport_info &in, int nbands)
+{
+    std::memset(&in, 0, sizeof in);
+    in.q_dma = 1; in.peer_ok = 1; in.nbands = nbands; in.ndevices = 1;
+    for (int i = 0; i < 4; i++) in.check_rel_l2[i] = -1.;
+}
+
 struct octane_vof_tiled {
     int nx = 0, ny = 0, nc = 0, nbands = 0;
     octane_vof_params prm;
@@ -81,6 +115,9 @@ struct octane_vof_tiled {
     int loaded = 0;
     long long copies = 0;                       // peer copies issued by the last solve (diagnostic)
     bool aborted = false;                       // a persistent mid-level solve of the last solve gave up: its flow is not valid
+    int transport = OCTANE_TRANSPORT_INPLACE;   // what the self-check (or OCTANE_TILED_TRANSPORT) chose
+    bool no_dma = false;                        // q-form band launches by the register-staged kernel
+    octane_vof_transport_info info;
 };
 
 static int round_to(int v, int m) { return (v + m / 2) / m * m; }
@@ -116,8 +153,148 @@ extern "C" int octane_vof_tiled_destroy(octane_vof_tiled *t)
     return OCTANE_OK;
 }
 
+// ---- first-contact self-check ----------------------------------------------------------------------------------------
+// A synthetic pair every rank can build for itself, bit for bit (the ranks share the node's libm): separable cosines, image 2 = image 1
+// moved by (1.25, -0.75) pixels.
+static void check_scene(int w, int h, std::vector<float> &a, std::vector<float> &b)
+{
+    const double lx[4] = {23., 37., 61., 97.}, ly[4] = {29., 41., 53., 89.}, dx = 1.25, dy = -0.75;
+    std::vector<double> cx[4], cy[4], sx[4], sy[4];
+    for (int k = 0; k < 4; k++) {
+        cx[k].resize(w); sx[k].resize(w); cy[k].resize(h); sy[k].resize(h);
+        for (int i = 0; i < w; i++) { cx[k][i] = std::cos(6.283185307179586 * i / lx[k] + 0.7 * k); sx[k][i] = std::cos(6.283185307179586 * (i - dx) / lx[k] + 0.7 * k); }
+        for (int j = 0; j < h; j++) { cy[k][j] = std::cos(6.283185307179586 * j / ly[k] + 1.3 * k); sy[k][j] = std::cos(6.283185307179586 * (j - dy) / ly[k] + 1.3 * k); }
+    }
+    a.resize((size_t)w * h); b.resize((size_t)w * h);
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            double va = 127.5, vb = 127.5;
+            for (int k = 0; k < 4; k++) { va += 25. * cx[k][i] * cy[k][j]; vb += 25. * sx[k][i] * sy[k][j]; }
+            a[(size_t)j * w + i] = (float)va; b[(size_t)j * w + i] = (float)vb;
+        }
+}
+static double flow_rel_l2(const std::vector<float> &u, const std::vector<float> &v, const std::vector<float> &uo, const std::vector<float> &vo, bool *finite)
+{
+    double num = 0., den = 0.;
+    bool fin = true;
+    for (size_t i = 0; i < u.size(); i++) {
+        const double du = (double)u[i] - uo[i], dv = (double)v[i] - vo[i];
+        num += du * du + dv * dv; den += (double)uo[i] * uo[i] + (double)vo[i] * vo[i];
+        fin = fin && std::isfinite(u[i]) && std::isfinite(v[i]);
+    }
+    if (finite) *finite = fin;
+    return den > 0. ? std::sqrt(num / den) : (num > 0. ? 1. : 0.);
+}
+// The check frame: two pyramid levels, both banded.  `large`: the finer level's bands hold 2 Mpixel -- the size from which band
+// launches are the q-recomputing kernel that fetches the neighbour's rows by LDS-DMA (pcg_fused_q_form) -- the coarser level's
+// bands run the stored-q kernel; small: both levels on the stored-q kernel.
+static void check_geometry(int nbands, bool large, int *w, int *h) { *w = large ? 2048 : 512; *h = (large ? 1024 : 128) * nbands; }
+static octane_vof_params check_params(const octane_vof_params &p, int device)
+{
+    octane_vof_params c = p;
+    c.kiters = 2; c.liters = 1; c.cgiters = 6; c.device = device;
+    return c;
+}
+constexpr double kCheckBar = 2e-5;      // banded against plain: two groupings of the same fp64 partial sums (bit-identical in every run so far)
+struct Candidate { int transport; bool no_dma; };
+
+static int plain_check_flow(const octane_vof_params &cp, int w, int h, const std::vector<float> &a, const std::vector<float> &b,
+                            std::vector<float> &u, std::vector<float> &v, long long *iters)
+{
+    octane_vof_plan *pl = nullptr;
+    int rc = plan_create_ex(&pl, w, h, 1, &cp, 1);
+    if (rc != OCTANE_OK) return rc;
+    u.assign((size_t)w * h, 0.f); v.assign((size_t)w * h, 0.f);
+    rc = octane_vof_plan_run(pl, a.data(), b.data(), u.data(), v.data(), OCTANE_MEM_HOST, nullptr);
+    if (rc == OCTANE_OK) *iters = octane_vof_plan_last_iterations(pl);
+    octane_vof_plan_destroy(pl);
+    return rc;
+}
+
+static int tiled_create_impl(octane_vof_tiled **out, int nx, int ny, int nchan, const octane_vof_params *p,
+                             int nbands, const int *devices, long long min_band_pixels, bool allow_selfcheck);
+
+struct CheckResult { int transport; bool no_dma; octane_vof_transport_info info; };
+static std::mutex g_check_mu;
+static std::vector<std::pair<std::string, CheckResult>> g_check_cache;     // per process: (devices, size class, drill bits) -> verdict
+
+// Thread form: the bands of `t` as they will run, on a small frame, against the plain plan; picks t->transport / t->no_dma.
+static int tiled_selfcheck(octane_vof_tiled *t)
+{
+    const int nb = t->nbands;
+    bool large = false;                  // does a banded level of the real plan run the q-recomputing kernel?
+    for (size_t k = 0; k < t->rows.size(); k++) {
+        if (t->rows[k].empty()) continue;
+        int maxrows = 0;
+        for (auto &r : t->rows[k]) maxrows = std::max(maxrows, r.y1 - r.y0);
+        if (t->pl[0]->use_fused && pcg_fused_q_form(t->pl[0]->lev[k].w, maxrows, t->pl[0]->lev[k].h)) large = true;
+    }
+    std::string key = (large ? "L" : "S") + std::to_string(test_break_bits()) + (t->info.peer_ok ? "p" : "n");
+    for (int b = 0; b < nb; b++) key += "," + std::to_string(t->dev[b]);
+    {
+        std::lock_guard<std::mutex> g(g_check_mu);
+        for (auto &e : g_check_cache)
+            if (e.first == key) {
+                t->transport = e.second.transport; t->no_dma = e.second.no_dma;
+                const int nd = t->info.ndevices, pk = t->info.peer_ok;
+                t->info = e.second.info; t->info.ndevices = nd; t->info.peer_ok = pk; t->info.nbands = nb;
+                return t->info.selfcheck < 0 ? OCTANE_E_HIP : OCTANE_OK;
+            }
+    }
+    int w, h;
+    check_geometry(nb, large, &w, &h);
+    std::vector<float> a, b2, up, vp, u, v;
+    check_scene(w, h, a, b2);
+    long long its_plain = 0;
+    const octane_vof_params cp = check_params(t->prm, t->dev[0]);
+    int rc = plain_check_flow(cp, w, h, a, b2, up, vp, &its_plain);
+    if (rc != OCTANE_OK) return rc;
+    std::vector<Candidate> cand;
+    if (t->info.peer_ok) { cand.push_back({OCTANE_TRANSPORT_INPLACE, false}); if (large) cand.push_back({OCTANE_TRANSPORT_INPLACE, true}); }
+    cand.push_back({OCTANE_TRANSPORT_COPY, false});
+    octane_vof_tiled *c = nullptr;
+    rc = tiled_create_impl(&c, w, h, 1, &cp, nb, t->dev.data(), 1, false);
+    if (rc != OCTANE_OK) return rc;
+    int chosen = -1;
+    std::string log;
+    for (size_t i = 0; i < cand.size() && chosen < 0; i++) {
+        c->transport = cand[i].transport; c->no_dma = cand[i].no_dma;
+        u.assign((size_t)w * h, 0.f); v.assign((size_t)w * h, 0.f);
+        rc = octane_vof_tiled_run(c, a.data(), b2.data(), u.data(), v.data(), OCTANE_MEM_HOST);
+        bool fin = false;
+        const double d = rc == OCTANE_OK ? flow_rel_l2(u, v, up, vp, &fin) : 1.;
+        const long long its = rc == OCTANE_OK ? octane_vof_tiled_last_iterations(c) : -1;
+        if (i < 4) t->info.check_rel_l2[i] = d;
+        t->info.candidates_tried = (int)i + 1;
+        const bool pass = rc == OCTANE_OK && fin && d <= kCheckBar && its == its_plain;
+        log += std::string(i ? "; " : "") + octane_vof_transport_name(cand[i].transport) + (cand[i].no_dma ? " without LDS-DMA from the neighbour" : "") +
+               (pass ? ": ok" : rc != OCTANE_OK ? std::string(": error (") + octane_last_error() + ")" :
+                       ": rel L2 " + std::to_string(d) + ", iterations " + std::to_string(its) + " / " + std::to_string(its_plain));
+        if (pass) chosen = (int)i;
+    }
+    octane_vof_tiled_destroy(c);
+    t->info.selfcheck = chosen < 0 ? -1 : chosen == 0 ? 1 : 2;
+    if (chosen >= 0) { t->transport = cand[chosen].transport; t->no_dma = cand[chosen].no_dma; }
+    t->info.transport = t->transport; t->info.q_dma = t->no_dma ? 0 : 1;
+    if (chosen != 0)
+        fprintf(stderr, "octane: row-band self-check on devices [%s] (%d x %d, %d bands): %s -> %s\n", key.c_str(), w, h, nb, log.c_str(),
+                chosen < 0 ? "NO transport reproduces the plain plan" : "using the last of these");
+    {
+        std::lock_guard<std::mutex> g(g_check_mu);
+        g_check_cache.push_back({key, {t->transport, t->no_dma, t->info}});
+    }
+    if (chosen < 0) { set_last_error("octane_vof_tiled_create: the first-contact self-check failed under every transport: " + log); return OCTANE_E_HIP; }
+    return OCTANE_OK;
+}
+
 extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, int nchan, const octane_vof_params *p,
                                        int nbands, const int *devices, long long min_band_pixels)
+{
+    return tiled_create_impl(out, nx, ny, nchan, p, nbands, devices, min_band_pixels, true);
+}
+
+static int tiled_create_impl(octane_vof_tiled **out, int nx, int ny, int nchan, const octane_vof_params *p,
+                             int nbands, const int *devices, long long min_band_pixels, bool allow_selfcheck)
 {
     if (!out || !p || nbands < 1 || nbands > kMaxBands) {
         set_last_error("octane_vof_tiled_create: invalid argument (1 <= nbands <= 8)");
@@ -128,6 +305,7 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
     if (ndev == 0) { set_last_error("No gpus available for use"); return OCTANE_E_NODEVICE; }
     octane_vof_tiled *t = new octane_vof_tiled();
     t->nx = nx; t->ny = ny; t->nc = nchan; t->nbands = nbands; t->prm = *p;
+    info_reset(t->info, nbands);
     // Below ~12 Mpixel one PCG iteration of the whole level (< 0.25 ms) is cheaper than issuing a banded one.
     t->min_band_pixels = min_band_pixels > 0 ? (long)min_band_pixels : (12L << 20);
     if (const char *e = getenv("OCTANE_TUNE_MIN_BAND_PIXELS")) t->min_band_pixels = atol(e);
@@ -136,12 +314,18 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
         if (d < 0 || d > ndev - 1) d = 0;                     // as the reference treats a bad -set_device (.cu:1260)
         t->dev.push_back(d);
     }
-    // peer access between every pair of distinct devices (an error here only means "already enabled")
+    {
+        std::vector<int> seen;
+        for (int d : t->dev) if (std::find(seen.begin(), seen.end(), d) == seen.end()) seen.push_back(d);
+        t->info.ndevices = (int)seen.size();
+    }
+    // Peer access between every pair of distinct devices ("already enabled" is fine).  The in-place transport needs it: its kernels
+    // dereference the other bands' memory.  Without it (no peer path, or enabling failed) the bands still solve the frame -- by the
+    // copy transport, whose hipMemcpyPeerAsync the runtime stages itself -- and transport_info says peer_ok = 0.
+    std::string peer_note;
     for (int a = 0; a < nbands; a++)
         for (int b = 0; b < nbands; b++)
             if (t->dev[a] != t->dev[b]) {
-                // the PCG kernels read the other bands' partials and edge rows in place: without peer access there is no
-                // solve, so both "cannot" and "could not be enabled" are errors (only "already enabled" is fine)
                 int can = 0;
                 hipError_t pe = hipSetDevice(t->dev[a]);
                 if (pe == hipSuccess) pe = hipDeviceCanAccessPeer(&can, t->dev[a], t->dev[b]);
@@ -150,11 +334,10 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
                     if (pe == hipErrorPeerAccessAlreadyEnabled) pe = hipSuccess;
                 }
                 (void)hipGetLastError();
-                if (pe != hipSuccess || !can) {
-                    set_last_error("octane_vof_tiled_create: device " + std::to_string(t->dev[a]) + " cannot access the memory of device " +
-                                   std::to_string(t->dev[b]) + (pe != hipSuccess ? std::string(": ") + hipGetErrorString(pe) : std::string(" (no peer path)")));
-                    delete t;
-                    return OCTANE_E_INVALID;
+                if ((pe != hipSuccess || !can) && t->info.peer_ok) {
+                    t->info.peer_ok = 0;
+                    peer_note = "device " + std::to_string(t->dev[a]) + " cannot access the memory of device " + std::to_string(t->dev[b]) +
+                                (pe != hipSuccess ? std::string(": ") + hipGetErrorString(pe) : std::string(" (no peer path)"));
                 }
             }
     t->pl.assign(nbands, nullptr);
@@ -168,7 +351,7 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
         // placement trials only when the band has its device to itself (they allocate four arenas)
         int sharing = 0;
         for (int c = 0; c < nbands; c++) sharing += (t->dev[c] == t->dev[b]);
-        rc = plan_create_ex(&t->pl[b], nx, ny, nchan, &pb, sharing > 1 ? 1 : 8);
+        rc = plan_create_ex(&t->pl[b], nx, ny, nchan, &pb, (sharing > 1 || !allow_selfcheck) ? 1 : 8);
         if (rc != OCTANE_OK) break;
         if (hipSetDevice(t->dev[b]) != hipSuccess ||
             hipMalloc((void **)&t->parts[b], (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
@@ -196,7 +379,39 @@ extern "C" int octane_vof_tiled_create(octane_vof_tiled **out, int nx, int ny, i
         for (int b = 0; b < nbands; b++) { r[b].y0 = edges[b]; r[b].y1 = edges[b + 1]; }
         t->rows[k] = r;
     }
+    // Which transport.  Forced by the environment; else the first-contact self-check decides (thread form: inplace -> inplace without
+    // LDS-DMA from the neighbour -> copy); without the check: inplace where every peer is reachable, copy otherwise.
+    t->transport = t->info.peer_ok ? OCTANE_TRANSPORT_INPLACE : OCTANE_TRANSPORT_COPY;
+    const int forced = forced_transport();
+    if (forced == -2 || forced == OCTANE_TRANSPORT_COLLECTIVE) {
+        set_last_error("octane_vof_tiled_create: OCTANE_TILED_TRANSPORT must be inplace or copy here (collective: one band per process, octane_vof_mp_*)");
+        octane_vof_tiled_destroy(t);
+        return OCTANE_E_INVALID;
+    }
+    if (forced == OCTANE_TRANSPORT_INPLACE && !t->info.peer_ok) {
+        set_last_error("octane_vof_tiled_create: OCTANE_TILED_TRANSPORT=inplace, but " + peer_note);
+        octane_vof_tiled_destroy(t);
+        return OCTANE_E_INVALID;
+    }
+    if (forced >= 0) { t->transport = forced; t->info.forced = 1; }
+    else if (!t->info.peer_ok && allow_selfcheck)
+        fprintf(stderr, "octane: row bands: %s -- the in-place transport is not available, using runtime peer copies\n", peer_note.c_str());
+    t->info.transport = t->transport; t->info.q_dma = 1;
+    bool any_banded = false;
+    for (auto &r : t->rows) any_banded = any_banded || !r.empty();
+    if (allow_selfcheck && forced < 0 && nbands > 1 && any_banded && selfcheck_enabled()) {
+        rc = tiled_selfcheck(t);
+        if (rc != OCTANE_OK) { octane_vof_tiled_destroy(t); return rc; }
+    }
     *out = t;
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_tiled_transport_info(const octane_vof_tiled *t, octane_vof_transport_info *out)
+{
+    if (!t || !out) return OCTANE_E_INVALID;
+    *out = t->info;
+    out->transport = t->transport; out->q_dma = t->no_dma ? 0 : 1;
     return OCTANE_OK;
 }
 
@@ -291,12 +506,12 @@ struct BandNet {
     // copy transport: from band `sband`'s memory (as mapped here) into band b's own memory, on band b's stream
     virtual hipError_t pull(int b, void *dst_local, int sband, const void *src, size_t bytes) = 0;
     virtual double *mirror(int b) = 0;                             // band b's local copies of all bands' partial blocks
-    bool copy_transport = false;
-    void read_transport()
-    {
-        const char *e = getenv("OCTANE_TILED_TRANSPORT");
-        copy_transport = e && std::string(e) == "copy";
-    }
+    // collective transport (process form only): the host program's collective library moves the bytes (octane_vof_exchange)
+    virtual int xchg_all_gather(int, const void *, void *const *, size_t) { return -1; }
+    virtual int xchg_sendrecv(int, int, const octane_vof_xfer *) { return -1; }
+    int transport = OCTANE_TRANSPORT_INPLACE;
+    bool no_dma = false;
+    int brk = 0;       // diagnostic library only: OCTANE_TEST_BREAK_TRANSPORT, the drill of the self-check's downgrade
     float *peer(int c, int b, float *plane_of_b) const
     {
         return reinterpret_cast<float *>(arena[c] + (reinterpret_cast<char *>(plane_of_b) - arena[b]));
@@ -338,6 +553,41 @@ static void pull_parts(BandNet &N, int b, int parity, int first, int count)
     }
 }
 
+// collective transport: the same bytes by the host program's collective library.  Every rank calls these at the same points of the
+// level loop with mirrored arguments; the stream has been drained (N.sync) and the calls return when the data is in place.
+static void gather_parts(BandNet &N, int b, int parity, int first, int count)
+{
+    if (N.failed()) return;
+    const size_t off = (size_t)parity * kPartBlock + first;
+    void *recv[kMaxBands];
+    for (int c = 0; c < N.nb; c++) recv[c] = (c == b) ? nullptr : (void *)(N.mirror(b) + (size_t)c * 2 * kPartBlock + off);
+    N.copies[b]++;
+    if (N.xchg_all_gather(b, N.parts[b] + off, recv, (size_t)count * sizeof(double)) != 0)
+        N.fail(b, OCTANE_E_HIP, "the collective transport's all_gather of the partial sums failed");
+}
+// What band b needs of a plane beyond its edges -- rows [y0 - a_hi, y0 - a_lo) from the band above, [y1 + b_lo, y1 + b_hi) from
+// the band below -- is exactly what its neighbours need of it, mirrored: it sends rows [y1 - a_hi, y1 - a_lo) down and
+// [y0 + b_lo, y0 + b_hi) up.  Rows of a plane are contiguous, so every transfer is one buffer.
+struct RowSpec { float *plane; int a_lo, a_hi, b_lo, b_hi; };
+static void exchange_rows(BandNet &N, int b, const RowSpec *spec, int nspec, int pitch, int y0, int y1)
+{
+    if (N.failed()) return;
+    std::vector<octane_vof_xfer> ops;
+    auto add = [&](int peer, int send, float *plane, int ya, int yb) {
+        if (yb <= ya) return;
+        octane_vof_xfer x; x.peer = peer; x.send = send; x.buf = plane + (size_t)ya * pitch; x.bytes = (size_t)(yb - ya) * pitch * sizeof(float);
+        ops.push_back(x);
+    };
+    for (int i = 0; i < nspec; i++) {
+        const RowSpec &r = spec[i];
+        if (b > 0) { add(b - 1, 0, r.plane, y0 - r.a_hi, y0 - r.a_lo); add(b - 1, 1, r.plane, y0 + r.b_lo, y0 + r.b_hi); }
+        if (b < N.nb - 1) { add(b + 1, 0, r.plane, y1 + r.b_lo, y1 + r.b_hi); add(b + 1, 1, r.plane, y1 - r.a_hi, y1 - r.a_lo); }
+    }
+    if (ops.empty()) return;
+    N.copies[b] += (long long)ops.size();
+    if (N.xchg_sendrecv(b, (int)ops.size(), ops.data()) != 0) N.fail(b, OCTANE_E_HIP, "the collective transport's sendrecv of edge rows failed");
+}
+
 // ---- one banded level, as band b issues it ----------------------------------------------------------------------------
 static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx &ctx, bool finest)
 {
@@ -353,9 +603,12 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
     L.ya0 = (b == 0) ? 0 : L.y0 - 1;
     L.ya1 = (b == nb - 1) ? li.h : L.y1 + 1;
     L.nbands = nb;
+    L.no_dma = N.no_dma ? 1 : 0;
     double *own = N.parts[b];
     L.part_rz = own + kPartRz; L.part_rr = own + kPartRr; L.part_pq = own + kPartPq; L.part_own = own;
-    const bool cp = N.copy_transport;                  // neighbours' rows and partial blocks are pulled into local memory, kernels read local
+    const int tr = N.transport;
+    const bool coll = tr == OCTANE_TRANSPORT_COLLECTIVE;
+    const bool cp = tr != OCTANE_TRANSPORT_INPLACE;    // neighbours' rows and partial blocks are brought into local memory, kernels read local
     for (int c = 0; c < kMaxBands; c++) {
         const int cc = c < nb ? c : b;
         L.band_parts[c] = (cp && cc != b) ? N.mirror(b) + (size_t)cc * 2 * kPartBlock : N.parts[cc];
@@ -390,6 +643,15 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
         }
         L.wy_up = N.peer(rup, b, pl->wy);
     }
+#ifdef OCTANE_DIAG
+    // Drill of the self-check's downgrade (diagnostic library only, OCTANE_TEST_BREAK_TRANSPORT): bit 0 -- the in-place transport
+    // folds its OWN partial block in place of band 0's / band nb-1's (wrong alpha and beta: what a peer mapping that returns stale
+    // data looks like); bit 1 -- with the LDS-DMA kernel the rows beyond the lower edge come from this band's own, never-written halo
+    // rows; bit 2 -- the copy transport leaves the other bands' partial blocks in the mirror unfilled.
+    if ((N.brk & 1) && !cp && nb > 1) L.band_parts[b == 0 ? nb - 1 : 0] = N.parts[b];
+    if ((N.brk & 2) && !cp && L.q_form && !N.no_dma && b < nb - 1)
+        for (int i = 0; i < 3; i++) { L.pdn_u[i] = L.pf_u[i]; L.pdn_v[i] = L.pf_v[i]; }
+#endif
 
     for (int gnc = 0; gnc < 3; gnc++) {                 // ref .cu:604-606
         AssembleParams ap;
@@ -411,15 +673,36 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
             }
             N.sync(b);
             if (cp) {      // what the first launch reads of the others: the sums of their right-hand sides, wy of the row above the upper ring row
-                if (!fused) N.fail(b, OCTANE_E_INVALID, "OCTANE_TILED_TRANSPORT=copy needs the one-kernel PCG iteration (OCTANE_TUNE_FUSED=1)");
-                pull_parts(N, b, 1, kPartRz, 2 * kMaxParts);
-                if (L.q_form && b > 0 && L.y0 >= 2) pull_rows(N, b, up, pl->wy, li.pitch, L.y0 - 2, L.y0 - 1);
+                if (!fused) N.fail(b, OCTANE_E_INVALID, "the copy and collective transports need the one-kernel PCG iteration (OCTANE_TUNE_FUSED=1)");
+                if (coll) {
+                    gather_parts(N, b, 1, kPartRz, 2 * kMaxParts);
+                    if (L.q_form) { const RowSpec wy = {pl->wy, 1, 2, 0, 0}; exchange_rows(N, b, &wy, 1, li.pitch, L.y0, L.y1); }
+                } else {
+#ifdef OCTANE_DIAG
+                    if (!(N.brk & 4))
+#endif
+                    pull_parts(N, b, 1, kPartRz, 2 * kMaxParts);
+                    if (L.q_form && b > 0 && L.y0 >= 2) pull_rows(N, b, up, pl->wy, li.pitch, L.y0 - 2, L.y0 - 1);
+                }
             }
             if (fused) {
                 for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182: one kernel and one boundary per iteration
                     if (!N.failed()) launch_pcg_fused(s, L, it, it == 0 ? g_asm : g_f, g_f, pl->tol);
                     N.sync(b);
-                    if (cp) {   // what launch it + 1 (or the flow update) reads of the others: their sums, the rows beyond this band's edges
+                    if (coll) {   // the same bytes as below, moved by the host program's collective library
+                        gather_parts(N, b, it & 1, 0, kPartBlock);
+                        if (L.q_form) {
+                            const RowSpec sp[4] = {{L.pf_u[it % 3], 0, 2, 0, 2}, {L.pf_v[it % 3], 0, 2, 0, 2},
+                                                   {L.rb_u[it & 1], 0, 1, 0, 1}, {L.rb_v[it & 1], 0, 1, 0, 1}};
+                            exchange_rows(N, b, sp, 4, li.pitch, L.y0, L.y1);
+                        } else {
+                            const RowSpec sp[2] = {{L.qb_u[it & 1], 0, 1, 0, 1}, {L.qb_v[it & 1], 0, 1, 0, 1}};
+                            exchange_rows(N, b, sp, 2, li.pitch, L.y0, L.y1);
+                        }
+                    } else if (cp) {   // what launch it + 1 (or the flow update) reads of the others: their sums, the rows beyond this band's edges
+#ifdef OCTANE_DIAG
+                        if (!(N.brk & 4))
+#endif
                         pull_parts(N, b, it & 1, 0, kPartBlock);
                         for (int side = 0; side < 2; side++) {
                             const int nbr = side == 0 ? up : dn;
@@ -452,23 +735,45 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
             }
             // the next assembly reads u, v two rows beyond the band (one for the halo row it fills, one for that
             // row's own 3 x 3 neighbourhood)
-            if (b > 0) {
-                send_rows(N, b, pl->U[cur], li.pitch, L.y0, L.y0 + 2, b - 1);
-                send_rows(N, b, pl->V[cur], li.pitch, L.y0, L.y0 + 2, b - 1);
+            if (coll) {
+                N.sync(b);
+                const RowSpec sp[2] = {{pl->U[cur], 0, 2, 0, 2}, {pl->V[cur], 0, 2, 0, 2}};
+                exchange_rows(N, b, sp, 2, li.pitch, L.y0, L.y1);
+            } else {
+                if (b > 0) {
+                    send_rows(N, b, pl->U[cur], li.pitch, L.y0, L.y0 + 2, b - 1);
+                    send_rows(N, b, pl->V[cur], li.pitch, L.y0, L.y0 + 2, b - 1);
+                }
+                if (b < nb - 1) {
+                    send_rows(N, b, pl->U[cur], li.pitch, L.y1 - 2, L.y1, b + 1);
+                    send_rows(N, b, pl->V[cur], li.pitch, L.y1 - 2, L.y1, b + 1);
+                }
+                N.sync(b);
             }
-            if (b < nb - 1) {
-                send_rows(N, b, pl->U[cur], li.pitch, L.y1 - 2, L.y1, b + 1);
-                send_rows(N, b, pl->V[cur], li.pitch, L.y1 - 2, L.y1, b + 1);
-            }
-            N.sync(b);
         }
     }
     // Level done: the next level's up-sampling (replicated) needs the whole flow on every band; after the finest
     // level only band 0, which hands the result out, does.
-    for (int c = 0; c < nb; c++) {
-        if (c == b || (finest && c != 0)) continue;
-        send_rows(N, b, pl->U[cur], li.pitch, L.y0, L.y1, c);
-        send_rows(N, b, pl->V[cur], li.pitch, L.y0, L.y1, c);
+    if (coll) {
+        std::vector<octane_vof_xfer> ops;
+        auto add = [&](int peer, int send, float *plane, int ya, int yb) {
+            octane_vof_xfer x; x.peer = peer; x.send = send; x.buf = plane + (size_t)ya * li.pitch; x.bytes = (size_t)(yb - ya) * li.pitch * sizeof(float);
+            ops.push_back(x);
+        };
+        for (int c = 0; c < nb; c++) {
+            if (c == b) continue;
+            if (!(finest && c != 0)) { add(c, 1, pl->U[cur], L.y0, L.y1); add(c, 1, pl->V[cur], L.y0, L.y1); }
+            if (!(finest && b != 0)) { add(c, 0, pl->U[cur], rows[c].y0, rows[c].y1); add(c, 0, pl->V[cur], rows[c].y0, rows[c].y1); }
+        }
+        N.copies[b] += (long long)ops.size();
+        if (!N.failed() && !ops.empty() && N.xchg_sendrecv(b, (int)ops.size(), ops.data()) != 0)
+            N.fail(b, OCTANE_E_HIP, "the collective transport's gather of the flow bands failed");
+    } else {
+        for (int c = 0; c < nb; c++) {
+            if (c == b || (finest && c != 0)) continue;
+            send_rows(N, b, pl->U[cur], li.pitch, L.y0, L.y1, c);
+            send_rows(N, b, pl->V[cur], li.pitch, L.y0, L.y1, c);
+        }
     }
     N.sync(b);
 }
@@ -520,7 +825,7 @@ struct ThreadNet : BandNet {
     {
         nb = t->nbands; prm = t->prm; rows = &t->rows;
         for (int b = 0; b < nb; b++) { arena[b] = reinterpret_cast<char *>(t->pl[b]->arena); parts[b] = t->parts[b]; }
-        read_transport();
+        transport = t->transport; no_dma = t->no_dma; brk = test_break_bits();
     }
     double *mirror(int b) override { return t->mirror[b]; }
     hipError_t pull(int b, void *dst_local, int sband, const void *src, size_t bytes) override
@@ -696,6 +1001,7 @@ struct MpShared {                 // lives in the shared-memory object; zero-fil
     std::atomic<int> dead;        // a rank timed out at a phase boundary: the barrier state is undefined, nobody synchronises again
     std::atomic<unsigned long long> nonce;   // of rank 0's IPC handle: tells this run's object from one a crashed run left behind
     std::atomic<unsigned long long> devid[kMaxBands];   // a hash of each rank's PCI bus id: ranks sharing a GPU share its CUs
+    std::atomic<int> ipc[kMaxBands];                    // 1: the rank opened every IPC mapping, 2: it could not; +4: it has a collective library
 };
 
 struct octane_vof_mp {
@@ -716,6 +1022,12 @@ struct octane_vof_mp {
     int last_cur = 0;
     long long copies = 0;
     bool aborted = false;          // a persistent mid-level solve of the last run gave up (on any rank): its flow is not valid
+    int transport = OCTANE_TRANSPORT_INPLACE;
+    bool no_dma = false;
+    bool ipc_ok = true;            // every rank opened every IPC mapping (agreed among the ranks in octane_vof_mp_connect)
+    octane_vof_exchange ex;        // the host program's collective library (all zero: none registered)
+    long long min_band_pixels = 0;
+    octane_vof_transport_info info;
 };
 
 struct MpHandles { hipIpcMemHandle_t arena, parts; };
@@ -729,9 +1041,17 @@ struct ProcNet : BandNet {
     {
         nb = m->world; prm = m->prm; rows = &m->rows;
         for (int b = 0; b < nb; b++) { arena[b] = m->arena[b]; parts[b] = m->parts_all[b]; }
-        read_transport();
+        transport = m->transport; no_dma = m->no_dma; brk = test_break_bits();
     }
     double *mirror(int) override { return m->mirror; }
+    int xchg_all_gather(int, const void *send, void *const *recv, size_t bytes) override
+    {
+        return m->ex.all_gather ? m->ex.all_gather(m->ex.user, send, recv, bytes) : -1;
+    }
+    int xchg_sendrecv(int, int n, const octane_vof_xfer *ops) override
+    {
+        return m->ex.sendrecv ? m->ex.sendrecv(m->ex.user, n, ops) : -1;
+    }
     hipError_t pull(int, void *dst_local, int, const void *src, size_t bytes) override
     {
         return hipMemcpyAsync(dst_local, src, bytes, hipMemcpyDefault, m->pl->own_stream);     // src is an IPC mapping
@@ -796,6 +1116,9 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
     *out = nullptr;
     octane_vof_mp *m = new octane_vof_mp();
     m->rank = rank; m->world = world; m->nx = nx; m->ny = ny; m->nc = nchan; m->prm = *p; m->shm_name = shm_name;
+    m->min_band_pixels = min_band_pixels;
+    std::memset(&m->ex, 0, sizeof m->ex);
+    info_reset(m->info, world);
     int rc = plan_create_ex(&m->pl, nx, ny, nchan, p, 1);
     if (rc != OCTANE_OK) { delete m; return rc; }
     m->device = m->pl->device;
@@ -847,9 +1170,21 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
         m->shm->failed.store(0);
         m->shm->dead.store(0);
         m->shm->nonce.store(0);
-        for (int b = 0; b < kMaxBands; b++) m->shm->devid[b].store(0);
+        for (int b = 0; b < kMaxBands; b++) { m->shm->devid[b].store(0); m->shm->ipc[b].store(0); }
     }
     *out = m;
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_mp_set_exchange(octane_vof_mp *m, const octane_vof_exchange *ex)
+{
+    if (!m || m->connected || (ex && (!ex->all_gather || !ex->sendrecv))) {
+        set_last_error("octane_vof_mp_set_exchange: call it between octane_vof_mp_create and octane_vof_mp_connect, with both callbacks set");
+        return OCTANE_E_INVALID;
+    }
+    if (ex) { m->ex = *ex; m->ex.name[sizeof m->ex.name - 1] = 0; }
+    else std::memset(&m->ex, 0, sizeof m->ex);
+    std::memcpy(m->info.exchange, m->ex.name, sizeof m->info.exchange);
     return OCTANE_OK;
 }
 
@@ -903,14 +1238,33 @@ extern "C" int octane_vof_mp_connect(octane_vof_mp *m, const void *all_handles)
             return OCTANE_E_INVALID;
         }
     }
-    for (int b = 0; b < m->world; b++) {
+    // The other ranks' allocations.  A mapping that cannot be opened (no IPC between these two processes / devices) is not fatal when
+    // the host program registered a collective library: the ranks then agree below on the collective transport, which needs none.
+    bool ipc_ok = true;
+    std::string ipc_err;
+    const int forced = forced_transport();
+    if (forced == -2) { set_last_error("octane_vof_mp_connect: OCTANE_TILED_TRANSPORT must be inplace, copy or collective"); return OCTANE_E_INVALID; }
+    const bool skip_ipc = forced == OCTANE_TRANSPORT_COLLECTIVE
+#ifdef OCTANE_DIAG
+                          || (test_break_bits() & 8)         // drill: "IPC unavailable"
+#endif
+                          ;
+    for (int b = 0; b < m->world && ipc_ok; b++) {
         if (b == m->rank) continue;
         void *pa = nullptr, *pp = nullptr;
-        TILED_TRY(hipIpcOpenMemHandle(&pa, h[b].arena, hipIpcMemLazyEnablePeerAccess));
-        TILED_TRY(hipIpcOpenMemHandle(&pp, h[b].parts, hipIpcMemLazyEnablePeerAccess));
+        hipError_t e = skip_ipc ? hipErrorNotSupported : hipIpcOpenMemHandle(&pa, h[b].arena, hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) e = hipIpcOpenMemHandle(&pp, h[b].parts, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            ipc_ok = false;
+            ipc_err = std::string("hipIpcOpenMemHandle of rank ") + std::to_string(b) + "'s memory: " + hipGetErrorString(e);
+            if (pa) (void)hipIpcCloseMemHandle(pa);
+            (void)hipGetLastError();
+            break;
+        }
         m->arena[b] = static_cast<char *>(pa);
         m->parts_all[b] = static_cast<double *>(pp);
     }
+    m->shm->ipc[m->rank].store((ipc_ok ? 1 : 2) + (m->ex.all_gather ? 4 : 0), std::memory_order_release);
     m->connected = true;
     {   // which GPU this rank drives, for the others to see
         char bus[64] = {0};
@@ -924,17 +1278,162 @@ extern "C" int octane_vof_mp_connect(octane_vof_mp *m, const void *all_handles)
         set_last_error("octane_vof_mp_connect: the other ranks did not arrive");
         return OCTANE_E_HIP;
     }
+    {   // what every rank can do decides what all of them do
+        bool all_ipc = true, all_ex = true;
+        for (int b = 0; b < m->world; b++) {
+            const int f = m->shm->ipc[b].load(std::memory_order_acquire);
+            all_ipc = all_ipc && (f & 3) == 1; all_ex = all_ex && (f & 4) != 0;
+        }
+        m->ipc_ok = all_ipc;
+        m->info.peer_ok = all_ipc ? 1 : 0;
+        if (!all_ipc) {                         // close what was opened: nobody will read through it
+            for (int b = 0; b < m->world; b++) {
+                if (b == m->rank) continue;
+                if (m->arena[b]) { (void)hipIpcCloseMemHandle(m->arena[b]); m->arena[b] = nullptr; }
+                if (m->parts_all[b]) { (void)hipIpcCloseMemHandle(m->parts_all[b]); m->parts_all[b] = nullptr; }
+            }
+        }
+        if (!all_ex) std::memset(&m->ex, 0, sizeof m->ex);          // registered on some ranks only: nobody uses it
+        const bool have_ex = all_ex;
+        if (forced >= 0) {
+            if ((forced != OCTANE_TRANSPORT_COLLECTIVE && !all_ipc) || (forced == OCTANE_TRANSPORT_COLLECTIVE && !have_ex)) {
+                set_last_error(std::string("octane_vof_mp_connect: OCTANE_TILED_TRANSPORT=") + octane_vof_transport_name(forced) + " is not available: " +
+                               (forced == OCTANE_TRANSPORT_COLLECTIVE ? "no collective library registered on every rank (octane_vof_mp_set_exchange)" : ipc_err));
+                return OCTANE_E_INVALID;
+            }
+            m->transport = forced; m->info.forced = 1;
+        } else if (!all_ipc) {
+            if (!have_ex) {
+                set_last_error("octane_vof_mp_connect: " + (ipc_err.empty() ? std::string("another rank could not open the IPC mappings") : ipc_err) +
+                               ", and no collective library is registered (octane_vof_mp_set_exchange) to carry the bands' exchange instead");
+                return OCTANE_E_HIP;
+            }
+            m->transport = OCTANE_TRANSPORT_COLLECTIVE;
+            if (m->rank == 0) fprintf(stderr, "octane: row bands, one per process: HIP IPC mappings are not available (%s) -- using the collective transport (%s)\n",
+                                      ipc_err.empty() ? "on another rank" : ipc_err.c_str(), m->ex.name);
+        }
+        m->info.transport = m->transport;
+        std::memcpy(m->info.exchange, m->ex.name, sizeof m->info.exchange);
+    }
     {   // Ranks that share a GPU (a rehearsal on a one-GPU box) share its CUs: their persistent PCG solves of the replicated
         // levels run at the same time and cannot be serialised across processes, so each may only hold its share of the CUs --
         // otherwise two of them could wait for each other's workgroups to become resident (pcg_persist.hip).
         int sharing = 0;
         const unsigned long long mine = m->shm->devid[m->rank].load(std::memory_order_acquire);
         for (int b = 0; b < m->world; b++) sharing += (m->shm->devid[b].load(std::memory_order_acquire) == mine);
+        int distinct = 0;
+        for (int b = 0; b < m->world; b++) {
+            bool dup = false;
+            for (int c = 0; c < b; c++) dup = dup || m->shm->devid[c].load(std::memory_order_acquire) == m->shm->devid[b].load(std::memory_order_acquire);
+            distinct += !dup;
+        }
+        m->info.ndevices = distinct;
         if (sharing > 1) {
             const int cap = m->pl->ncu / sharing;
             if (cap < m->pl->persist_max_g) m->pl->persist_max_g = cap;
         }
     }
+    return OCTANE_OK;
+}
+
+extern "C" int octane_vof_mp_transport_info(const octane_vof_mp *m, octane_vof_transport_info *out)
+{
+    if (!m || !out) return OCTANE_E_INVALID;
+    *out = m->info;
+    out->transport = m->transport; out->q_dma = m->no_dma ? 0 : 1; out->nbands = m->world;
+    return OCTANE_OK;
+}
+
+// The first-contact self-check of the process form (include/octane_vof.h): the ranks build a second, small group with the host
+// program's byte all-gather, solve the check frame under each candidate transport and keep the first one rank 0 finds within the bar
+// of the plain plan's flow (every rank's own return code can veto).  Collective; the verdicts travel by the same all-gather.
+extern "C" int octane_vof_mp_selfcheck(octane_vof_mp *m, octane_allgather_bytes_fn ag, void *user)
+{
+    if (!m || !m->connected || !ag) { set_last_error("octane_vof_mp_selfcheck: call it after octane_vof_mp_connect, with an all-gather"); return OCTANE_E_INVALID; }
+    bool any_banded = false, large = false;
+    for (size_t k = 0; k < m->rows.size(); k++) {
+        if (m->rows[k].empty()) continue;
+        any_banded = true;
+        int maxrows = 0;
+        for (auto &r : m->rows[k]) maxrows = std::max(maxrows, r.y1 - r.y0);
+        if (m->pl->use_fused && pcg_fused_q_form(m->pl->lev[k].w, maxrows, m->pl->lev[k].h)) large = true;
+    }
+    if (m->world < 2 || !any_banded || m->info.forced || !selfcheck_enabled()) return OCTANE_OK;
+    TILED_TRY(hipSetDevice(m->device));
+    const int nb = m->world;
+    int w, h;
+    check_geometry(nb, large, &w, &h);
+    const octane_vof_params cp = check_params(m->prm, m->device);
+    std::vector<Candidate> cand;
+    if (m->ipc_ok) {
+        cand.push_back({OCTANE_TRANSPORT_INPLACE, false});
+        if (large) cand.push_back({OCTANE_TRANSPORT_INPLACE, true});
+        cand.push_back({OCTANE_TRANSPORT_COPY, false});
+    }
+    if (m->ex.all_gather) cand.push_back({OCTANE_TRANSPORT_COLLECTIVE, false});
+    // the check group: same ranks, same devices, same collective library, a shared-memory object of its own
+    octane_vof_mp *c = nullptr;
+    int rc = octane_vof_mp_create(&c, w, h, 1, &cp, m->rank, nb, 1, (m->shm_name + "_chk").c_str());
+    std::vector<unsigned char> all((size_t)nb * OCTANE_MP_HANDLE_BYTES);
+    unsigned char mine[OCTANE_MP_HANDLE_BYTES] = {0};
+    if (rc == OCTANE_OK && m->ex.all_gather) rc = octane_vof_mp_set_exchange(c, &m->ex);
+    if (rc == OCTANE_OK) rc = octane_vof_mp_handles(c, mine);
+    // every rank joins every all-gather whatever happened to it before: a rank that failed says so in its verdict below
+    const int ag_rc = ag(user, mine, all.data(), OCTANE_MP_HANDLE_BYTES);
+    if (rc == OCTANE_OK && ag_rc != 0) { set_last_error("octane_vof_mp_selfcheck: the host program's all-gather failed"); rc = OCTANE_E_HIP; }
+    if (rc == OCTANE_OK) rc = octane_vof_mp_connect(c, all.data());
+    std::vector<float> a, b2, up, vp, u, v;
+    long long its_plain = 0;
+    if (rc == OCTANE_OK) {
+        check_scene(w, h, a, b2);
+        if (m->rank == 0) rc = plain_check_flow(cp, w, h, a, b2, up, vp, &its_plain);
+    }
+    std::vector<int> verdicts(nb);
+    int setup_ok = rc == OCTANE_OK ? 1 : 0;
+    if (ag(user, &setup_ok, verdicts.data(), sizeof(int)) != 0) setup_ok = 0;
+    for (int r = 0; r < nb; r++) setup_ok = setup_ok && verdicts[r];
+    int chosen = -1;
+    std::string log;
+    if (setup_ok) {
+        for (size_t i = 0; i < cand.size() && chosen < 0; i++) {
+            c->transport = cand[i].transport; c->no_dma = cand[i].no_dma;
+            u.assign((size_t)w * h, 0.f); v.assign((size_t)w * h, 0.f);
+            const int rrc = octane_vof_mp_run(c, a.data(), b2.data(), nullptr, nullptr, u.data(), v.data(), OCTANE_MEM_HOST);
+            int pass = rrc == OCTANE_OK ? 1 : 0;
+            double d = -1.;
+            if (m->rank == 0 && pass) {
+                bool fin = false;
+                d = flow_rel_l2(u, v, up, vp, &fin);
+                const long long its = octane_vof_mp_last_iterations(c);
+                pass = fin && d <= kCheckBar && its == its_plain;
+                log += std::string(i ? "; " : "") + octane_vof_transport_name(cand[i].transport) + (cand[i].no_dma ? " without LDS-DMA from the neighbour" : "") +
+                       (pass ? ": ok" : ": rel L2 " + std::to_string(d) + ", iterations " + std::to_string(its) + " / " + std::to_string(its_plain));
+            } else if (m->rank == 0) {
+                log += std::string(i ? "; " : "") + octane_vof_transport_name(cand[i].transport) + ": error (" + octane_last_error() + ")";
+            }
+            if (i < 4) m->info.check_rel_l2[i] = d;
+            m->info.candidates_tried = (int)i + 1;
+            if (ag(user, &pass, verdicts.data(), sizeof(int)) != 0) { pass = 0; for (int r = 0; r < nb; r++) verdicts[r] = 0; }
+            bool all_pass = true;
+            for (int r = 0; r < nb; r++) all_pass = all_pass && verdicts[r] != 0;
+            if (c->dead || (c->shm && c->shm->dead.load() != 0)) break;        // the check group is gone: nothing more can be tried
+            if (all_pass) chosen = (int)i;
+        }
+    }
+    if (c) octane_vof_mp_destroy(c);
+    TILED_TRY(hipSetDevice(m->device));
+    if (!setup_ok) {
+        m->info.selfcheck = -1;
+        set_last_error("octane_vof_mp_selfcheck: the check group could not be set up on every rank" + (rc != OCTANE_OK ? std::string(": ") + octane_last_error() : std::string()));
+        return OCTANE_E_HIP;
+    }
+    m->info.selfcheck = chosen < 0 ? -1 : chosen == 0 ? 1 : 2;
+    if (chosen >= 0) { m->transport = cand[chosen].transport; m->no_dma = cand[chosen].no_dma; }
+    m->info.transport = m->transport; m->info.q_dma = m->no_dma ? 0 : 1;
+    if (chosen != 0 && m->rank == 0)
+        fprintf(stderr, "octane: row-band self-check, %d ranks (%d x %d): %s -> %s\n", nb, w, h, log.c_str(),
+                chosen < 0 ? "NO transport reproduces the plain plan" : "using the last of these");
+    if (chosen < 0) { set_last_error("octane_vof_mp_selfcheck: the first-contact self-check failed under every transport" + (log.empty() ? std::string() : ": " + log)); return OCTANE_E_HIP; }
     return OCTANE_OK;
 }
 

@@ -64,11 +64,12 @@ _libs: dict[str, C.CDLL] = {}
 
 def lib(flavour: str = "strict") -> C.CDLL:
     """flavour: 'strict' (no FMA contraction), 'fma', or 'omp' (strict arithmetic, loops spread over the host
-    cores with OpenMP; bit-identical to 'strict' under the grid dot schedule)."""
+    cores with OpenMP; bit-identical to 'strict' under the grid dot schedule), or 'fma_omp' (the same for 'fma')."""
     if flavour in _libs:
         return _libs[flavour]
     build()
-    name = {"strict": "liboct_oracle.so", "fma": "liboct_oracle_fma.so", "omp": "liboct_oracle_omp.so"}[flavour]
+    name = {"strict": "liboct_oracle.so", "fma": "liboct_oracle_fma.so", "omp": "liboct_oracle_omp.so",
+            "fma_omp": "liboct_oracle_fma_omp.so"}[flavour]
     L = C.CDLL(os.path.join(_HERE, name))
     L.oct_oracle_num_threads.restype = C.c_int
     L.oct_oracle_vof.restype = C.c_int

@@ -32,7 +32,21 @@ def main():
         u0 = (2.0 + 0.2 * rng.randn(ny, nx)).astype(np.float32)
         v0 = (-1.0 + 0.2 * rng.randn(ny, nx)).astype(np.float32)
         prm = capi.FlowParams(kiters=kit, liters=lit, cgiters=cg, lambdac=0.4, device=dev)
-    mp = capi.MpPlan(nx, ny, 1, prm, rank, world, f"/octane_test_{os.environ['MASTER_PORT']}", all_gather, min_band_pixels=minpix)
+    # "xchg": register torch.distributed (gloo here: host-staged) as the library's collective transport; which transport then RUNS
+    # is the self-check's choice, or OCTANE_TILED_TRANSPORT's
+    exchange = None
+    if os.environ.get("OCTANE_TEST_EXCHANGE") == "1":
+        from octane_amd import exchange as xch
+        torch.cuda.set_device(dev)
+        exchange = xch.TorchExchange(torch.device("cuda", dev))
+    try:
+        mp = capi.MpPlan(nx, ny, 1, prm, rank, world, f"/octane_test_{os.environ['MASTER_PORT']}", all_gather, min_band_pixels=minpix,
+                         exchange=exchange)
+    except capi.OctaneError as e:
+        print(f"MP_CREATE_FAILED rank={rank} msg={str(e)!r}", flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(3)
     banded = mp.banded_levels
     if len(sys.argv) > 7 and sys.argv[7] == "loop":
         # dead-peer drill: solve again and again until the library reports that the group is dead (the test kills another
@@ -95,7 +109,21 @@ def main():
         d = float(np.sqrt((((u - up).astype(np.float64)) ** 2 + ((v - vp).astype(np.float64)) ** 2).sum() /
                           ((up.astype(np.float64)) ** 2 + (vp.astype(np.float64)) ** 2).sum()))
         ok = np.isfinite(u).all() and d < 2e-5 and mp.last_iterations() == ip
-        print(f"MP_RESULT devices={capi.band_devices(world)} banded={banded} relL2={d:.3e} its={mp.last_iterations()}/{ip} ok={ok}", flush=True)
+        import json
+        import zlib
+        d_or = -1.0
+        if nx * ny <= 400000:                                   # the oracle too, where it takes a moment
+            from oracle import oct_oracle as oo
+            uo, vo, _ = oo.flow(a, b, oo.FlowParams(kiters=kit, liters=lit, cgiters=cg, lambdac=prm.lambdac), u0=u0, v0=v0,
+                                 flavour="omp", dot_threads=oo.REF_GRID_THREADS)
+            d_or = float(np.sqrt((((u - uo).astype(np.float64)) ** 2 + ((v - vo).astype(np.float64)) ** 2).sum() /
+                                 ((uo.astype(np.float64)) ** 2 + (vo.astype(np.float64)) ** 2).sum()))
+            ok = ok and d_or < 2e-5
+        info = mp.transport_info()
+        if exchange is not None:
+            info["exchange_calls"] = exchange.calls
+        print(f"MP_RESULT devices={capi.band_devices(world)} banded={banded} relL2={d:.3e} oracle={d_or:.3e} its={mp.last_iterations()}/{ip} ok={ok} "
+              f"crc={zlib.crc32(u.tobytes() + v.tobytes()):08x} info={json.dumps(info)}", flush=True)
     mp.close()
     dist.barrier()
     dist.destroy_process_group()

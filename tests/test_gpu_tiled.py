@@ -298,3 +298,82 @@ def test_two_real_peers_in_place_and_copy_transports_agree(capi):
     assert np.array_equal(ui, uc) and np.array_equal(vi, vc)
     assert np.array_equal(ui, uv) and np.array_equal(vi, vv)
     assert rel_l2(ui, vi, up, vp) < ORDER_BAR
+
+
+def test_first_contact_selfcheck_runs_at_creation_and_keeps_in_place_reads(capi):
+    """octane_vof_tiled_create solves a small two-level frame on the plan's own devices under each candidate
+    transport and keeps the first that reproduces the plain plan (include/octane_vof.h).  On a box where in-place reads work that is
+    the first candidate: small bands check the stored-q kernel's peer reads, bands of 2 Mpixel and more also the LDS-DMA from the
+    neighbouring band (the self-check's frame is then 2048 x 1024 per band)."""
+    small = capi.TiledPlan(300, 420, 1, capi.FlowParams(kiters=2), nbands=3, devices=capi.band_devices(3), min_band_pixels=1)
+    large = capi.TiledPlan(2432, 3584, 1, capi.FlowParams(kiters=2, liters=1, cgiters=5), nbands=2, devices=capi.band_devices(2), min_band_pixels=1)
+    try:
+        for tp, nb in ((small, 3), (large, 2)):
+            info = tp.transport_info()
+            print("SELFCHECK", info)
+            assert info["transport_used"] == "inplace" and info["q_dma"] and not info["forced"]
+            assert info["selfcheck"] == "first candidate passed" and info["candidates_tried"] == 1
+            assert info["bands"] == nb and info["peer_ok"] and 0 <= info["check_rel_l2"][0] <= ORDER_BAR
+    finally:
+        small.close(); large.close()
+
+
+def test_forced_transport_and_switched_off_selfcheck_are_reported(capi, monkeypatch):
+    monkeypatch.setenv("OCTANE_TILED_TRANSPORT", "copy")
+    tp = capi.TiledPlan(300, 420, 1, capi.FlowParams(kiters=2), nbands=2, devices=capi.band_devices(2), min_band_pixels=1)
+    info = tp.transport_info(); tp.close()
+    assert info["transport_used"] == "copy" and info["forced"] and info["selfcheck"] == "not run"
+    monkeypatch.delenv("OCTANE_TILED_TRANSPORT")
+    monkeypatch.setenv("OCTANE_TILED_SELFCHECK", "0")
+    tp = capi.TiledPlan(300, 420, 1, capi.FlowParams(kiters=2), nbands=2, devices=capi.band_devices(2), min_band_pixels=1)
+    info = tp.transport_info(); tp.close()
+    assert info["transport_used"] == "inplace" and not info["forced"] and info["selfcheck"] == "not run"
+    monkeypatch.setenv("OCTANE_TILED_TRANSPORT", "collective")
+    with pytest.raises(capi.OctaneError):          # the collective transport is the process form's (octane_vof_mp_*)
+        capi.TiledPlan(300, 420, 1, capi.FlowParams(kiters=2), nbands=2, devices=capi.band_devices(2), min_band_pixels=1)
+
+
+def _drill(capi, bits, nx, ny, nbands, prm=(2, 1, 6)):
+    import json
+    import os
+    import subprocess
+    import sys
+    if not os.path.exists(capi.DIAG_LIB_PATH):
+        pytest.skip("diagnostic library not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tiled_diag_worker.py"), str(nx), str(ny), str(nbands), *map(str, prm)],
+                       env=dict(os.environ, OCTANE_LIB=capi.DIAG_LIB_PATH, OCTANE_TEST_BREAK_TRANSPORT=str(bits)),
+                       capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("TILED_RESULT ")]
+    assert r.returncode == 0 and line, r.stdout + r.stderr
+    return json.loads(line[0][len("TILED_RESULT "):]), r.stderr
+
+
+def test_selfcheck_downgrades_in_place_reads_to_copies_when_they_return_wrong_sums(capi):
+    """The drill of the automatic downgrade (diagnostic library's fault hook, bit 0: a band folds its own partial block in place of
+    another band's -- what stale peer reads would look like): the self-check's first candidate fails, the copy transport passes, the
+    plan uses it, says so once on stderr, and the solve of the real frame is right."""
+    res, err = _drill(capi, 1, 300, 420, 3)
+    print("DRILL-1", res, err.strip().splitlines()[-1:] )
+    assert res["created"] and res["info"]["transport_used"] == "copy" and res["info"]["selfcheck"] == "downgraded"
+    assert res["info"]["candidates_tried"] == 2 and res["info"]["check_rel_l2"][0] > ORDER_BAR >= res["info"]["check_rel_l2"][1]
+    assert res["rel_l2"] < ORDER_BAR and res["its"] == res["its_plain"] and res["banded"] >= 1
+    assert "self-check" in err and "copy" in err
+
+
+def test_selfcheck_drops_lds_dma_from_the_neighbour_before_it_gives_up_in_place_reads(capi):
+    """Fault hook bit 1: the rows the LDS-DMA kernel fetches from beyond a band's lower edge come from the wrong place.  Bands of
+    2 Mpixel: the self-check runs its large frame, candidate 1 (in place, LDS-DMA) fails, candidate 2 -- in place with the
+    register-staged q-recomputing kernel -- passes; the real frame is then solved that way and is right."""
+    res, err = _drill(capi, 2, 2048, 2112, 2, prm=(1, 1, 6))
+    print("DRILL-2", res, err.strip().splitlines()[-1:])
+    assert res["created"] and res["info"]["transport_used"] == "inplace" and not res["info"]["q_dma"]
+    assert res["info"]["selfcheck"] == "downgraded" and res["info"]["candidates_tried"] == 2
+    assert res["rel_l2"] < ORDER_BAR and res["its"] == res["its_plain"]
+
+
+def test_selfcheck_that_finds_no_working_transport_fails_creation_with_a_reason(capi):
+    """Bits 0 and 2: in-place reads AND the copy transport are broken; there is no third transport in the thread form.  Creation must
+    fail (not return a plan that solves wrongly) and the error must say which candidates were tried."""
+    res, err = _drill(capi, 5, 300, 420, 2)
+    assert not res["created"] and "self-check" in res["msg"] and "inplace" in res["msg"] and "copy" in res["msg"]

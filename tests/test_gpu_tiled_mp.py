@@ -55,6 +55,92 @@ def test_one_band_per_process_with_the_copy_transport():
     assert line and "ok=True" in line[0], outs[0]
 
 
+def _result(out):
+    import json
+    line = [l for l in out.splitlines() if l.startswith("MP_RESULT")]
+    assert line and "ok=True" in line[0], out
+    crc = line[0].split("crc=")[1].split()[0]
+    return crc, json.loads(line[0].split("info=")[1])
+
+
+def test_collective_transport_over_torch_distributed_gloo_equals_the_copy_transport():
+    """the third transport.  Two ranks share GPU 0; everything that crosses ranks -- the partial sums, the rows
+    beyond the band edges, the flow rows and bands -- travels through torch.distributed (gloo: staged through the host; on a node the
+    same code runs on backend nccl = RCCL over xGMI with the device buffers themselves, octane_amd/exchange.py).  The kernels read
+    local memory only, as with the copy transport, and every rank folds all ranks' partial sums in the same order: the flow must be
+    the copy transport's BIT FOR BIT, within 2e-5 of the plain plan and of the oracle, with equal iteration counts."""
+    args = (320, 288, 3, 2, 12, 1)
+    codes, outs = _run(2, args, extra_env={"OCTANE_TILED_TRANSPORT": "copy"})
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    crc_copy, info_copy = _result(outs[0])
+    codes, outs = _run(2, args, extra_env={"OCTANE_TILED_TRANSPORT": "collective", "OCTANE_TEST_EXCHANGE": "1"})
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    crc_coll, info_coll = _result(outs[0])
+    print("COLLECTIVE", crc_copy, crc_coll, info_coll)
+    assert info_copy["transport_used"] == "copy" and info_coll["transport_used"] == "collective" and info_coll["forced"]
+    assert info_coll["exchange"].startswith("torch.distributed/gloo")
+    assert info_coll["exchange_calls"]["all_gather"] > 0 and info_coll["exchange_calls"]["sendrecv"] > 0
+    assert crc_coll == crc_copy
+
+
+def test_collective_transport_three_ranks_with_hint():
+    """Three ranks (a middle band with two neighbours), first-guess hint term, the collective transport chosen by force."""
+    codes, outs = _run(3, (300, 420, 3, 1, 10, 1), extra_env={"OCTANE_TILED_TRANSPORT": "collective", "OCTANE_TEST_EXCHANGE": "1"})
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    crc, info = _result(outs[0])
+    codes, outs = _run(3, (300, 420, 3, 1, 10, 1), extra_env={"OCTANE_TILED_TRANSPORT": "copy"})
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    crc_copy, _ = _result(outs[0])
+    assert info["transport_used"] == "collective" and crc == crc_copy
+
+
+def test_first_contact_selfcheck_keeps_the_in_place_transport_when_it_works():
+    """Default environment: octane_vof_mp_selfcheck solves a small frame under inplace first; on this box (IPC mappings of one GPU)
+    that passes, so the plan reads in place and says so."""
+    codes, outs = _run(2, (320, 288, 3, 2, 12, 1), extra_env={"OCTANE_TEST_EXCHANGE": "1"})
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    _, info = _result(outs[0])
+    print("SELFCHECK", info)
+    assert info["transport_used"] == "inplace" and info["selfcheck"] == "first candidate passed" and not info["forced"]
+    assert info["peer_ok"] and info["bands"] == 2 and info["check_rel_l2"] and info["check_rel_l2"][0] <= 2e-5
+
+
+@pytest.mark.parametrize("bits,want,exchange", [
+    (1, "copy", "1"),              # in-place reads of the partial sums return the wrong block -> the copy transport
+    (5, "collective", "1"),        # ... and the copy transport leaves the mirror unfilled -> the collective library
+    (8, "collective", "1"),        # the IPC mappings cannot be opened at all -> the collective library, no check candidates before it
+])
+def test_first_contact_selfcheck_downgrades_automatically(bits, want, exchange):
+    """VERDICT r3 item 2(b), the drill: with the DIAGNOSTIC library's fault hook (OCTANE_TEST_BREAK_TRANSPORT; the product library has
+    none) a transport gives wrong sums / cannot be set up.  The self-check must notice, say so once on stderr, fall back to the next
+    transport on every rank alike -- and the solve that follows must still be right (ok=True: plain plan, oracle, iteration counts)."""
+    from octane_amd import capi
+    if not os.path.exists(capi.DIAG_LIB_PATH):
+        pytest.skip("diagnostic library not built")
+    codes, outs = _run(2, (320, 288, 3, 2, 12, 1), extra_env={"OCTANE_TEST_EXCHANGE": exchange, "OCTANE_LIB": capi.DIAG_LIB_PATH,
+                                                              "OCTANE_TEST_BREAK_TRANSPORT": str(bits)})
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    _, info = _result(outs[0])
+    print("DOWNGRADE", bits, info)
+    assert info["transport_used"] == want
+    if bits == 8:
+        assert not info["peer_ok"]
+    else:
+        assert info["selfcheck"] == "downgraded" and info["candidates_tried"] >= 2
+        assert "self-check" in outs[0]
+
+
+def test_no_usable_transport_is_an_error_on_every_rank_not_a_hang():
+    """IPC unavailable (drill) and no collective library registered: octane_vof_mp_connect has to fail on both ranks, with a message
+    that names the way out."""
+    from octane_amd import capi
+    if not os.path.exists(capi.DIAG_LIB_PATH):
+        pytest.skip("diagnostic library not built")
+    codes, outs = _run(2, (320, 288, 3, 2, 12, 1), extra_env={"OCTANE_LIB": capi.DIAG_LIB_PATH, "OCTANE_TEST_BREAK_TRANSPORT": "8"})
+    assert all(c == 3 for c in codes), "\n".join(outs)
+    assert all("octane_vof_mp_set_exchange" in o for o in outs)
+
+
 def test_an_abandoned_persistent_solve_fails_every_rank():
     """the process form runs its replicated levels through the persistent mid-level solve as well.  With the
     test hook on in both ranks the 320 x 250 level's solve is abandoned; both ranks' octane_vof_mp_run must return the error
