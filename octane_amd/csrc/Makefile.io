@@ -8,7 +8,15 @@
 CXX       ?= g++
 HDF5_ROOT ?= /opt/conda
 HERE  := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
+# SAN=1: AddressSanitizer + UndefinedBehaviorSanitizer build into octane_amd/_san/ (after `make -f Makefile.host SAN=1`)
+SAN   ?= 0
+ifeq ($(SAN),1)
+LIBD  := $(HERE)../_san
+OPT   := -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined
+else
 LIBD  := $(HERE)..
+OPT   := -O2
+endif
 HAVE_HDF5 := $(wildcard $(HDF5_ROOT)/include/hdf5_hl.h)
 
 ifeq ($(HAVE_HDF5),)
@@ -18,12 +26,12 @@ else
 all: $(LIBD)/liboctane_io.so $(LIBD)/octane
 
 $(LIBD)/liboctane_io.so: $(HERE)io/nc4lite.cpp $(HERE)io/goes_io.cpp $(HERE)io/nc4lite.hpp $(LIBD)/liboctane_host.so
-	$(CXX) -O2 -fPIC -shared -std=c++17 -Wall -I$(HDF5_ROOT)/include -o $@ $(HERE)io/nc4lite.cpp $(HERE)io/goes_io.cpp \
+	$(CXX) $(OPT) -fPIC -shared -std=c++17 -Wall -I$(HDF5_ROOT)/include -o $@ $(HERE)io/nc4lite.cpp $(HERE)io/goes_io.cpp \
 	    -L$(LIBD) -loctane_host -loctane_vof $(HDF5_ROOT)/lib/libhdf5_hl.so $(HDF5_ROOT)/lib/libhdf5.so \
 	    -Wl,--enable-new-dtags -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(HDF5_ROOT)/lib
 
 $(LIBD)/octane: $(HERE)io/octane_main.cpp $(LIBD)/liboctane_io.so
-	$(CXX) -O2 -std=c++17 -Wall -o $@ $(HERE)io/octane_main.cpp -L$(LIBD) -loctane_io -loctane_host -loctane_vof \
+	$(CXX) $(OPT) -std=c++17 -Wall -o $@ $(HERE)io/octane_main.cpp -L$(LIBD) -loctane_io -loctane_host -loctane_vof \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,$(HDF5_ROOT)/lib
 endif
 

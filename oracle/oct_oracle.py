@@ -70,7 +70,11 @@ def lib(flavour: str = "strict") -> C.CDLL:
     build()
     name = {"strict": "liboct_oracle.so", "fma": "liboct_oracle_fma.so", "omp": "liboct_oracle_omp.so",
             "fma_omp": "liboct_oracle_fma_omp.so"}[flavour]
-    L = C.CDLL(os.path.join(_HERE, name))
+    if os.environ.get("OCT_SANITIZE") == "1":      # the ASan + UBSan builds (`make sanitize`; the process runs under LD_PRELOAD=libasan.so:libubsan.so)
+        subprocess.check_call(["make", "-C", _HERE, "-s", "sanitize"])
+        L = C.CDLL(os.path.join(_HERE, "_san", name))
+    else:
+        L = C.CDLL(os.path.join(_HERE, name))
     L.oct_oracle_num_threads.restype = C.c_int
     L.oct_oracle_vof.restype = C.c_int
     L.oct_oracle_vof.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, _F, _F, C.POINTER(Params), C.c_void_p]

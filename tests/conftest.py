@@ -22,6 +22,19 @@ def rel_l2(u, v, uo, vo):
     return float(np.sqrt(num / den)) if den > 0 else float(np.sqrt(num))
 
 
+SANITIZE = os.environ.get("OCT_SANITIZE") == "1"      # `make sanitize`: host libraries and oracle built with ASan + UBSan (the process is preloaded)
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g"] if SANITIZE else []
+
+
+def host_libdir():
+    """Where liboctane_host.so / liboctane_io.so are: octane_amd/, or octane_amd/_san/ under `make sanitize`."""
+    return os.path.join(ROOT, "octane_amd", "_san") if SANITIZE else os.path.join(ROOT, "octane_amd")
+
+
+def host_make_args():
+    return ["SAN=1"] if SANITIZE else []
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oct_oracle

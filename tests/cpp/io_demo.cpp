@@ -8,6 +8,8 @@
 //   io_demo --write-out out.nc GOES|POLAR|MERC nx ny nchan    runs oct_filewrite on a synthetic, fully populated GOESVar (no GPU)
 //   io_demo --dump file.nc                                    one line per variable: name|shape|att=value;...
 //   io_demo --read file.nc var type out.bin                   whole variable as short|int|float|double
+//   io_demo --goesread file.nc                                oct_goesread on the file (channel 1, RAW, no navigation): prints rc=<code>; a file
+//                                                            that is not a readable GOES-R L1b has to come back as an error, not a crash
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +22,7 @@
 using nc4lite::Type;
 
 int oct_filewrite(std::string, std::string, GOESVar &, OFFlags);
+int oct_goesread(std::string, std::string, int, int, GOESVar &, OFFlags &);
 
 int main(int argc, char **argv)
 {
@@ -152,6 +155,14 @@ int main(int argc, char **argv)
             const int rc = oct_filewrite(argv[2], ftype, g, args);
             g.data.data = nullptr;          // the vectors own the memory
             return rc;
+        }
+        if (argc == 3 && !strcmp(argv[1], "--goesread")) {
+            GOESVar g;
+            OFFlags args;
+            octane_default_flags(args);
+            const int rc = oct_goesread(argv[2], "RAW", 0, 1, g, args);
+            printf("rc=%d\n", rc);
+            return rc == 0 ? 0 : 4;
         }
         if (argc == 3 && !strcmp(argv[1], "--dump")) {
             fputs(nc4lite::describe(argv[2]).c_str(), stdout);

@@ -13,17 +13,18 @@ BUILD = os.path.join(ROOT, "tests", "cpp", "build")
 
 def _compile(src, out, inc, extra=()):
     os.makedirs(BUILD, exist_ok=True)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-I", inc, os.path.join(ROOT, "tests", "cpp", src), "-o", out, *extra])
+    from conftest import SAN_FLAGS
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", *SAN_FLAGS, "-I", inc, os.path.join(ROOT, "tests", "cpp", src), "-o", out, *extra])
     return out
 
 
 @pytest.fixture(scope="module")
 def host_demo(capi):
     capi.lib()
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "octane_amd", "csrc"), "-s", "-f", "Makefile.host"])
+    from conftest import host_libdir, host_make_args
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "octane_amd", "csrc"), "-s", "-f", "Makefile.host", *host_make_args()])
     return _compile("host_demo.cpp", os.path.join(BUILD, "host_demo"), os.path.join(ROOT, "include"),
-                    ["-L", os.path.join(ROOT, "octane_amd"), "-loctane_host", "-loctane_vof",
-                     "-Wl,-rpath," + os.path.join(ROOT, "octane_amd")])
+                    ["-L", host_libdir(), "-loctane_host", "-loctane_vof", "-Wl,-rpath," + host_libdir()])
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_INC), reason="reference headers not on this machine")

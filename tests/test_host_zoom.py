@@ -13,7 +13,10 @@ F = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 def _lib():
     from octane_amd import capi
     capi.lib()                                       # liboctane_host.so links the flow library
-    L = C.CDLL(os.path.join(ROOT, "octane_amd", "liboctane_host.so"))
+    import subprocess
+    from conftest import host_libdir, host_make_args
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "octane_amd", "csrc"), "-s", "-f", "Makefile.host", *host_make_args()])
+    L = C.CDLL(os.path.join(host_libdir(), "liboctane_host.so"))
     zo = L._Z18oct_zoom_out_floatPfS_iidii
     zo.argtypes = [F, F, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
     zi = L._Z17oct_zoom_in_floatPfS_iiiiii

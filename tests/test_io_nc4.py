@@ -9,12 +9,13 @@ import subprocess
 import numpy as np
 import pytest
 
+from conftest import SAN_FLAGS, host_libdir, host_make_args
 from octane_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "tests", "cpp", "build")
 HDF5_ROOT = os.environ.get("HDF5_ROOT", "/opt/conda")
-LIBD = os.path.join(ROOT, "octane_amd")
+LIBD = host_libdir()
 
 # the reader's lam0: the file's float attribute times a double DTOR, rounded back to float (ref fr:179-182)
 LAM0 = np.float32(np.float64(np.float32(-75.0)) * (3.14159265359 / 180.0))
@@ -27,11 +28,11 @@ pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(HDF5_ROOT, "incl
 def io_demo(capi):
     capi.lib()
     csrc = os.path.join(ROOT, "octane_amd", "csrc")
-    subprocess.check_call(["make", "-C", csrc, "-s", "-f", "Makefile.host"])
-    subprocess.check_call(["make", "-C", csrc, "-s", "-f", "Makefile.io"])
+    subprocess.check_call(["make", "-C", csrc, "-s", "-f", "Makefile.host", *host_make_args()])
+    subprocess.check_call(["make", "-C", csrc, "-s", "-f", "Makefile.io", *host_make_args()])
     os.makedirs(BUILD, exist_ok=True)
     out = os.path.join(BUILD, "io_demo")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-I", os.path.join(csrc, "io"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", *SAN_FLAGS, "-I", os.path.join(csrc, "io"),
                            os.path.join(ROOT, "tests", "cpp", "io_demo.cpp"), "-o", out, "-L", LIBD, "-loctane_io", "-loctane_host",
                            "-loctane_vof", "-Wl,-rpath," + LIBD, "-Wl,-rpath-link," + os.path.join(HDF5_ROOT, "lib")])
     return out
@@ -481,3 +482,48 @@ def test_outfile_is_read_by_an_independent_hdf5_tool(io_demo, tmp_path):
     # and the values come back through the tool as well: a corner of U
     r = subprocess.run([H5DUMP, "-d", "/U", "-s", "0,0", "-c", "1,5", str(out)], capture_output=True, text=True)
     assert r.returncode == 0 and "(0,0): 0, 1, 2, 3, 4" in r.stdout, r.stdout
+
+
+def _damaged_copies(good, tmp_path):
+    raw = good.read_bytes()
+    n = len(raw)
+    cases = {"empty": b"", "not_hdf5": b"this is not an HDF5 file\n" * 200, "truncated_to_a_third": raw[:n // 3],
+             "truncated_by_one_kilobyte": raw[:n - 1024], "header_only": raw[:512]}
+    rng = np.random.RandomState(11)
+    noisy = bytearray(raw)
+    for pos in rng.randint(64, n, size=400):            # 400 flipped bytes anywhere behind the signature
+        noisy[pos] ^= 0xFF
+    cases["random_bytes_flipped"] = bytes(noisy)
+    zeroed = bytearray(raw)
+    zeroed[n // 2:n // 2 + 4096] = bytes(4096)            # a hole in the middle (object headers / chunk data)
+    cases["hole_in_the_middle"] = bytes(zeroed)
+    out = {}
+    for name, data in cases.items():
+        f = tmp_path / (name + ".nc")
+        f.write_bytes(data)
+        out[name] = f
+    return out
+
+
+def test_truncated_and_corrupt_files_are_errors_not_crashes(io_demo, tmp_path):
+    """the reader parses files.  Damaged inputs -- empty, not HDF5, cut short, bytes flipped, a zeroed hole -- must
+    come back as an error code / message from every entry (nc4lite::describe, Reader::read, oct_goesread), never as a signal, and
+    under `make sanitize` (ASan + UBSan builds of nc4lite.cpp / goes_io.cpp / io_demo.cpp) without a sanitizer report.  The
+    reference's reader has no such handling (netcdf-cxx4 exceptions escape, ref src/oct_fileread.cc:43-419)."""
+    nx, ny = 96, 64
+    c1, _ = _counts(nx, ny, 3)
+    raw = tmp_path / "rad.bin"
+    c1.tofile(raw)
+    good = tmp_path / "good.nc"
+    subprocess.check_call([io_demo, "--make-goes", str(good), str(nx), str(ny), str(raw), "7.1e8", "13", "-0.031332", "0.081212"])
+    for name, f in _damaged_copies(good, tmp_path).items():
+        for mode in (["--dump", str(f)], ["--read", str(f), "Rad", "short", str(tmp_path / "o.bin")], ["--goesread", str(f)]):
+            r = subprocess.run([io_demo, *mode], capture_output=True, text=True, timeout=120)
+            log = r.stdout + r.stderr
+            assert r.returncode >= 0, f"{name} {mode[0]}: killed by signal {-r.returncode}\n{log}"
+            assert "AddressSanitizer" not in log and "runtime error:" not in log, f"{name} {mode[0]}:\n{log}"
+            if name in ("empty", "not_hdf5", "truncated_to_a_third", "header_only"):
+                assert r.returncode != 0, f"{name} {mode[0]} was accepted:\n{log}"       # nothing readable can be in there
+            elif r.returncode == 0 and mode[0] == "--read":
+                # flipped bytes / a hole may leave the file readable (damage in chunk data or unused space); whatever comes back has the right size
+                assert os.path.getsize(tmp_path / "o.bin") == nx * ny * 2

@@ -103,7 +103,9 @@ def test_fma_flavour_is_within_the_noise_floor(oracle):
     u, v, _ = oracle.flow(a, b)
     uf, vf, _ = oracle.flow(a, b, flavour="fma")
     d = rel_l2(uf, vf, u, v)
-    assert 0 < d < 1e-5
+    from conftest import SANITIZE
+    # (the -O1 sanitizer builds of `make sanitize` may leave the products uncontracted: the two flavours can then coincide)
+    assert (0 < d or SANITIZE) and d < 1e-5
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference sources not on this machine")
@@ -204,7 +206,8 @@ def test_band_range_table_equals_the_reference_table(capi):
     values untouched in the shim (the reference's if-chain has no else) and is an error code in the C-ABI.  No GPU involved."""
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_bandminmax.npz"))
     sentinel = np.float32(g["sentinel"])
-    host = os.path.join(os.path.dirname(capi.LIB_PATH), "liboctane_host.so")
+    from conftest import host_libdir
+    host = os.path.join(host_libdir(), "liboctane_host.so")
     shim = None
     if os.path.exists(host):
         capi.lib()                                   # liboctane_vof.so first: the shim links against it
