@@ -95,14 +95,23 @@ int octane_vof_plan_run(octane_vof_plan *plan, const float *img1, const float *i
 int octane_vof_plan_solve(octane_vof_plan *plan, const float *img1, const float *img2, const float *u0, const float *v0,
                           float *u_out, float *v_out, int mem, void *hip_stream);
 
-/* Number of PCG iterations the last completed run executed (sum over all solves); blocks on the stream. */
-int octane_vof_plan_wait(octane_vof_plan *plan);          /* blocks until the plan's private stream is idle; OCTANE_E_HIP when a
-                                                            * persistent solve of the run gave up (see below) */
-/* -2 when the last run is not valid: the mid-size pyramid levels are solved by ONE persistent launch each whose workgroups all
- * have to be resident on the GPU at once; if they cannot become so within 0.25 s (another process running the same kind of
- * kernel on this GPU) the solve gives up instead of hanging the GPU.  Host-buffer runs return OCTANE_E_HIP themselves;
- * OCTANE_TUNE_PERSIST=0 selects one launch per iteration. */
+/* Blocks until the plan's private stream (and the stream of its last device-buffer run) is idle. */
+int octane_vof_plan_wait(octane_vof_plan *plan);
+/* Number of PCG iterations the last completed run executed (sum over all solves).
+ * An ABANDONED persistent solve: the mid-size pyramid levels are solved by ONE persistent launch each whose workgroups all have to be
+ * resident on the GPU at once; if they cannot become so within 0.25 s (another process running the same kind of kernel on this GPU)
+ * the solve gives up instead of hanging the GPU, and the run's flow is not valid.  The library repairs that itself: host-buffer runs
+ * solve the pair again before they return; device-buffer runs are repaired by the first of octane_vof_plan_wait /
+ * octane_vof_plan_last_iterations called after the caller has synchronised with the run -- the pyramid is made again (one launch per
+ * PCG iteration) from the plan's own copy of the inputs, on that run's stream, and written into THAT RUN'S output buffers, which
+ * therefore have to stay valid until one of the two has been called.  A caller of the device-buffer path that calls neither never
+ * learns of an abandoned solve: it MUST call one of them per run before it uses the flow.  -2 / OCTANE_E_HIP only when the repair
+ * fails too.  After such an event the plan runs its next 16 pairs with one launch per iteration and then tries the persistent solve
+ * again; octane_vof_plan_persist_state tells: 1 on, 0 off (OCTANE_TUNE_PERSIST=0 / tune), -n off for the next n runs, and how
+ * often a solve of this plan was abandoned.  The row-band forms (octane_vof_tiled_*, octane_vof_mp_*) report -2 / an error and do
+ * not retry. */
 long long octane_vof_plan_last_iterations(octane_vof_plan *plan);
+int octane_vof_plan_persist_state(const octane_vof_plan *plan, int *abandoned_total);
 
 /* Debug tap (NULL = off, zero cost): called on the host after each stage with a copy of the stage's
  * planes: data is nplanes planes of ny rows of nx floats.  Tags match oracle/vof_oracle.c's trace. */
@@ -145,7 +154,7 @@ int octane_selftest_rcp(int device, unsigned long long *out3);
  * or six times per pixel, takes 1 / (s + 1) three times per channel (Zimmer's normalisation) and 1 / sqrt(x + 1e-6) twice, all in double
  * and rounded to float afterwards.  The library uses cheaper instruction sequences for these where -- and only where -- the
  * sequence reproduces the IEEE result on EVERY float input for that alpha; this runs the comparison: out8 = {patterns, mismatches}
- * x {x / alpha, all finite floats; 1 / (s + 1), all floats s >= 0; 1 / sqrt(x + 1e-6), all floats x >= 0}, [6] = a mismatching bit pattern,
+ * x {x / alpha, all floats but the NaNs; 1 / (s + 1), all floats s >= 0 and +inf; 1 / sqrt(x + 1e-6), the same}, [6] = a mismatching bit pattern,
  * [7] = its test.  octane_selftest_assembly_math_bits: which forms (bit 0, 1, 2 in that order) plans with this alpha use; runs the
  * self-test the first time an alpha is seen (~10 ms), exactly as plan creation does. */
 int octane_selftest_assembly_math(int device, double alpha, unsigned long long *out8);

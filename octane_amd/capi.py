@@ -28,7 +28,7 @@ DIAG_EXPORTS = ("octane_vof_plan_probe_stamps", "octane_vof_mid_stamps")
 EXPORTS = (
     "octane_vof_default_params", "octane_vof_run", "octane_vof_release_cache", "octane_vof_plan_create", "octane_vof_plan_destroy",
     "octane_vof_plan_device_bytes", "octane_vof_plan_placement_trials", "octane_vof_plan_run", "octane_vof_plan_solve", "octane_vof_plan_wait", "octane_vof_plan_last_iterations",
-    "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_get_launch_times", "octane_vof_plan_probe", "octane_vof_tune", "octane_vof_mid_geometry", "octane_selftest_rcp", "octane_selftest_assembly_math", "octane_selftest_assembly_math_bits",
+    "octane_vof_plan_persist_state", "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_get_launch_times", "octane_vof_plan_probe", "octane_vof_tune", "octane_vof_mid_geometry", "octane_selftest_rcp", "octane_selftest_assembly_math", "octane_selftest_assembly_math_bits",
     "octane_vof_batch_run",
     "octane_vof_tiled_create", "octane_vof_tiled_destroy", "octane_vof_tiled_load", "octane_vof_tiled_solve",
     "octane_vof_tiled_wait", "octane_vof_tiled_fetch", "octane_vof_tiled_run", "octane_vof_tiled_banded_levels",

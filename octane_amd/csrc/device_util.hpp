@@ -82,7 +82,9 @@ __device__ __forceinline__ void block_sum_multi(const double (&v)[N], double *sc
 }
 // 1 / x, correctly rounded for every normal x whose reciprocal is normal (checked against the division on all of them by
 // octane_selftest_rcp (pcg_persist.hip) / tests/test_gpu_persist.py): the hardware estimate (1 ulp) and one Newton step in fused arithmetic.
-// Three instructions instead of the eleven of an IEEE division; the diagonal of the operator is >= 1, far inside that range.
+// Three instructions instead of the eleven of an IEEE division; the diagonal of the operator is a normal float with a normal reciprocal
+// (in the robust GNC step it can be well below 1: psi' weights of a steep flow) -- inside that range.  NOT equal to the division at
+// +-inf (NaN instead of 0): callers that can meet an infinity in a diverged run guard it (vof_kernels.hip psi_smooth).
 __device__ __forceinline__ float rcp_exact(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);
@@ -261,7 +263,7 @@ __device__ __forceinline__ void slab_walk_next(SlabWalk &w) { w.idx += w.per; }
 // (float)(1. / (double)a) IS the correctly rounded float reciprocal: rounding a quotient of two 24-bit numbers to 53 bits and then to 24
 // cannot differ from rounding it to 24 at once (53 >= 2 * 24 + 2), checked on all 2 130 706 432 positive normal floats by
 // tests/test_oracle_pins.py::test_float_reciprocal_through_double_is_the_float_division -- and rcp_exact is that reciprocal in three
-// instructions (octane_selftest_rcp).  The diagonal of the operator is >= 1: normal, with a normal reciprocal.
+// instructions (octane_selftest_rcp).  The diagonal of the operator is a normal float with a normal reciprocal.
 __device__ __forceinline__ float jacobi_inv(float a) { return rcp_exact(a); }
 
 }  // namespace octane

@@ -185,7 +185,11 @@ __global__ __launch_bounds__(kMidT) void k_pcg_solve_mid(LevelPtrs L, MidArgs A)
 
     // The solve's scalars between the launches of the stepped form, double-buffered by the parity of the first iteration (a
     // one-iteration launch has no barrier, so workgroup 0 may write the new state before another workgroup has read the old)
-    if (A.fault && wg == A.G - 1) return;                  // test hook: a workgroup that never shows up -- the others have to give up, not hang
+#ifdef OCTANE_DIAG
+    // diagnostic library only (round 4: the product kernel carries no test hook): a workgroup that never shows up -- the others have to
+    // give up, not hang (tests/persist_fault_worker.py)
+    if (A.fault && wg == A.G - 1) return;
+#endif
     PcgState st = L.st[A.k0 & 1];
     if (A.k0 == 0) { st.rz = 0.f; st.stopped = 0; st.iters = 0; }
     if (st.stopped) {                                      // stepped form: the loop ended in an earlier launch (uniform)
@@ -610,7 +614,7 @@ size_t pcg_mid_workspace_bytes()
 #endif
 // Iterations [k0, k1) of one solve; k0 = 0 and k1 = cgiters is the whole solve in one launch (plus the flow update).
 static int g_mid_fault = 0;
-#ifndef MID_DIAG
+#if defined(OCTANE_DIAG) && !defined(MID_DIAG)
 void set_mid_fault(int v) { g_mid_fault = v != 0; }
 #endif
 

@@ -224,7 +224,9 @@ constexpr int kAsmTX = 64, kAsmTY = 4;
 // NaN here and 0 there.)
 __device__ __forceinline__ float psi_smooth(float x)
 {
-    return rcp_exact(sqrtf((float)((double)x + 1E-6)));
+    // (rcp_exact's Newton step turns 1 / inf into NaN where the division gives 0: a run that has diverged keeps the reference's value)
+    const float s = sqrtf((float)((double)x + 1E-6));
+    return s == __builtin_inff() ? 0.f : rcp_exact(s);
 }
 // psi'_d (ref .cu:96-103) as the reference's expression compiles: IEEE square root, IEEE division, in double
 __device__ __forceinline__ float psi_data_ieee(float x)
@@ -240,7 +242,7 @@ __device__ __forceinline__ float psi_data_fast(float x)
     double h = 0.5 * d;
     y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
     y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
-    return (float)y;
+    return (float)(d == (double)__builtin_inff() ? 0. : y);       // x = +inf (a diverged run): the Newton steps give NaN, 1 / sqrt(inf) is 0
 }
 // 1 / (s + 1) in double, rounded to float (the Zimmer normalisations, ref .cu:795-803), the reference's way ...
 __device__ __forceinline__ float rcp1p_ieee(float s) { return (float)(1. / ((double)s + 1.)); }
@@ -251,7 +253,7 @@ __device__ __forceinline__ float rcp1p_fast(float s)
     double r = __builtin_amdgcn_rcp(d);
     r = __builtin_fma(__builtin_fma(-d, r, 1.), r, r);
     r = __builtin_fma(__builtin_fma(-d, r, 1.), r, r);
-    return (float)r;
+    return (float)(d == (double)__builtin_inff() ? 0. : r);       // s = +inf: 0, as the division gives (the Newton steps: NaN)
 }
 // x / alpha, correctly rounded, from the correctly rounded reciprocal of alpha: q = x * ralpha, then one step on the exact residual
 // x - alpha * q (Markstein).  Three fp64 instructions instead of ~14; fast_math bit 0: only after the self-test has compared it with
@@ -259,8 +261,8 @@ __device__ __forceinline__ float rcp1p_fast(float s)
 __device__ __forceinline__ double div_alpha_fast(double x, double alpha, double ralpha)
 {
     const double q = x * ralpha;
-    // (a zero keeps its sign as the quotient does: the residual step would turn -0 into +0)
-    return q == 0. ? q : __builtin_fma(__builtin_fma(-alpha, q, x), ralpha, q);
+    // (a zero keeps its sign as the quotient does: the residual step would turn -0 into +0; an infinity stays one: the step gives NaN)
+    return (q == 0. || __builtin_fabs(q) == (double)__builtin_inff()) ? q : __builtin_fma(__builtin_fma(-alpha, q, x), ralpha, q);
 }
 __device__ __forceinline__ float sq(float x) { return x * x; }
 
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
         float t1 = 0, t2 = 0, t4 = 0, t5 = 0, t6 = 0, e1 = 0;
         float g1 = 0, g2s = 0, g4 = 0, g5 = 0, g6 = 0, e2 = 0;
         const int nchan = NC > 0 ? NC : L.nc;
-        for (int c = 0; c < nchan; c++) {
+        for (int c = 0; c < nchan; c++) {      // (a constant trip count of 1 ... 3 is unrolled by the compiler)
             const size_t cb = L.cstride * c;
 #define OCT_BIL(F) (p3 * ((p1) * (F)[cb + c1] + (p2) * (F)[cb + c1 + 1]) + p4 * ((p1) * (F)[cb + c3] + (p2) * (F)[cb + c3 + 1]))
             float w2 = OCT_BIL(L.img2);
@@ -488,9 +490,20 @@ int assemble_grid_size(int w, int h)
 
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid)
 {
-    if (L.nc != 1) { hipLaunchKernelGGL((k_assemble<0, -1, -1, -1>), dim3(grid), dim3(256), 0, s, L, P); return; }
+    static const bool generic_only = [] { const char *e = getenv("OCTANE_TUNE_ASM_GENERIC"); return e && atoi(e) != 0; }();   // developer knob: A/B timing
+    if (generic_only) { hipLaunchKernelGGL((k_assemble<0, -1, -1, -1>), dim3(grid), dim3(256), 0, s, L, P); return; }
     const int mode = P.al1 == 1.0 ? 0 : (P.al1 == 0.0 ? 2 : 1);
     const int z = P.dozim ? 1 : 0, hn = P.lambdac != 0.f ? 1 : 0;
+    // Two and three channels (round 4; the reference's loop treats 1 ... 3 alike, ref .cu:749-829): the channel count and the GNC step as
+    // template parameters for the default flags (Zimmer's normalisation on, no hint term) -- the channel loop is then unrolled and its
+    // `cstride * c` address arithmetic folds into the 27 loads; every other combination runs the generic instance.
+    if (L.nc != 1) {
+#define OCT_ASM_NC(N, M) if (L.nc == N && mode == M && z == 1 && hn == 0) { hipLaunchKernelGGL((k_assemble<N, M, 1, 0>), dim3(grid), dim3(256), 0, s, L, P); return; }
+        OCT_ASM_NC(2, 0) OCT_ASM_NC(2, 1) OCT_ASM_NC(2, 2) OCT_ASM_NC(3, 0) OCT_ASM_NC(3, 1) OCT_ASM_NC(3, 2)
+#undef OCT_ASM_NC
+        hipLaunchKernelGGL((k_assemble<0, -1, -1, -1>), dim3(grid), dim3(256), 0, s, L, P);
+        return;
+    }
 #define OCT_ASM_CASE(M, Z, H) if (mode == M && z == Z && hn == H) { hipLaunchKernelGGL((k_assemble<1, M, Z, H>), dim3(grid), dim3(256), 0, s, L, P); return; }
     OCT_ASM_CASE(0, 1, 0) OCT_ASM_CASE(1, 1, 0) OCT_ASM_CASE(2, 1, 0) OCT_ASM_CASE(0, 0, 0) OCT_ASM_CASE(1, 0, 0) OCT_ASM_CASE(2, 0, 0)
     OCT_ASM_CASE(0, 1, 1) OCT_ASM_CASE(1, 1, 1) OCT_ASM_CASE(2, 1, 1) OCT_ASM_CASE(0, 0, 1) OCT_ASM_CASE(1, 0, 1) OCT_ASM_CASE(2, 0, 1)
@@ -507,12 +520,12 @@ __global__ void k_selftest_asm_math(double alpha, double ralpha, unsigned long l
     for (unsigned long long b = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; b < 0x100000000ull; b += stride) {
         const unsigned u = (unsigned)b;
         const float x = __uint_as_float(u);
-        if ((u & 0x7F800000u) != 0x7F800000u) {          // x / alpha: every finite float, both signs, zeros and denormals included
+        if ((u & 0x7FFFFFFFu) <= 0x7F800000u) {          // x / alpha: every float but the NaNs, both signs, zeros, denormals and infinities included
             const double want = (double)x / alpha, got = div_alpha_fast((double)x, alpha, ralpha);
             n0++;
             if (__double_as_longlong(want) != __double_as_longlong(got)) { if (!(b0 + b1 + b2)) { first = b; which = 0; } b0++; }
         }
-        if (u < 0x7F800000u) {                           // s >= 0 finite: 1 / (s + 1) and 1 / sqrt(x + 1e-6)
+        if (u <= 0x7F800000u) {                          // s >= 0, +inf included: 1 / (s + 1) and 1 / sqrt(x + 1e-6)
             n1++;
             if (__float_as_uint(rcp1p_ieee(x)) != __float_as_uint(rcp1p_fast(x))) { if (!(b0 + b1 + b2)) { first = b; which = 1; } b1++; }
             n2++;
@@ -535,9 +548,9 @@ int assemble_fast_math_bits(double alpha)
     unsigned long long r[8] = {0};
     int bits = 0;
     if (assemble_math_selftest(nullptr, alpha, r) == 0) {
-        if (r[0] == 0xFF000000ull && r[1] == 0) bits |= 1;       // 2 x (2^31 - 2^23) finite floats
-        if (r[2] == 0x7F800000ull && r[3] == 0) bits |= 2;
-        if (r[4] == 0x7F800000ull && r[5] == 0) bits |= 4;
+        if (r[0] == 0xFF000002ull && r[1] == 0) bits |= 1;       // 2 x (2^31 - 2^23) finite floats and the two infinities
+        if (r[2] == 0x7F800001ull && r[3] == 0) bits |= 2;       // every float >= 0 and +inf
+        if (r[4] == 0x7F800001ull && r[5] == 0) bits |= 4;
     }
     known[alpha] = bits;
     return bits;

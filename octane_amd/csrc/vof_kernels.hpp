@@ -150,7 +150,7 @@ struct MidArgs {
     int k0, k1, kcap;                // this launch runs iterations [k0, k1) of a solve capped at kcap
     int nparts_asm;                  // partial sums the assembly wrote (r.z, r.r of the right-hand side)
     int full_state;                  // stepped form: the complete state is stored to / loaded from the level's planes
-    int fault;                       // test hook: the last workgroup leaves at once (the others' waits then have to give up)
+    int fault;                       // diagnostic library only (the product kernel ignores it): the last workgroup leaves at once, the others' waits then have to give up
     float tol;
     unsigned tag0;                   // granule tags of this solve are tag0 + iteration + 1
     unsigned int *abort_word;        // raised when a wait timed out
@@ -160,7 +160,7 @@ struct MidArgs {
 };
 int  pcg_mid_config(int w, int h, int ncu, int force_p, MidGeom *g);
 void set_mid_min_p(int p);          // smallest slot count pcg_mid_config may choose (developer knob OCTANE_TUNE_PERSIST_MINP)
-void set_mid_fault(int v);               // test hook, see MidArgs::fault
+void set_mid_fault(int v);               // diagnostic library only, see MidArgs::fault
 void pcg_mid_configure();
 size_t pcg_mid_workspace_bytes();
 hipError_t launch_pcg_solve_mid(hipStream_t s, const LevelPtrs &L, const MidGeom &g, void *workspace, unsigned seq, int k0, int k1, int kcap,

@@ -47,6 +47,7 @@ struct octane_vof_plan {
     hipStream_t side_stream = nullptr;      // prepares the next level's images and gradients beside the current level's solve
     hipEvent_t ev_fork = nullptr, ev_img[2] = {nullptr, nullptr}, ev_solved[2] = {nullptr, nullptr};
     int use_overlap = 1;                    // OCTANE_TUNE_OVERLAP=0: everything on one stream, level by level
+    int has_bset = 1;                       // the second set of level planes exists (not in band plans, not with the overlap off at creation)
     octane_vof_trace_fn trace = nullptr;
     void *trace_user = nullptr;
     int trace_levels = 0;                   // > 0: the debug tap reports only that many coarsest levels (tune key "trace_levels")
@@ -79,6 +80,15 @@ struct octane_vof_plan {
     unsigned mid_seq = 1;          // solves issued on that workspace: part of the granules' tags
     unsigned *h_mid_abort = nullptr;   // pinned copy of the abort word, refreshed at the end of every run
     std::vector<float> pcg_launch_ms;   // the finest-level PCG launches of the last profiled run, in launch order
+    // An abandoned persistent solve (its workgroups could not all become resident: a co-tenant on the GPU) switches the persistent solve
+    // off for the NEXT persist_off_runs runs of this plan, not for its whole life, and the run is made again: at once on the
+    // host-buffer path, by the next synchronising call on the device-buffer path -- from the plan's own copy of the inputs, into the
+    // caller's output buffers of that run (heal_abandoned_run)
+    int persist_off_runs = 0;
+    int persist_abandoned_total = 0;        // how often that happened to this plan
+    float *last_u = nullptr, *last_v = nullptr;
+    hipStream_t last_stream = nullptr;
+    int last_mem = -1;
     int asm_fast = 0;    // AssembleParams::fast_math: the fast exact forms the device self-test has cleared for this plan's alpha
     int ntrials = 0;     // placement trials made when the plan was created, and what each candidate arena measured
     double trial_ms[8] = {0};
@@ -92,7 +102,9 @@ struct LevelCtx { const float *lev1, *lev2, *ut, *vt; float *gx1, *gy1, *gx2, *g
 
 void set_last_error(const std::string &msg);
 // Plan without the placement trials (several bands may share one device, and the trials allocate 4 arenas).
-int  plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, const octane_vof_params *p, int placement_trials);
+// band_plan: the plan is one band of a row-band solve (vof_tiled.hip): it never runs run_on_stream, so the second set of level planes the
+// one-level-ahead overlap needs (9 nc + 2 full-size planes, 5.2 GB at 10848^2) is not allocated; nor is it when OCTANE_TUNE_OVERLAP=0.
+int  plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, const octane_vof_params *p, int placement_trials, bool band_plan = false);
 // Level k up to the point where the solve starts: flow up-sampling (flips `cur`), pyramid images, gradients.
 // Everything is computed for the whole level -- bands replicate this work instead of exchanging halos for it.
 int  plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur, LevelCtx &c);

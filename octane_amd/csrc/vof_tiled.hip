@@ -351,7 +351,7 @@ static int tiled_create_impl(octane_vof_tiled **out, int nx, int ny, int nchan, 
         // placement trials only when the band has its device to itself (they allocate four arenas)
         int sharing = 0;
         for (int c = 0; c < nbands; c++) sharing += (t->dev[c] == t->dev[b]);
-        rc = plan_create_ex(&t->pl[b], nx, ny, nchan, &pb, (sharing > 1 || !allow_selfcheck) ? 1 : 8);
+        rc = plan_create_ex(&t->pl[b], nx, ny, nchan, &pb, (sharing > 1 || !allow_selfcheck) ? 1 : 8, true);
         if (rc != OCTANE_OK) break;
         if (hipSetDevice(t->dev[b]) != hipSuccess ||
             hipMalloc((void **)&t->parts[b], (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
@@ -1119,7 +1119,7 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
     m->min_band_pixels = min_band_pixels;
     std::memset(&m->ex, 0, sizeof m->ex);
     info_reset(m->info, world);
-    int rc = plan_create_ex(&m->pl, nx, ny, nchan, p, 1);
+    int rc = plan_create_ex(&m->pl, nx, ny, nchan, p, 1, true);
     if (rc != OCTANE_OK) { delete m; return rc; }
     m->device = m->pl->device;
     if (hipMalloc((void **)&m->parts, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||

@@ -242,6 +242,30 @@ def test_assembly_of_every_gnc_step_is_bit_exact(capi, oracle):
         assert np.abs(g[5]).max() > 0 and np.isfinite(g).all()
 
 
+@pytest.mark.parametrize("nc", [2, 3])
+def test_assembly_with_two_and_three_channels_is_bit_exact_in_every_gnc_step(capi, oracle, nc):
+    """Round 4: two and three channels have template instances of k_assemble of their own for the default flags
+    (Zimmer's normalisation on, no hint term; ref .cu:749-829 loops over 1 ... 3 channels alike).  With cgiters = 0 the three assemblies
+    of the level -- al1 = 1, 0.5, 0 -- see the first guess: coefficient planes and right-hand sides bit for bit the oracle's."""
+    nx, ny = 150, 97
+    a, b = synth.lattice_scene(nx, ny, seed=23, nchan=nc)
+    tu, tv = synth.true_lattice_flow(nx, ny)
+    u0 = (0.8 * tu).astype(np.float32); v0 = (0.8 * tv).astype(np.float32)
+    prm = dict(kiters=1, liters=1, cgiters=0)
+    tr_o, tr_g = {}, {}
+    oracle.flow(a, b, oracle.FlowParams(**prm), u0=u0, v0=v0, trace=tr_o)
+    pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm))
+    pl.set_trace(tr_g)
+    pl.run_host(a, b, u0, v0)
+    pl.close()
+    for gnc in range(3):
+        g = tr_g[("coef7", 0, gnc, 0)]
+        o = tr_o[("coef", 0, gnc, 0)]
+        for gi, oi, nm in zip(range(7), (0, 1, 2, 5, 6, 7, 8), ("a1", "a2", "a4", "a7", "a8", "bu", "bv")):
+            assert np.array_equal(g[gi], o[oi]), (nc, gnc, nm, int((g[gi] != o[oi]).sum()))
+        assert np.abs(g[5]).max() > 0 and np.isfinite(g).all()
+
+
 def test_runs_are_bitwise_reproducible(capi):
     """Two-stage fixed-order reductions: no float atomics, so repeated runs agree exactly
     (the CUDA reference does not: SURVEY.md 2.2, jVecXVec)."""
