@@ -59,6 +59,10 @@ void octane_vof_default_params(octane_vof_params *p);
  * Caller keeps ownership of every pointer; inputs are not modified. */
 int octane_vof_run(const float *img1, const float *img2, int nx, int ny, int nchan,
                    float *u_inout, float *v_inout, const octane_vof_params *p);
+/* The same with the first guess apart from the result.  u0 = v0 = NULL: zero first guess (what oct_optical_flow passes without
+ * -firstguess, ref src/oct_optical_flow.cc:38-48) -- and nothing is uploaded for it: two of the call's six PCIe transfers less. */
+int octane_vof_solve(const float *img1, const float *img2, int nx, int ny, int nchan, const float *u0, const float *v0,
+                     float *u_out, float *v_out, const octane_vof_params *p);
 /* octane_vof_run keeps the plan of its last call and reuses it when the next call has the same shape and parameters
  * (creating and freeing a multi-GB arena per pair costs up to 0.5 s at 10848^2).  This frees the kept plan;
  * OCTANE_VOF_CACHE=0 in the environment restores allocate-per-call, as the reference does (.cu:1268-1472). */
@@ -186,7 +190,7 @@ int octane_vof_batch_run(int npairs, const float *const *img1, const float *cons
 /* ---- one frame over several GPUs (BASELINE configs[3]: a full-disk pair as row bands) ----------------------------
  * `nbands` (1..8) row bands, band b on devices[b] (NULL: b modulo the device count; ids may repeat -- several bands
  * then share a device, which is how a one-GPU machine exercises this path).  Pyramid levels with fewer than
- * min_band_pixels pixels (0 = default, 12 Mpixel) are solved redundantly by every band; on the larger ones a band
+ * min_band_pixels pixels (0 = default, 4 Mpixel; 12 until round 3) are solved redundantly by every band; on the larger ones a band
  * owns a range of rows and the bands exchange, per PCG iteration, their reduction partials and one row of the
  * residual per inner edge (stream-ordered peer copies over xGMI; no host synchronisation inside a pyramid).
  * The iterates are those of the single-GPU solve up to the summation order of the dot products.
@@ -317,6 +321,13 @@ typedef struct octane_nav {      /* the GOESNAVVar fields oct_pix2uv_cuda.cu rea
 #define OCTANE_NAV_GEOS  0   /* GOES-R fixed grid (default)   */
 #define OCTANE_NAV_POLAR 1   /* -Polar                         */
 #define OCTANE_NAV_MERC  2   /* -Merc                          */
+/* Or into `mode`: run the build of the navigation kernel in which a * b + c is fused wherever the compiler may (float and double), as
+ * nvcc's default -fmad=true builds the reference's kernel (ref src/Makefile sets no -fmad flag; ref p2u:40-44 xi * xScale + xOffset and
+ * the projection formulas).  Without it every product and sum is rounded on its own -- the build the oracle's strict flavour and the
+ * bit-exactness tests are defined on.  The two differ in 2.3 % of the navigated shorts, by 1 cm/s (profiles/r4_pix2uv_fmad_exposure.txt);
+ * which of them a given CUDA build of the reference equals depends on that build's flags and cannot be checked here (no CUDA).
+ * OCTANE_PIX2UV_FMAD=0|1 in the environment overrides (the C++ shim oct_pix2uv_cuda has no argument for it). */
+#define OCTANE_NAV_FMAD  0x100
 /* Host buffers.  pixuv != 0 reproduces -pd (ur/vr = (short)(100*u), ur2/vr2 untouched).
  * *sector_moved is set to 1 when the x/yOffset guard (oct_pix2uv_cuda.cu:295) zeroed the outputs. */
 int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, const float *u, const float *v,

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("OCTANE_LIB") or os.path.join(_HERE, "liboctane_vof.so
 OK, E_INVALID, E_NODEVICE, E_HIP, E_TOOSMALL, E_NOMEM = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1
 NAV_GEOS, NAV_POLAR, NAV_MERC = 0, 1, 2
+NAV_FMAD = 0x100      # or into mode: the navigation kernel built with fused multiply-adds (include/octane_vof.h)
 
 # the diagnostic library (make -C octane_amd/csrc DIAG=1: stamped copies of two kernels for tools/probe_stamps.py / probe_mid_stamps.py and
 # one GPU test; never the product) and what it exports on top of EXPORTS
@@ -26,7 +27,7 @@ DIAG_EXPORTS = ("octane_vof_plan_probe_stamps", "octane_vof_mid_stamps")
 
 # every symbol include/octane_vof.h declares (outside its OCTANE_DIAG section)
 EXPORTS = (
-    "octane_vof_default_params", "octane_vof_run", "octane_vof_release_cache", "octane_vof_plan_create", "octane_vof_plan_destroy",
+    "octane_vof_default_params", "octane_vof_run", "octane_vof_solve", "octane_vof_release_cache", "octane_vof_plan_create", "octane_vof_plan_destroy",
     "octane_vof_plan_device_bytes", "octane_vof_plan_placement_trials", "octane_vof_plan_run", "octane_vof_plan_solve", "octane_vof_plan_wait", "octane_vof_plan_last_iterations",
     "octane_vof_plan_persist_state", "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_get_launch_times", "octane_vof_plan_probe", "octane_vof_tune", "octane_vof_mid_geometry", "octane_selftest_rcp", "octane_selftest_assembly_math", "octane_selftest_assembly_math_bits",
     "octane_vof_batch_run",
@@ -159,6 +160,7 @@ def lib() -> C.CDLL:
     L.octane_vof_default_params.argtypes = [C.POINTER(VofParams)]
     L.octane_vof_default_params.restype = None
     L.octane_vof_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(VofParams)]
+    L.octane_vof_solve.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(VofParams)]
     L.octane_vof_release_cache.restype = None
     L.octane_vof_plan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.POINTER(VofParams)]
     L.octane_vof_plan_destroy.argtypes = [vp]
@@ -604,6 +606,18 @@ def flow_inplace(img1, img2, u, v, params: FlowParams | None = None) -> None:
     rc = lib().octane_vof_run(_ptr(a), _ptr(b), nx, ny, nc, _ptr(u), _ptr(v), C.byref(p))
     if rc != OK:
         raise OctaneError(rc, "octane_vof_run")
+
+
+def flow_into(img1, img2, u, v, params: FlowParams | None = None) -> None:
+    """One-shot solve with the zero first guess NOT uploaded (octane_vof_solve with u0 = v0 = NULL): u / v are written only."""
+    a, b = _f32(img1), _f32(img2)
+    if a.ndim == 2:
+        a, b = a[None], b[None]
+    nc, ny, nx = a.shape
+    p = (params or FlowParams()).c()
+    rc = lib().octane_vof_solve(_ptr(a), _ptr(b), nx, ny, nc, None, None, _ptr(u), _ptr(v), C.byref(p))
+    if rc != OK:
+        raise OctaneError(rc, "octane_vof_solve")
 
 
 def release_cache() -> None:

@@ -7,10 +7,19 @@
 #include "../../include/octane_host.hpp"
 #include "../../include/octane_vof.h"
 
+// zero_guess: the caller KNOWS uarr / varr hold the zero first guess (oct_optical_flow below, without -firstguess): it is then not uploaded
+static void variational_flow(Image geo1i, Image geo2i, float *uarr, float *varr, int nx, int ny, OFFlags args, bool zero_guess);
+
 void oct_variational_optical_flow(Image geo1i, Image geo2i, float *CTH, float *uarr, float *varr,
                                   int nx, int ny, int nc, OFFlags args)
 {
-    (void)CTH; (void)nc; (void)geo2i.nchannels;
+    (void)CTH; (void)nc;         // CTH is never dereferenced (dodiscrete is hard-wired false, ref .cu:1302); nc is ignored (ref .cu:1223)
+    variational_flow(geo1i, geo2i, uarr, varr, nx, ny, args, false);
+}
+
+static void variational_flow(Image geo1i, Image geo2i, float *uarr, float *varr, int nx, int ny, OFFlags args, bool zero_guess)
+{
+    (void)geo2i.nchannels;
     octane_vof_params p;
     octane_vof_default_params(&p);
     p.alpha = args.alpha; p.lambda = args.lambda; p.lambdac = args.lambdac;
@@ -40,7 +49,8 @@ void oct_variational_optical_flow(Image geo1i, Image geo2i, float *CTH, float *u
         if (rc == OCTANE_OK) rc = octane_vof_tiled_run(t, geo1i.data, geo2i.data, uarr, varr, OCTANE_MEM_HOST);
         octane_vof_tiled_destroy(t);
     } else {
-        rc = octane_vof_run(geo1i.data, geo2i.data, nx, ny, geo1i.nchannels, uarr, varr, &p);
+        rc = octane_vof_solve(geo1i.data, geo2i.data, nx, ny, geo1i.nchannels, zero_guess ? nullptr : uarr, zero_guess ? nullptr : varr,
+                              uarr, varr, &p);
     }
     if (rc != OCTANE_OK)   // the reference ignores CUDA errors (.cu:1421,1431); a failed solve is reported here
         std::cerr << "oct_variational_optical_flow: " << octane_last_error() << " (code " << rc << ")\n";
@@ -109,7 +119,8 @@ int oct_optical_flow(GOESVar &goesData, GOESVar &goesData2, OFFlags &args)
         }
         oct_patch_match_optical_flow(goesData.data.data, goesData2.data.data, goesData.uPix, goesData.vPix, nx, ny, args);
     } else {
-        oct_variational_optical_flow(goesData.data, goesData2.data, goesData.CTHVal, goesData.uPix, goesData.vPix, nx, ny, nc, args);
+        (void)nc;
+        variational_flow(goesData.data, goesData2.data, goesData.uPix, goesData.vPix, nx, ny, args, args.dofirstguess == 0);
     }
     short *CTP = nullptr;
     if (args.doCTH == 1) {                   // ref oct_optical_flow.cc:71-88

@@ -5,7 +5,22 @@
 // compiled with -ffp-contract=off and uses no fast-math: the base pixel position is formed in
 // float (int*float+float, ref p2u:40-41), the displaced one in double (ref p2u:43-44), and
 // latitude/longitude pass through float on their way into the haversine (ref p2u:13).
+//
+// Round 4: this file is compiled TWICE.  As pix2uv_kernel.o with -ffp-contract=off (k_pix2uv, launch_pix2uv: every product and sum a
+// rounding of its own -- what the oracle's strict build and every parity test use) and as pix2uv_kernel_fmad.o with -DPIX2UV_FMAD
+// -ffp-contract=fast (k_pix2uv_fmad, launch_pix2uv_fmad: a * b + c fused wherever the compiler may, in float and in double).  The
+// reference is built by nvcc with its default -fmad=true (ref src/Makefile: no -fmad flag), which fuses the same way, so its outputs
+// are likelier the second kind's; tools/pix2uv_fmad_exposure.py counts what that is worth: 2.3 % of the navigated shorts differ by
+// 1 cm/s between the two builds of one source (profiles/r4_pix2uv_fmad_exposure.txt).  OCTANE_NAV_FMAD in `mode` (or
+// OCTANE_PIX2UV_FMAD=1 in the environment) selects the fused build.
 #include "vof_kernels.hpp"
+
+#ifdef PIX2UV_FMAD
+#define k_pix2uv k_pix2uv_fmad
+#define launch_pix2uv launch_pix2uv_fmad
+#define great_circle great_circle_fmad
+#define navigate_pixel navigate_pixel_fmad
+#endif
 
 namespace octane {
 

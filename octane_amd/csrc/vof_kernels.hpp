@@ -184,6 +184,9 @@ struct NavArgs {
 };
 void launch_pix2uv(hipStream_t s, const NavArgs &nav, double t1, double t2, const float *u, const float *v,
                    int mode, short *ur, short *vr, short *ur2, short *vr2, long n);
+// the same source compiled with fused multiply-adds, as nvcc's default -fmad=true builds the reference (pix2uv_kernel.hip)
+void launch_pix2uv_fmad(hipStream_t s, const NavArgs &nav, double t1, double t2, const float *u, const float *v,
+                        int mode, short *ur, short *vr, short *ur2, short *vr2, long n);
 
 struct NavcalArgs {
     float xScale, xOffset, yScale, yOffset, radScale, radOffset, rpol, req, H, lam0, fk1, fk2, bc1, bc2, kap1;

@@ -1125,7 +1125,18 @@ extern "C" void octane_vof_release_cache(void)
 extern "C" int octane_vof_run(const float *img1, const float *img2, int nx, int ny, int nchan,
                               float *u, float *v, const octane_vof_params *p)
 {
-    if (!p) { g_last_error = "octane_vof_run: invalid argument"; return OCTANE_E_INVALID; }
+    if (!u || !v) { g_last_error = "octane_vof_run: invalid argument"; return OCTANE_E_INVALID; }
+    return octane_vof_solve(img1, img2, nx, ny, nchan, u, v, u, v, p);
+}
+
+// The same one-shot call with the first guess apart from the result; u0 = v0 = NULL is the zero first guess of a run without
+// -firstguess (ref src/oct_optical_flow.cc:38-48), which is then not uploaded: two of the call's six PCIe transfers (3.5 of 10.5 ms at
+// 5000^2; the transfers run at the link's 57 GB/s each way and nothing of them can hide behind the solve, which needs all inputs at
+// its coarsest level and has both outputs only after its finest: profiles/r4_h2d_pitch.txt).
+extern "C" int octane_vof_solve(const float *img1, const float *img2, int nx, int ny, int nchan, const float *u0, const float *v0,
+                                float *u, float *v, const octane_vof_params *p)
+{
+    if (!p) { g_last_error = "octane_vof_solve: invalid argument"; return OCTANE_E_INVALID; }
     const char *e = getenv("OCTANE_VOF_CACHE");
     const bool use_cache = !(e && atoi(e) == 0);
     // A kept plan lives for many pairs (a time series through one host program), so it gets the placement trials a plan created through
@@ -1143,7 +1154,7 @@ extern "C" int octane_vof_run(const float *img1, const float *img2, int nx, int 
             if (rc != OCTANE_OK) { g_cache_plan = nullptr; return rc; }
             g_cache_prm = *p; g_cache_nx = nx; g_cache_ny = ny; g_cache_nc = nchan;
         }
-        const int rc = octane_vof_plan_run(g_cache_plan, img1, img2, u, v, OCTANE_MEM_HOST, nullptr);
+        const int rc = octane_vof_plan_solve(g_cache_plan, img1, img2, u0, v0, u, v, OCTANE_MEM_HOST, nullptr);
         if (rc != OCTANE_OK) { octane_vof_plan_destroy(g_cache_plan); g_cache_plan = nullptr; }   // do not keep a plan that failed
         return rc;
     }
@@ -1151,7 +1162,7 @@ extern "C" int octane_vof_run(const float *img1, const float *img2, int nx, int 
     octane_vof_plan *pl = nullptr;
     int rc = plan_create_ex(&pl, nx, ny, nchan, p, 1);
     if (rc != OCTANE_OK) return rc;
-    rc = octane_vof_plan_run(pl, img1, img2, u, v, OCTANE_MEM_HOST, nullptr);
+    rc = octane_vof_plan_solve(pl, img1, img2, u0, v0, u, v, OCTANE_MEM_HOST, nullptr);
     octane_vof_plan_destroy(pl);
     return rc;
 }
@@ -1212,6 +1223,9 @@ extern "C" int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, co
                                  int pixuv, int mode, short *ur, short *vr, short *ur2, short *vr2,
                                  float *dT, int *sector_moved, int device)
 {
+    bool fmad = (mode & OCTANE_NAV_FMAD) != 0;          // the kernel built with fused multiply-adds (pix2uv_kernel.hip)
+    mode &= ~OCTANE_NAV_FMAD;
+    if (const char *e = getenv("OCTANE_PIX2UV_FMAD")) fmad = atoi(e) != 0;
     if (!nav || !u || !v || !ur || !vr || nav->nx < 1 || nav->ny < 1 || mode < 0 || mode > 2 ||
         (pixuv == 0 && (!ur2 || !vr2))) {
         g_last_error = "octane_pix2uv_run: invalid argument";
@@ -1252,7 +1266,7 @@ extern "C" int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, co
         a.xScale = nav->xScale; a.xOffset = nav->xOffset; a.yScale = nav->yScale; a.yOffset = nav->yOffset;
         a.lat1 = nav->lat1; a.lon1 = nav->lon1; a.lon0 = nav->lon0; a.R = nav->R;
         a.minX = nav->minX; a.minY = nav->minY; a.nx = nav->nx; a.ny = nav->ny;
-        launch_pix2uv(s, a, t1, t2, du, dv, mode, dout, dout + n, dout + 2 * n, dout + 3 * n, n);
+        (fmad ? launch_pix2uv_fmad : launch_pix2uv)(s, a, t1, t2, du, dv, mode, dout, dout + n, dout + 2 * n, dout + 3 * n, n);
         if (hipGetLastError() != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMemcpyAsync(ur, dout, n * sizeof(short), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMemcpyAsync(vr, dout + n, n * sizeof(short), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }

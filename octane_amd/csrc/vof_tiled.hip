@@ -68,6 +68,7 @@ using namespace octane;
     } while (0)
 
 struct BandRows { int y0, y1; };
+constexpr long kDefaultMinBandPixels = 4L << 20;     // levels below this many pixels are solved redundantly by every band (octane_vof_tiled_create)
 
 extern "C" const char *octane_vof_transport_name(int transport)
 {
@@ -306,8 +307,12 @@ static int tiled_create_impl(octane_vof_tiled **out, int nx, int ny, int nchan, 
     octane_vof_tiled *t = new octane_vof_tiled();
     t->nx = nx; t->ny = ny; t->nc = nchan; t->nbands = nbands; t->prm = *p;
     info_reset(t->info, nbands);
-    // Below ~12 Mpixel one PCG iteration of the whole level (< 0.25 ms) is cheaper than issuing a banded one.
-    t->min_band_pixels = min_band_pixels > 0 ? (long)min_band_pixels : (12L << 20);
+    // Which levels are worth banding (round 4, measured with four virtual bands at 10848^2, profiles/r4_tiled_threshold.txt): a level's
+    // PCG iteration as bands costs the band's kernel (10.7 us + 12 ps x its pixels) + ~15 us of phase boundary, replicated it costs the
+    // whole level's kernel on EVERY device.  The 2712^2 level (7.4 Mpixel: 99 us replicated, ~48 us as four bands, ~37 us as eight)
+    // pays -- banding it lowers even the total work of four bands sharing one GPU, 692 -> 646 ms per pyramid; the 1356^2 level
+    // (1.8 Mpixel: a persistent solve of ~17 us per iteration) does not.  Until round 3 the threshold was 12 Mpixel.
+    t->min_band_pixels = min_band_pixels > 0 ? (long)min_band_pixels : kDefaultMinBandPixels;
     if (const char *e = getenv("OCTANE_TUNE_MIN_BAND_PIXELS")) t->min_band_pixels = atol(e);
     for (int b = 0; b < nbands; b++) {
         int d = devices ? devices[b] : b % ndev;
@@ -1132,7 +1137,7 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
     }
     m->arena[rank] = reinterpret_cast<char *>(m->pl->arena);
     m->parts_all[rank] = m->parts;
-    long minpix = min_band_pixels > 0 ? (long)min_band_pixels : (12L << 20);
+    long minpix = min_band_pixels > 0 ? (long)min_band_pixels : kDefaultMinBandPixels;
     if (const char *e = getenv("OCTANE_TUNE_MIN_BAND_PIXELS")) minpix = atol(e);
     m->rows.resize(m->pl->lev.size());
     for (size_t k = 0; k < m->pl->lev.size(); k++) {

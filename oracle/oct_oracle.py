@@ -195,14 +195,14 @@ def level_dims(nx: int, ny: int, factor: float):
     return lx.value, ly.value
 
 
-def pix2uv(nav: Nav, t1: float, t2: float, u: np.ndarray, v: np.ndarray, pixuv: int = 0, mode: int = 0):
-    """Returns (ur, vr, ur2, vr2, dT, sector_moved)."""
+def pix2uv(nav: Nav, t1: float, t2: float, u: np.ndarray, v: np.ndarray, pixuv: int = 0, mode: int = 0, flavour: str = "strict"):
+    """Returns (ur, vr, ur2, vr2, dT, sector_moved).  flavour "fma": the build with contracted multiply-adds."""
     u = np.ascontiguousarray(u, np.float32)
     v = np.ascontiguousarray(v, np.float32)
     n = u.size
     ur, vr, ur2, vr2 = (np.zeros(n, np.int16) for _ in range(4))
     dT = C.c_float()
-    moved = lib().oct_oracle_pix2uv(C.byref(nav), t1, t2, u.ravel(), v.ravel(), pixuv, mode, ur, vr, ur2, vr2, C.byref(dT))
+    moved = lib(flavour).oct_oracle_pix2uv(C.byref(nav), t1, t2, u.ravel(), v.ravel(), pixuv, mode, ur, vr, ur2, vr2, C.byref(dT))
     shp = u.shape
     return ur.reshape(shp), vr.reshape(shp), ur2.reshape(shp), vr2.reshape(shp), dT.value, moved
 

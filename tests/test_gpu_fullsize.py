@@ -137,7 +137,7 @@ def test_config3_quarter_scale_2712_four_bands_and_plain_match_oracle(capi, orac
     uo, vo, io, to = _oracle(oracle, a, b, prm)
     up, vp, ip, tp_s = _plain(capi, a, b, prm)
     tp = capi.TiledPlan(n, n, 1, capi.FlowParams(**prm), nbands=4, devices=capi.band_devices(4),
-                        min_band_pixels=(12 << 20) // 16)
+                        min_band_pixels=(12 << 20) // 16)      # (round 3's threshold, scaled: two banded levels)
     try:
         nbanded = tp.banded_levels
         ut, vt = tp.run_host(a, b)

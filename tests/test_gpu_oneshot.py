@@ -96,3 +96,17 @@ def test_two_lanes_on_their_own_streams(capi):
     assert float(u0[0, 0]) == 1.5                       # the first guess is not written
     for p in plans:
         p.close()
+
+
+def test_one_shot_call_without_a_first_guess_equals_the_call_with_zeros(capi):
+    """octane_vof_solve(u0 = v0 = NULL) -- what the shim of oct_optical_flow() calls when there is no -firstguess (ref
+    src/oct_optical_flow.cc:38-48 zero-fills uPix / vPix) -- does not upload the zeros; the flow is the in-out call's bit for bit, and the
+    output buffers' previous contents do not matter."""
+    a, b = synth.lattice_scene(260, 190, seed=8)
+    prm = capi.FlowParams(kiters=3, liters=2, cgiters=12)
+    want = capi.flow(a, b, prm)
+    u = np.full((190, 260), np.nan, np.float32)
+    v = np.full((190, 260), 7.0, np.float32)
+    capi.flow_into(a, b, u, v, prm)
+    assert np.array_equal(u, want[0]) and np.array_equal(v, want[1])
+    capi.release_cache()

@@ -91,3 +91,34 @@ def test_flow_then_navigation_end_to_end(capi, oracle):
     a, b = synth.lattice_scene(nx, ny, seed=12)
     u, v = capi.flow(a, b, capi.FlowParams(kiters=3))
     _compare(capi, oracle, conus_nav(capi.Nav, nx, ny), u, v, capi.NAV_GEOS)
+
+
+def test_fused_multiply_add_build_of_the_kernel_and_what_it_is_worth(capi, oracle):
+    """VERDICT r3 item 6.  The reference's kernel is built by nvcc with its default -fmad=true (ref src/Makefile has no -fmad flag), which
+    fuses a * b + c in float (xi * xScale + xOffset, ref p2u:40-41) and in double; the bit-exactness above is defined on the strict
+    build.  The library carries the kernel in both builds (mode | NAV_FMAD selects the fused one).  Measured here: the strict kernel
+    equals the strict oracle (0 mismatches); the fused kernel is far closer to the oracle's FMA-contracted build (gcc chooses the
+    same products to fuse in almost every place) than to the strict one; and the two builds differ in a few per cent of the shorts by
+    1 cm/s -- the exposure of the bit-exactness claim to the reference's compiler flags (profiles/r4_pix2uv_fmad_exposure.txt)."""
+    nx, ny = 500, 300
+    rng = np.random.RandomState(0)
+    u = (rng.randn(ny, nx) * 3).astype(np.float32)
+    v = (rng.randn(ny, nx) * 3).astype(np.float32)
+    nav = conus_nav(capi.Nav, nx, ny, 100, 50)
+    nav_o = _same(nav, oracle.Nav())
+    strict_g = capi.pix2uv(nav, 0.0, 300.0, u, v, 0, capi.NAV_GEOS)
+    fused_g = capi.pix2uv(nav, 0.0, 300.0, u, v, 0, capi.NAV_GEOS | capi.NAV_FMAD)
+    strict_o = oracle.pix2uv(nav_o, 0.0, 300.0, u, v, 0, 0)
+    fused_o = oracle.pix2uv(nav_o, 0.0, 300.0, u, v, 0, 0, flavour="fma")
+
+    def diff(a, b):
+        return int((a[0] != b[0]).sum() + (a[1] != b[1]).sum())
+    n = 2 * nx * ny
+    d_ss, d_ff, d_fs, d_builds = diff(strict_g, strict_o), diff(fused_g, fused_o), diff(fused_g, strict_o), diff(fused_g, strict_g)
+    print(f"PIX2UV-FMAD of {n} shorts: strict kernel vs strict oracle {d_ss}; fused kernel vs FMA oracle {d_ff}; fused kernel vs strict oracle {d_fs}; "
+          f"fused vs strict kernel {d_builds} ({d_builds / n:.2%}); max |difference| {np.abs(fused_g[0].astype(int) - strict_g[0]).max()} cm/s")
+    assert d_ss == 0
+    assert 0 < d_builds < 0.06 * n                    # the two builds of one source differ, by a few per cent
+    assert np.abs(fused_g[0].astype(int) - strict_g[0]).max() <= 1 and np.abs(fused_g[1].astype(int) - strict_g[1]).max() <= 1
+    assert d_ff <= d_fs / 4                           # the fused kernel follows the contracted oracle, not the strict one
+    assert np.array_equal(fused_g[2], strict_g[2]) and np.array_equal(fused_g[3], strict_g[3])     # (short)(100 * uPix): no product-sum

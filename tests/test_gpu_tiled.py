@@ -101,8 +101,8 @@ def test_wide_frame_many_tiles_per_band(capi):
 
 
 def test_small_levels_stay_replicated_by_default_threshold(capi):
-    """With the default threshold (12 Mpixel) nothing at 2000 x 1500 is banded: every band solves every level and
-    band 0's result is the plain plan's, bit for bit."""
+    """With the default threshold (4 Mpixel since round 4, 12 before) nothing at 2000 x 1500 is banded: every band solves every level
+    and band 0's result is the plain plan's, bit for bit."""
     nx, ny = 2000, 1500
     a, b = synth.lattice_scene(nx, ny, seed=5)
     prm = dict(kiters=3, liters=1, cgiters=6)
@@ -203,7 +203,7 @@ def test_config3_full_disk_10848_four_bands_equals_plain_plan(capi):
     assert ip == 8 * 3 * 3 * 30
     tp = capi.TiledPlan(n, n, 1, prm, nbands=4, devices=capi.band_devices(4))
     nbanded = tp.banded_levels
-    assert nbanded == 2                                   # 10848^2 and 5424^2 are above the default 12 Mpixel threshold
+    assert nbanded == 3                                   # 10848^2, 5424^2 and 2712^2 are above the default 4 Mpixel threshold (round 4; 12 before)
     tp.load_device(a.data_ptr(), b.data_ptr(), z.data_ptr(), z.data_ptr())
     tp.solve()
     tp.fetch_device(ou.data_ptr(), ov.data_ptr())

@@ -185,3 +185,34 @@ def test_a_dead_rank_does_not_leave_the_survivor_spinning():
     print(out0)
     assert res and procs[0].returncode == 0, out0
     assert waited < 25.0, f"the survivor needed {waited:.1f} s after the kill (time-out 4 s)"
+
+
+def test_rccl_exchange_library_single_rank():
+    """liboctane_xchg_rccl.so (octane_amd/csrc/exchange_rccl.cpp): the collective transport's callbacks on RCCL itself, for C++ host
+    programs.  Two ranks cannot share this box's one GPU (RCCL refuses: profiles/r2_rccl_same_device.txt), so what can be checked here is
+    what one rank can do: the library loads, RCCL initialises a communicator on the device, the callbacks run (an all-gather that has
+    nobody else to hear from, an empty batch of transfers) and everything is torn down.  The protocol the callbacks carry is tested
+    through torch.distributed above and on CPU (tests/test_exchange_gloo.py)."""
+    import ctypes as C
+    from octane_amd import capi
+    path = os.path.join(ROOT, "octane_amd", "liboctane_xchg_rccl.so")
+    if not os.path.exists(path):
+        pytest.skip("liboctane_xchg_rccl.so has not been built (no RCCL?)")
+    capi.lib()
+    X = C.CDLL(path)
+    ident = C.create_string_buffer(128)
+    assert X.octane_rccl_unique_id(ident) == 0
+    ex = capi.Exchange()
+    X.octane_rccl_exchange_create.argtypes = [C.POINTER(capi.Exchange), C.c_void_p, C.c_int, C.c_int, C.c_int]
+    assert X.octane_rccl_exchange_create(C.byref(ex), ident, 0, 1, 0) == 0
+    try:
+        assert ex.name.decode().startswith("RCCL ")
+        import torch
+        buf = torch.arange(64, dtype=torch.float32, device="cuda")
+        recv = (C.c_void_p * 1)(None)
+        assert ex.all_gather(ex.user, buf.data_ptr(), recv, buf.numel() * 4) == 0
+        assert ex.sendrecv(ex.user, 0, None) == 0
+        assert float(buf.sum()) == 2016.0
+    finally:
+        X.octane_rccl_exchange_destroy.argtypes = [C.POINTER(capi.Exchange)]
+        X.octane_rccl_exchange_destroy(C.byref(ex))
