@@ -148,8 +148,8 @@ def test_device_resident_inputs_and_repeated_solves(capi):
 
 def test_full_disk_quarter_scale_four_bands(capi):
     """5424 x 5424 (the second level of a 10848^2 full-disk pyramid; 29 Mpixel, above the default banding
-    threshold), four bands, default threshold: the finest level is banded, the 2712^2 one replicated.  Checked
-    against the plain plan on the same inputs."""
+    threshold), four bands, default threshold (4 Mpixel since round 4): the finest level and the 2712^2 one (7.4 Mpixel: bands of
+    1.8 Mpixel on the stored-q kernel) are banded, the rest replicated.  Checked against the plain plan on the same inputs."""
     import torch
     n = 5424
     dev = torch.device("cuda:0")
@@ -164,7 +164,7 @@ def test_full_disk_quarter_scale_four_bands(capi):
     up, vp, ip = ou.cpu().numpy(), ov.cpu().numpy(), pl.last_iterations()
     pl.close()
     tp = capi.TiledPlan(n, n, 1, prm, nbands=4, devices=capi.band_devices(4))
-    assert tp.banded_levels == 1
+    assert tp.banded_levels == 2
     banded, y0, y1 = tp.band_rows(5, 2)
     assert banded and (y0, y1) == (2720, 4064)
     tp.load_device(a.data_ptr(), b.data_ptr(), z.data_ptr(), z.data_ptr())
