@@ -50,6 +50,13 @@
                                         "v"(*(const f4v *)r3u[slot]), "v"(*(const f4v *)r3v[slot]))
 #define Q_STR2(x) #x
 #define Q_STR(x) Q_STR2(x)
+#ifndef Q_LASTFOLD
+#define Q_LASTFOLD 0    // EXPERIMENT (round 4; tools/build_variants.sh "lastfold:-DQ_LASTFOLD=1 ..."): the last workgroup to finish launch k
+                        // folds the 7 x gridDim.x partial sums -- same order as the fold at the head of a launch, same bits -- and publishes seven doubles
+                        // in the last slot of each kind; launch k + 1 loads those instead of folding 3584 values per workgroup.  Whole levels only.
+                        // Arrival is counted in the `pad` word of the state slot this launch only reads (the next launch rewrites that slot: pad = 0).
+                        // Measured: DESIGN 8.  Off in the product.
+#endif
 #ifndef Q_ROT
 #define Q_ROT 1         // rotate the tile columns by the round number when the column count divides the grid
 #endif
@@ -263,6 +270,10 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     } else {
         double t[kPartKinds];
         if (Q_ABL & 32) { t[0] = 4.; t[1] = 4.; t[2] = 1.; t[3] = 1.; t[4] = 1.; t[5] = 1.; t[6] = 1.; }      // (ablation: no fold)
+        else if (Q_LASTFOLD && !BANDED) {
+#pragma unroll
+            for (int j = 0; j < kPartKinds; j++) t[j] = L.band_parts[0][pin_off + j * kMaxParts + (kMaxParts - 1)];    // published by the previous launch's last workgroup
+        }
         else fold_band_partials_multi_256<kPartKinds>(L.band_parts, pin_off, kMaxParts, nparts_prev, L.nbands, s_red, t);
         const double rzd = t[0], rrd = t[1], pq = t[2], qz = t[3], qmq = t[4], rq = t[5], qq = t[6];
         alpha = prev.rz / (float)pq;                 // ref .cu:1169
@@ -445,6 +456,33 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     const double accs[kPartKinds] = {acc_rz, acc_rr, acc_pq, acc_qz, acc_qmq, acc_rq, acc_qq};
     double tot[kPartKinds];
     block_sum_multi_256<kPartKinds>(accs, s_red, tot);
+    if (Q_LASTFOLD && !BANDED) {
+        // every workgroup: partials write-through (sc1), drained, then one add to the arrival counter; whoever's add came last folds
+        __shared__ int s_last;
+        if (tid == 0) {
+#pragma unroll
+            for (int j = 0; j < kPartKinds; j++) __hip_atomic_store(&own_blk[j * kMaxParts + blockIdx.x], tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int old = __hip_atomic_fetch_add(&L.st[k & 1].pad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_last) {            // uniform
+            double v7[kPartKinds], out7[kPartKinds];
+#pragma unroll
+            for (int j = 0; j < kPartKinds; j++) v7[j] = 0.;
+            for (int i = tid; i < (int)gridDim.x; i += 256) {
+#pragma unroll
+                for (int j = 0; j < kPartKinds; j++) v7[j] += __hip_atomic_load(&own_blk[j * kMaxParts + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            block_sum_multi_256<kPartKinds>(v7, s_red, out7);
+            if (tid == 0) {
+#pragma unroll
+                for (int j = 0; j < kPartKinds; j++) own_blk[j * kMaxParts + (kMaxParts - 1)] = out7[j];
+            }
+        }
+        return;
+    }
     if (tid == 0) {
 #pragma unroll
         for (int j = 0; j < kPartKinds; j++) own_blk[j * kMaxParts + blockIdx.x] = tot[j];
