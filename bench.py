@@ -675,9 +675,17 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             tk = "k_pcg_fused" if fused else dom          # the summariser files every fused instance under one name
             if tj.get(tk, {}).get("size") == n and tj[tk].get("kernel", dom) == dom:
-                traffic = tj[tk]["read_bytes"] + tj[tk]["write_bytes"]
-                traffic_source = "profiles/traffic.json @ %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this " \
-                                 "kernel; NOT measured in this run)" % tj.get("commit", tj[tk].get("commit", "unknown commit"))
+                # the counters describe a kernel TEXT: if the kernel's sources have changed since they were collected the figure is stale
+                # and is not reported ("goes stale silently the next time the kernel text changes")
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from summarize_rocprof import kernel_source_sha1
+                same_text = tj.get("kernel_source_sha1") == kernel_source_sha1()
+                if same_text:
+                    traffic = tj[tk]["read_bytes"] + tj[tk]["write_bytes"]
+                traffic_source = ("profiles/traffic.json @ %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this kernel, whose "
+                                  "source text is unchanged since; NOT measured in this run)" % tj.get("commit", "unknown commit")) if same_text else \
+                                 ("profiles/traffic.json @ %s is STALE: the kernel's sources have changed since those counter passes; not reported"
+                                  % tj.get("commit", "unknown commit"))
         except (OSError, ValueError):
             pass
         # the four kinds of finest-level launch, each priced on its own bytes (q-recomputing kernel; launch k of a solve: k = 0 forms no

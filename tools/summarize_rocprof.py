@@ -96,9 +96,22 @@ def pmc_section(d, size, kiters, per_level, two_pass_levels, qform=False, qname=
             traffic["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or os.environ.get("OCTANE_COMMIT", "unknown")
         except OSError:
             traffic["commit"] = os.environ.get("OCTANE_COMMIT", "unknown")
+        # the text of the dominant kernel these counters were measured on: bench.py reports the traffic only while the text is the same
+        traffic["kernel_source_sha1"] = kernel_source_sha1()
         with open(os.path.join(os.path.dirname(os.path.abspath(sys.argv[2])), "traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
     return out
+
+
+def kernel_source_sha1():
+    """sha1 over the sources of the finest-level PCG kernel (what bench.py's roofline block is about)."""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "octane_amd", "csrc")
+    h = hashlib.sha1()
+    for name in ("pcg_fused_q_dma.hip", "pcg_fused_q_phase1.inc", "pcg_fused_q_phase2.inc", "device_util.hpp", "vof_kernels.hpp"):
+        with open(os.path.join(root, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def main():
