@@ -540,6 +540,8 @@ def main():
                          "configs[3], one --size frame as row bands: --bands bands driven by a single process, or -- "
                          "under torchrun -- one band per rank")
     ap.add_argument("--bands", type=int, default=4, help="row bands of the tiled workload")
+    ap.add_argument("--nchan", type=int, default=1, choices=[1, 2, 3], help="pair workload only: channels of the synthetic pair (the reference's loop "
+                    "handles 1 ... 3 alike, ref .cu:749-829; BASELINE's configurations are single-channel: not the headline with 2 or 3)")
     ap.add_argument("--lanes", type=int, default=1, help="pair workload only: this many pairs in flight per GPU, each on its own plan, "
                     "stream and host thread (a step is then one pair per lane); 1 = the headline configuration")
     ap.add_argument("--cpu-sample", type=int, default=0, help="0 (default): the CPU baseline is the workload's own frame and pyramid with one "
@@ -598,10 +600,12 @@ def main():
     prm = capi.FlowParams(kiters=args.kiters, liters=args.liters, cgiters=args.cgiters, device=local)
     if args.lanes > 1:
         return pair_lanes(args, capi, shard, synth, torch, dist, world, rank, dev, n, prm)
-    a, b = synth.lattice_scene(n, n, seed=20240613 + 2 + rank, device=dev)
+    a, b = synth.lattice_scene(n, n, seed=20240613 + 2 + rank, nchan=args.nchan, device=dev)
     u = torch.zeros(n, n, device=dev)
     v = torch.zeros(n, n, device=dev)
-    plan = capi.Plan(n, n, 1, prm)
+    plan = capi.Plan(n, n, args.nchan, prm)
+    if args.nchan != 1:          # the host-buffer, secondary and CPU legs are defined on the single-channel configurations
+        args.no_transfers = args.no_secondary = args.no_cpu_baseline = True
     tr = sorted(t for t in plan.placement_trials() if t > 0)
     trials_ms = {"n": len(tr), "min_ms": round(tr[0], 4), "median_ms": round(tr[len(tr) // 2], 4), "max_ms": round(tr[-1], 4),
                  "what": "ms per launch of the trial PCG iterations on each candidate arena (stop test held open, varying weights, x work "
@@ -805,8 +809,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
-               "config": {"workload": f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan=1 "
-                                      f"alpha=5 lambda=1 ({run_name(n, args.kiters, args.liters, args.cgiters)}), "
+               "config": {"workload": f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan={args.nchan} "
+                                      f"alpha=5 lambda=1 ({run_name(n, args.kiters, args.liters, args.cgiters) if args.nchan == 1 else 'R1-shaped, NOT a BASELINE configuration: ' + str(args.nchan) + ' channels'}), "
                                       f"{iters} PCG iterations per pyramid (expected {expect}), one pair per GPU",
                           "sharding": "independent pairs, no data-path collective"},
                # the whole call on host buffers (H2D + all levels + D2H): SURVEY 8d's primary metric; `value` above is the
