@@ -9,7 +9,8 @@ point-to-point transfers, on DEVICE memory of the calling rank.  This module imp
 * backend ``nccl`` (= RCCL on ROCm; ranks on distinct GPUs of one node, the bytes travel over xGMI): the device pointers are
   aliased as torch tensors (``__cuda_array_interface__``, no copy) and go to ``dist.all_gather`` / ``dist.batch_isend_irecv``;
 * backend ``gloo`` (or any backend without GPU point-to-point; also the only way several ranks can share ONE GPU, which RCCL
-  refuses, profiles/r2_rccl_same_device.txt): the same calls on pinned host staging copies.
+  refuses, profiles/r2_rccl_same_device.txt): the same transfers on host staging copies (the all-gather as point-to-point
+  transfers: gloo's own all_gather needs 226 ms per call on the GPU boxes of this pool, profiles/r4_exchange_costs.txt).
 
 Either way the bytes that arrive are the bytes that were sent, the kernels and their order are the in-place transport's, every rank
 folds the partial sums of all ranks in the same order: the flow is the copy transport's bit for bit
