@@ -21,7 +21,7 @@
 #include <cstdio>
 #include <cstring>
 
-#include "../../include/octane_vof.h"
+#include "../../include/octane_xchg_rccl.h"
 
 namespace {
 struct RcclExchange {
@@ -67,7 +67,7 @@ int cb_sendrecv(void *user, int n, const octane_vof_xfer *ops)
 
 extern "C" {
 
-#define OCTANE_RCCL_ID_BYTES NCCL_UNIQUE_ID_BYTES      /* 128 */
+static_assert(OCTANE_RCCL_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "OCTANE_RCCL_ID_BYTES must be RCCL's unique-id size");
 
 // rank 0: 128 bytes for every rank's octane_rccl_exchange_create
 int octane_rccl_unique_id(void *out128)

@@ -29,6 +29,24 @@ def test_library_exports_every_declared_symbol(capi):
     assert sorted(capi.EXPORTS) == declared
 
 
+def test_rccl_exchange_library_exports_what_its_header_declares(capi):
+    """include/octane_xchg_rccl.h <-> liboctane_xchg_rccl.so (optional: built where RCCL is installed), and the flow library itself links
+    no collective library (the collective transport reaches it through callbacks only).  No compute: loads and symbol look-ups."""
+    import subprocess
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "octane_xchg_rccl.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(octane_rccl_[a-z0-9_]+)\s*\(", text)))
+    assert declared == ["octane_rccl_exchange_create", "octane_rccl_exchange_destroy", "octane_rccl_unique_id"]
+    needed = subprocess.run(["readelf", "-d", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower() and "nccl" not in needed.lower()
+    path = os.path.join(ROOT, "octane_amd", "liboctane_xchg_rccl.so")
+    if not os.path.exists(path):
+        pytest.skip("liboctane_xchg_rccl.so has not been built (no RCCL on this machine)")
+    capi.lib()
+    X = C.CDLL(path)
+    for name in declared:
+        assert hasattr(X, name), name
+
+
 def test_product_library_carries_no_diagnostics(capi):
     """the stamped diagnostic copies of two kernels, their exports and their tune keys live in a library of their
     own (liboctane_vof_diag.so, `make DIAG=1`); the product library has none of them -- no symbol, no kernel, no switch."""
