@@ -765,7 +765,11 @@ def main():
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary and (args.kiters, args.liters, args.cgiters) == (8, 3, 30):
         plan.close()
-        secondary = secondary_runs(args, capi, torch, a, b, u, v, n, local)
+        try:        # the headline line must not be lost to a failure of a side leg: it is reported in its place
+            secondary = secondary_runs(args, capi, torch, a, b, u, v, n, local)
+        except (Exception, SystemExit) as e:
+            secondary = {"error": f"{type(e).__name__}: {e}"}
+            print(f"bench.py: the secondary runs failed: {secondary['error']}", file=sys.stderr)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
