@@ -239,7 +239,8 @@ static int tiled_selfcheck(octane_vof_tiled *t)
                 t->transport = e.second.transport; t->no_dma = e.second.no_dma;
                 const int nd = t->info.ndevices, pk = t->info.peer_ok;
                 t->info = e.second.info; t->info.ndevices = nd; t->info.peer_ok = pk; t->info.nbands = nb;
-                return t->info.selfcheck < 0 ? OCTANE_E_HIP : OCTANE_OK;
+                if (t->info.selfcheck < 0) { set_last_error("octane_vof_tiled_create: the first-contact self-check failed under every transport on these devices (earlier in this process)"); return OCTANE_E_HIP; }
+                return OCTANE_OK;
             }
     }
     int w, h;
