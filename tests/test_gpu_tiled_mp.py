@@ -83,6 +83,21 @@ def test_collective_transport_over_torch_distributed_gloo_equals_the_copy_transp
     assert crc_coll == crc_copy
 
 
+def test_collective_transport_with_bands_on_the_q_recomputing_kernel():
+    """Bands of 2 Mpixel run the q-recomputing kernel, which wants other rows of its neighbours than the stored-q kernel: p on TWO rows
+    beyond each edge, r on one, and wy of the row above the upper ring row after every assembly (exchange_rows' four-plane batch and the
+    one-sided wy transfer).  Collective against copy, bit for bit; both within 2e-5 of the plain plan with equal iteration counts."""
+    args = (2048, 2112, 1, 1, 6, 1)
+    codes, outs = _run(2, args, extra_env={"OCTANE_TILED_TRANSPORT": "copy"})
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    crc_copy, _ = _result(outs[0])
+    codes, outs = _run(2, args, extra_env={"OCTANE_TILED_TRANSPORT": "collective", "OCTANE_TEST_EXCHANGE": "1"})
+    assert all(c == 0 for c in codes), "\n".join(outs)
+    crc_coll, info = _result(outs[0])
+    assert info["transport_used"] == "collective" and info["exchange_calls"]["sendrecv"] > 0
+    assert crc_coll == crc_copy
+
+
 def test_collective_transport_three_ranks_with_hint():
     """Three ranks (a middle band with two neighbours), first-guess hint term, the collective transport chosen by force."""
     codes, outs = _run(3, (300, 420, 3, 1, 10, 1), extra_env={"OCTANE_TILED_TRANSPORT": "collective", "OCTANE_TEST_EXCHANGE": "1"})
