@@ -231,3 +231,15 @@ def test_rccl_exchange_library_single_rank():
     finally:
         X.octane_rccl_exchange_destroy.argtypes = [C.POINTER(capi.Exchange)]
         X.octane_rccl_exchange_destroy(C.byref(ex))
+
+
+def test_torch_exchange_on_the_nccl_backend_single_rank():
+    """octane_amd/exchange.py in the mode a multi-GPU node would run it in: backend nccl (= RCCL), device buffers aliased as tensors, no
+    host staging.  RCCL wants one rank per GPU, so this box can give it one rank: process-group set-up on RCCL, the aliasing of memory
+    torch did not allocate, an all-gather through RCCL on it and an empty batch of transfers -- everything but a second device."""
+    port = _free_port()
+    env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_exchange_worker.py")], env=env, capture_output=True, text=True, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("NCCL_EXCHANGE_RESULT")]
+    assert r.returncode == 0 and line and "ok=True" in line[0], r.stdout[-2000:] + r.stderr[-2000:]
+    assert "torch.distributed/nccl (device buffers)" in line[0]
