@@ -782,6 +782,13 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
     // solve of level k waits for the event of its images, the side stream waits for the solve that last read the set it overwrites.
     const bool overlap = pl->use_overlap && pl->has_bset && !prof && !pl->trace && pl->side_stream && nlev > 1 && !pl->use_graph;
     LevelCtx next_c;
+    // An early return with an error must not leave work of this run on the side stream behind it: whoever uses the plan
+    // next -- its destruction, a re-solve after an abandoned persistent solve -- would race that work.  The normal end needs no join:
+    // every side-stream piece is waited for by the event of the level that consumes it.
+    struct SideJoin {
+        hipStream_t side; bool armed;
+        ~SideJoin() { if (armed && side) (void)hipStreamSynchronize(side); }
+    } side_join{pl->side_stream, overlap};
     if (overlap) {
         hipStream_t side = pl->side_stream;
         HIP_TRY(hipEventRecord(pl->ev_fork, s));                 // the inputs are in place (and the previous run on this stream is over)
@@ -870,6 +877,7 @@ static int run_on_stream(octane_vof_plan *pl, hipStream_t s)
     }
     // the result lives in U[cur], V[cur]; remember which for the copy-out
     pl->prof.finest_pixels = (long long)pl->nx * pl->ny;
+    side_join.armed = false;
     return cur;   // >= 0
 }
 
