@@ -216,7 +216,17 @@ void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpi
 // straight into r (r0 = b because x0 = 0).  It also emits the block partials of b.b and
 // b.(M^-1 b) and resets the solve's state, so the first PCG pass needs no separate init.
 // ---------------------------------------------------------------------------------------
-constexpr int kAsmTX = 64, kAsmTY = 4;
+#ifndef ASM_ROWS
+#define ASM_ROWS 1      // EXPERIMENT (round 4): with R > 1 a thread of k_assemble marches through R consecutive rows -- the 3 x 3
+                        // window of u, v rolls upward in registers (six loads per row instead of eighteen) and psi'_s of the northern edge of row j IS
+                        // psi'_s of the southern edge of row j + 1, the same float, computed once (1 + 3 R instead of 4 R evaluations).  Bit-identical
+                        // coefficient planes (the parity suite passes with R = 4).  Measured, us per launch at 5000^2 / 2500^2 / 1250^2 (two runs each,
+                        // profiles/r4_time_assembly.txt): R = 1 495-497 / 139 / 37.2; 4: 496-501 / 140-141 / 38.1; 6: 501-504 / 141-143 / 39.4;
+                        // 8: 469-471 / 139 / 40.4-41.0; 12: 558-561 / 156 / 46; 16: 579-583 / 162-166 / 47 -- a fifth fewer psi' and two thirds fewer u, v
+                        // loads buy nothing (the kernel is not as VALU-bound as its instruction count suggests; beyond 8 rows the registers cost
+                        // occupancy), and the one gain (8 rows at 5000^2, -5 %) is a loss on every smaller level.  1 = the form of rounds 1-3, the product.
+#endif
+constexpr int kAsmTX = 64, kAsmRows = ASM_ROWS, kAsmTY = 4 * kAsmRows;
 
 // psi'_s (ref .cu:73-80): (float)(1. / (double)y) with y = sqrtf(...) a float is the correctly rounded float reciprocal of y (see
 // jacobi_inv in device_util.hpp: double rounding is innocuous for a quotient of floats), which rcp_exact gives in three instructions
@@ -291,20 +301,40 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
     double acc_rr = 0., acc_rz = 0.;
 
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int ii = (t % tiles_x) * kAsmTX + lx;
-        const int jj = L.ya0 + (t / tiles_x) * kAsmTY + ly;
-        if (ii >= w || jj >= L.ya1) continue;
-        // mirrored neighbour coordinates (ref .cu:629-652)
-        const int xe = (ii == w - 1) ? ii - 1 : ii + 1;
-        const int xw = (ii == 0) ? ii + 1 : ii - 1;
+      const int ii = (t % tiles_x) * kAsmTX + lx;
+      const int jj0 = L.ya0 + (t / tiles_x) * kAsmTY + ly * kAsmRows;
+      if (ii >= w || jj0 >= L.ya1) continue;
+      // mirrored neighbour columns (ref .cu:629-652)
+      const int xe = (ii == w - 1) ? ii - 1 : ii + 1;
+      const int xw = (ii == 0) ? ii + 1 : ii - 1;
+      const float *U = L.u, *V = L.v;
+      // The thread marches through kAsmRows consecutive rows.  Its 3 x 3 windows of u and v roll with it: the centre row becomes the
+      // southern one, the northern the centre, and only the new northern row is loaded (the frame's last row mirrors: its "north" is
+      // the row below it, which the window already holds).  And the north edge's psi'_s of one row is the south edge's of the next:
+      // Un(i, j) and Us(i, j + 1) are the same four squares added in the same order (the inner sums commute), see DESIGN 8.
+      float use = 0.f, us = 0.f, usw = 0.f, ue = 0.f, uc = 0.f, uw = 0.f, une = 0.f, un = 0.f, unw = 0.f;
+      float vse = 0.f, vs = 0.f, vsw = 0.f, ve = 0.f, vc = 0.f, vw = 0.f, vne = 0.f, vn = 0.f, vnw = 0.f;
+      float ps_south = 0.f;
+#pragma unroll
+      for (int r = 0; r < kAsmRows; r++) {
+        const int jj = jj0 + r;
+        if (jj >= L.ya1) break;
         const int yn = (jj == h - 1) ? jj - 1 : jj + 1;
         const int ys = (jj == 0) ? jj + 1 : jj - 1;
         const size_t rc = (size_t)jj * pitch, rn = (size_t)yn * pitch, rs = (size_t)ys * pitch;
-        const float *U = L.u, *V = L.v;
-        float ue = U[rc + xe], uc = U[rc + ii], une = U[rn + xe], use = U[rs + xe], un = U[rn + ii], us = U[rs + ii];
-        float unw = U[rn + xw], uw = U[rc + xw], usw = U[rs + xw];
-        float ve = V[rc + xe], vc = V[rc + ii], vne = V[rn + xe], vse = V[rs + xe], vn = V[rn + ii], vs = V[rs + ii];
-        float vnw = V[rn + xw], vw = V[rc + xw], vsw = V[rs + xw];
+        if (r == 0) {
+            ue = U[rc + xe]; uc = U[rc + ii]; uw = U[rc + xw]; use = U[rs + xe]; us = U[rs + ii]; usw = U[rs + xw];
+            ve = V[rc + xe]; vc = V[rc + ii]; vw = V[rc + xw]; vse = V[rs + xe]; vs = V[rs + ii]; vsw = V[rs + xw];
+        } else {            // jj >= 1 here, so the southern row is row jj - 1: the previous centre
+            use = ue; us = uc; usw = uw; ue = une; uc = un; uw = unw;
+            vse = ve; vs = vc; vsw = vw; ve = vne; vc = vn; vw = vnw;
+        }
+        if (r > 0 && jj == h - 1) {       // mirrored north = row jj - 1 = the southern row of the window
+            une = use; un = us; unw = usw; vne = vse; vn = vs; vnw = vsw;
+        } else {
+            une = U[rn + xe]; un = U[rn + ii]; unw = U[rn + xw];
+            vne = V[rn + xe]; vn = V[rn + ii]; vnw = V[rn + xw];
+        }
 
         float Ue = sq(ue - uc) + sq((float)(0.25 * (double)((une - use) + (un - us))))
                  + sq(ve - vc) + sq((float)(0.25 * (double)((vne - vse) + (vn - vs))));
@@ -320,7 +350,9 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
         // the quadratic ones -- five fp64 divisions by alpha -- at al1 == 0.  Uniform branches.
         float ps1 = 0.f, ps2 = 0.f, ps3 = 0.f, ps4 = 0.f, pstot = 0.f, snu = 0.f, snv = 0.f;
         if (!quad_only) {
-            ps1 = psi_smooth(Uw); ps2 = psi_smooth(Us); ps3 = psi_smooth(Ue); ps4 = psi_smooth(Un);
+            ps1 = psi_smooth(Uw); ps3 = psi_smooth(Ue); ps4 = psi_smooth(Un);
+            ps2 = (r == 0) ? psi_smooth(Us) : ps_south;      // = the previous row's ps4, bit for bit
+            ps_south = ps4;
             pstot = ps1 + ps2 + ps3 + ps4;
             snu = ps1 * uw + ps2 * us + ps3 * ue + ps4 * un;
             snv = ps1 * vw + ps2 * vs + ps3 * ve + ps4 * vn;
@@ -445,6 +477,7 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
             acc_rr += (double)(bu * bu) + (double)(bv * bv);
             acc_rz += (double)(bu * zu) + (double)(bv * zv);
         }
+      }
     }
     double tot_rr = block_sum_256(acc_rr, s_red);
     double tot_rz = block_sum_256(acc_rz, s_red);
