@@ -226,7 +226,11 @@ void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpi
                         // loads buy nothing (the kernel is not as VALU-bound as its instruction count suggests; beyond 8 rows the registers cost
                         // occupancy), and the one gain (8 rows at 5000^2, -5 %) is a loss on every smaller level.  1 = the form of rounds 1-3, the product.
 #endif
-constexpr int kAsmTX = 64, kAsmRows = ASM_ROWS, kAsmTY = 4 * kAsmRows;
+#ifndef ASM_WAVES
+#define ASM_WAVES 4     // waves (= rows of 64 pixels marched by one wave each) per workgroup of k_assemble: 4 = 256 threads, a 64 x 4 tile (rounds 1-3);
+                        // 8 / 16 = taller tiles, fewer halo rows fetched per tile (EXPERIMENT, round 4: tools/time_assembly.py)
+#endif
+constexpr int kAsmTX = 64, kAsmRows = ASM_ROWS, kAsmWaves = ASM_WAVES, kAsmThreads = 64 * kAsmWaves, kAsmTY = kAsmWaves * kAsmRows;
 
 // psi'_s (ref .cu:73-80): (float)(1. / (double)y) with y = sqrtf(...) a float is the correctly rounded float reciprocal of y (see
 // jacobi_inv in device_util.hpp: double rounding is innocuous for a quotient of floats), which rcp_exact gives in three instructions
@@ -281,9 +285,9 @@ __device__ __forceinline__ float sq(float x) { return x * x; }
 // (quadratic terms only), 1 the blend, 2 al1 == 0 (robust terms only), -1 decided at run time.  DOZIM / HINT: Zimmer's normalisation on /
 // off, the first-guess hint term present (lambdac != 0) / absent, -1 at run time.  Same expressions, same order, same bits in every instance.
 template <int NC, int MODE, int DOZIM, int HINT>
-__global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
+__global__ __launch_bounds__(kAsmThreads) void k_assemble(LevelPtrs L, AssembleParams P)
 {
-    __shared__ double s_red[8];
+    __shared__ double s_red[2 * kAsmWaves];
     const int w = L.w, h = L.h, pitch = L.pitch;
     // rows [ya0, ya1): the whole level for a plain plan; a band also fills the first row of each neighbouring band,
     // so that pass A finds the coefficients and the initial residual of its halo rows without an exchange
@@ -479,8 +483,16 @@ __global__ __launch_bounds__(256) void k_assemble(LevelPtrs L, AssembleParams P)
         }
       }
     }
-    double tot_rr = block_sum_256(acc_rr, s_red);
-    double tot_rz = block_sum_256(acc_rz, s_red);
+    double tot_rr, tot_rz;
+    if (kAsmWaves == 4) {          // (the reduction of rounds 1-3, kept to the letter for the product's four waves)
+        tot_rr = block_sum_256(acc_rr, s_red);
+        tot_rz = block_sum_256(acc_rz, s_red);
+    } else {
+        const double acc2[2] = {acc_rr, acc_rz};
+        double tot2[2];
+        block_sum_multi<2, kAsmThreads>(acc2, s_red, tot2);
+        tot_rr = tot2[0]; tot_rz = tot2[1];
+    }
     if (threadIdx.x == 0) {
         L.part_rr[blockIdx.x] = tot_rr;
         L.part_rz[blockIdx.x] = tot_rz;
@@ -524,20 +536,20 @@ int assemble_grid_size(int w, int h)
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid)
 {
     static const bool generic_only = [] { const char *e = getenv("OCTANE_TUNE_ASM_GENERIC"); return e && atoi(e) != 0; }();   // developer knob: A/B timing
-    if (generic_only) { hipLaunchKernelGGL((k_assemble<0, -1, -1, -1>), dim3(grid), dim3(256), 0, s, L, P); return; }
+    if (generic_only) { hipLaunchKernelGGL((k_assemble<0, -1, -1, -1>), dim3(grid), dim3(kAsmThreads), 0, s, L, P); return; }
     const int mode = P.al1 == 1.0 ? 0 : (P.al1 == 0.0 ? 2 : 1);
     const int z = P.dozim ? 1 : 0, hn = P.lambdac != 0.f ? 1 : 0;
     // Two and three channels (round 4; the reference's loop treats 1 ... 3 alike, ref .cu:749-829): the channel count and the GNC step as
     // template parameters for the default flags (Zimmer's normalisation on, no hint term) -- the channel loop is then unrolled and its
     // `cstride * c` address arithmetic folds into the 27 loads; every other combination runs the generic instance.
     if (L.nc != 1) {
-#define OCT_ASM_NC(N, M) if (L.nc == N && mode == M && z == 1 && hn == 0) { hipLaunchKernelGGL((k_assemble<N, M, 1, 0>), dim3(grid), dim3(256), 0, s, L, P); return; }
+#define OCT_ASM_NC(N, M) if (L.nc == N && mode == M && z == 1 && hn == 0) { hipLaunchKernelGGL((k_assemble<N, M, 1, 0>), dim3(grid), dim3(kAsmThreads), 0, s, L, P); return; }
         OCT_ASM_NC(2, 0) OCT_ASM_NC(2, 1) OCT_ASM_NC(2, 2) OCT_ASM_NC(3, 0) OCT_ASM_NC(3, 1) OCT_ASM_NC(3, 2)
 #undef OCT_ASM_NC
-        hipLaunchKernelGGL((k_assemble<0, -1, -1, -1>), dim3(grid), dim3(256), 0, s, L, P);
+        hipLaunchKernelGGL((k_assemble<0, -1, -1, -1>), dim3(grid), dim3(kAsmThreads), 0, s, L, P);
         return;
     }
-#define OCT_ASM_CASE(M, Z, H) if (mode == M && z == Z && hn == H) { hipLaunchKernelGGL((k_assemble<1, M, Z, H>), dim3(grid), dim3(256), 0, s, L, P); return; }
+#define OCT_ASM_CASE(M, Z, H) if (mode == M && z == Z && hn == H) { hipLaunchKernelGGL((k_assemble<1, M, Z, H>), dim3(grid), dim3(kAsmThreads), 0, s, L, P); return; }
     OCT_ASM_CASE(0, 1, 0) OCT_ASM_CASE(1, 1, 0) OCT_ASM_CASE(2, 1, 0) OCT_ASM_CASE(0, 0, 0) OCT_ASM_CASE(1, 0, 0) OCT_ASM_CASE(2, 0, 0)
     OCT_ASM_CASE(0, 1, 1) OCT_ASM_CASE(1, 1, 1) OCT_ASM_CASE(2, 1, 1) OCT_ASM_CASE(0, 0, 1) OCT_ASM_CASE(1, 0, 1) OCT_ASM_CASE(2, 0, 1)
 #undef OCT_ASM_CASE
