@@ -223,7 +223,7 @@ void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpi
                         // coefficient planes (the parity suite passes with R = 4).  Measured, us per launch at 5000^2 / 2500^2 / 1250^2 (two runs each,
                         // profiles/r4_time_assembly.txt): R = 1 495-497 / 139 / 37.2; 4: 496-501 / 140-141 / 38.1; 6: 501-504 / 141-143 / 39.4;
                         // 8: 469-471 / 139 / 40.4-41.0; 12: 558-561 / 156 / 46; 16: 579-583 / 162-166 / 47 -- a fifth fewer psi' and two thirds fewer u, v
-                        // loads buy nothing (the kernel is not as VALU-bound as its instruction count suggests; beyond 8 rows the registers cost
+                        // loads buy nothing (what the shared psi' saves, the rolling window and the row loop spend; beyond 8 rows the registers cost
                         // occupancy), and the one gain (8 rows at 5000^2, -5 %) is a loss on every smaller level.  1 = the form of rounds 1-3, the product.
 #endif
 #ifndef ASM_WAVES
