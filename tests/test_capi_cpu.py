@@ -47,6 +47,21 @@ def test_rccl_exchange_library_exports_what_its_header_declares(capi):
         assert hasattr(X, name), name
 
 
+def test_transport_names_and_error_codes_without_a_gpu(capi):
+    """Host-side pieces of the row bands' transport selection that need no GPU: the names the JSON lines and logs use, and that the entry
+    points refuse bad arguments before they touch a device."""
+    L = capi.lib()
+    assert [L.octane_vof_transport_name(i).decode() for i in (0, 1, 2, 7)] == ["inplace", "copy", "collective", "unknown"]
+    assert capi.TRANSPORT_NAMES == ("inplace", "copy", "collective")
+    ti = capi.TransportInfo()
+    assert L.octane_vof_tiled_transport_info(None, C.byref(ti)) == capi.E_INVALID
+    assert L.octane_vof_mp_transport_info(None, C.byref(ti)) == capi.E_INVALID
+    assert L.octane_vof_mp_set_exchange(None, None) == capi.E_INVALID
+    assert L.octane_vof_mp_selfcheck(None, capi.ALLGATHER_BYTES_FN(lambda *a: 0), None) == capi.E_INVALID
+    assert L.octane_vof_solve(None, None, 8, 8, 1, None, None, None, None, None) == capi.E_INVALID
+    assert C.sizeof(capi.TransportInfo) == 8 * 4 + 4 * 8 + 48 and C.sizeof(capi.Xfer) == 24       # the C structs of include/octane_vof.h
+
+
 def test_product_library_carries_no_diagnostics(capi):
     """the stamped diagnostic copies of two kernels, their exports and their tune keys live in a library of their
     own (liboctane_vof_diag.so, `make DIAG=1`); the product library has none of them -- no symbol, no kernel, no switch."""
