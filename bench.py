@@ -314,7 +314,7 @@ def tiled(args, capi, synth, torch):
                       "peer_pairs": [list(p) for p in peers]},
            "transport": dict(tp.transport_info(), attempts=attempts, bench_fell_back=len(attempts) > 1),
            "parity_vs_plain": {"rel_l2": attempts[-1]["rel_l2"], "bar": TILED_PARITY_BAR, "iterations_plain": plain_its,
-                               "iterations_banded": attempts[-1]["iterations_banded"], "ok": True},
+                               "iterations_banded": attempts[-1]["iterations_banded"], "ok": bool(attempts[-1]["ok"])},
            "roofline": None, "cpu_baseline": None}
     tp.close()
     print(json.dumps(out), flush=True)
@@ -413,29 +413,45 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         mp.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr())     # blocking and collective
     barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev if os.environ.get("OCTANE_BENCH_BACKEND", "nccl") == "nccl" else None)
+    # the verdict on the TIMED solves is formed on rank 0 before anything is printed and shared with every rank: a run whose last
+    # solve was abandoned (-2) or ran another number of iterations than the configuration names reports no value and fails on all
+    # ranks, as the thread form (tiled) does
+    iters, expect = mp.last_iterations(), args.kiters * 3 * args.liters * args.cgiters
+    timed = [None]
     if rank == 0:
-        iters, expect = mp.last_iterations(), args.kiters * 3 * args.liters * args.cgiters
-        out = {"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n),
-               "value": round(n * n * args.steps / elapsed / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan=1 alpha=5 "
-                                      f"lambda=1 (BASELINE.json configs[3]), {iters} PCG iterations per pyramid (expected {expect}); "
-                                      f"one row band per rank, {world} ranks",
-                          "sharding": f"row bands of the {mp.banded_levels} finest level(s), coarser levels replicated; what crosses ranks per PCG "
-                                      "iteration (partial sums, a few rows per inner edge) is read through HIP IPC mappings, copied through them, "
-                                      "or moved by torch.distributed: see transport",
-                          "ranks": world, "backend": backend},
-               "transport": dict(mp.transport_info(), attempts=attempts, bench_fell_back=len(attempts) > 1, exchange_calls=ex.calls),
-               "parity_vs_plain": {"rel_l2": attempts[-1]["rel_l2"], "bar": TILED_PARITY_BAR, "iterations_plain": plain_its,
-                                   "iterations_banded": attempts[-1]["iterations_banded"], "ok": True},
-               "roofline": None, "cpu_baseline": None}
-        print(json.dumps(out), flush=True)
-        if iters < 0 or (iters != expect and not args.allow_early_exit):
-            print(f"bench.py tiled: the timed solves ran {iters} PCG iterations per pyramid, expected {expect}", file=sys.stderr)
+        timed = [{"iterations": iters, "expected": expect,
+                  "ok": bool(iters >= 0 and (iters == expect or args.allow_early_exit))}]
+    dist.broadcast_object_list(timed, src=0)
+    if rank == 0:
+        workload = (f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan=1 alpha=5 "
+                    f"lambda=1 (BASELINE.json configs[3]), {iters} PCG iterations per pyramid (expected {expect}); "
+                    f"one row band per rank, {world} ranks")
+        if not timed[0]["ok"]:
+            print(f"bench.py tiled: the timed solves ran {iters} PCG iterations per pyramid, expected {expect}"
+                  + (" (a persistent solve was abandoned)" if iters < 0 else ""), file=sys.stderr)
+            print(json.dumps({"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n), "value": None, "n_gpus": world,
+                              "error": "the timed solves are not valid: %d PCG iterations per pyramid, expected %d" % (iters, expect),
+                              "config": {"workload": workload}, "attempts": attempts}), flush=True)
+        else:
+            out = {"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n),
+                   "value": round(n * n * args.steps / elapsed / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": workload,
+                              "sharding": f"row bands of the {mp.banded_levels} finest level(s), coarser levels replicated; what crosses ranks per PCG "
+                                          "iteration (partial sums, a few rows per inner edge) is read through HIP IPC mappings, copied through them, "
+                                          "or moved by torch.distributed: see transport",
+                              "ranks": world, "backend": backend},
+                   "transport": dict(mp.transport_info(), attempts=attempts, bench_fell_back=len(attempts) > 1, exchange_calls=ex.calls),
+                   "parity_vs_plain": {"rel_l2": attempts[-1]["rel_l2"], "bar": TILED_PARITY_BAR, "iterations_plain": plain_its,
+                                       "iterations_banded": attempts[-1]["iterations_banded"], "ok": bool(attempts[-1]["ok"])},
+                   "roofline": None, "cpu_baseline": None}
+            print(json.dumps(out), flush=True)
     mp.close()
     dist.barrier()
     dist.destroy_process_group()
+    if not timed[0]["ok"]:
+        raise SystemExit(4)
 
 
 def _free_port():

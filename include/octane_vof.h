@@ -64,7 +64,9 @@ int octane_vof_run(const float *img1, const float *img2, int nx, int ny, int nch
 int octane_vof_solve(const float *img1, const float *img2, int nx, int ny, int nchan, const float *u0, const float *v0,
                      float *u_out, float *v_out, const octane_vof_params *p);
 /* octane_vof_run keeps the plan of its last call and reuses it when the next call has the same shape and parameters
- * (creating and freeing a multi-GB arena per pair costs up to 0.5 s at 10848^2).  This frees the kept plan;
+ * (creating and freeing a multi-GB arena per pair costs up to 0.5 s at 10848^2).  The first call of a process takes the first arena
+ * it gets; the first REUSE re-creates the plan with the placement trials of octane_vof_plan_create (~0.3 s once at 5000^2, up to 11 %
+ * per pair from then on), so a single-pair run never pays for them.  This frees the kept plan;
  * OCTANE_VOF_CACHE=0 in the environment restores allocate-per-call, as the reference does (.cu:1268-1472). */
 void octane_vof_release_cache(void);
 
@@ -99,7 +101,9 @@ int octane_vof_plan_run(octane_vof_plan *plan, const float *img1, const float *i
 int octane_vof_plan_solve(octane_vof_plan *plan, const float *img1, const float *img2, const float *u0, const float *v0,
                           float *u_out, float *v_out, int mem, void *hip_stream);
 
-/* Blocks until the plan's private stream (and the stream of its last device-buffer run) is idle. */
+/* Blocks until the plan's private stream and the stream of its last device-buffer run -- the NULL stream too, if that is what the
+ * run was given -- are idle.  octane_vof_plan_last_iterations waits for that run's stream as well before it reads the run's count:
+ * the stream handle passed to a device-buffer run therefore has to stay valid until one of the two has been called. */
 int octane_vof_plan_wait(octane_vof_plan *plan);
 /* Number of PCG iterations the last completed run executed (sum over all solves).
  * An ABANDONED persistent solve: the mid-size pyramid levels are solved by ONE persistent launch each whose workgroups all have to be

@@ -963,13 +963,17 @@ extern "C" int octane_vof_plan_wait(octane_vof_plan *pl)
     if (!pl) return OCTANE_E_INVALID;
     HIP_TRY(hipSetDevice(pl->device));
     HIP_TRY(hipStreamSynchronize(pl->own_stream));
-    if (pl->last_mem == OCTANE_MEM_DEVICE && pl->last_stream && pl->last_stream != pl->own_stream) HIP_TRY(hipStreamSynchronize(pl->last_stream));
+    // the stream of the last device-buffer run, the NULL stream included (what callers on PyTorch's default stream pass: own_stream is
+    // non-blocking, so draining it says nothing about the NULL stream -- ADVICE r4)
+    if (pl->last_mem == OCTANE_MEM_DEVICE && pl->last_stream != pl->own_stream) HIP_TRY(hipStreamSynchronize(pl->last_stream));
     return heal_abandoned_run(pl);
 }
 
 extern "C" long long octane_vof_plan_last_iterations(octane_vof_plan *pl)
 {
     if (!pl) return -1;
+    // the abort word and the count belong to a run that may still be in flight on the caller's stream: wait for it before reading them
+    if (pl->last_mem == OCTANE_MEM_DEVICE) { (void)hipSetDevice(pl->device); if (hipStreamSynchronize(pl->last_stream) != hipSuccess) return -1; }
     if (pl->h_mid_abort && *pl->h_mid_abort != 0) {
         // the run's persistent solve was abandoned: make the run again (device buffers; see heal_abandoned_run) -- -2 only if that fails
         (void)hipSetDevice(pl->device);
@@ -1117,6 +1121,7 @@ static std::mutex g_cache_mu;
 static octane_vof_plan *g_cache_plan = nullptr;
 static octane_vof_params g_cache_prm;
 static int g_cache_nx = 0, g_cache_ny = 0, g_cache_nc = 0;
+static bool g_cache_placed = false;     // the kept plan has had its placement trials (from its first reuse on)
 
 static bool same_params(const octane_vof_params &a, const octane_vof_params &b)
 {
@@ -1149,18 +1154,28 @@ extern "C" int octane_vof_solve(const float *img1, const float *img2, int nx, in
     const bool use_cache = !(e && atoi(e) == 0);
     // A kept plan lives for many pairs (a time series through one host program), so it gets the placement trials a plan created through
     // octane_vof_plan_create gets (up to eight candidate arenas timed, the fastest kept: worth up to 11 % per pair, ~0.3 s once at
-    // 5000^2) -- round 4; until then the one-shot path and the plan path ran on differently placed arenas.  Only the allocate-per-call
-    // form (OCTANE_VOF_CACHE=0, or a second thread while the kept plan is busy) takes the first arena it gets.
+    // 5000^2) -- but only once it IS reused: the first call of a process takes the first arena it gets (a single-pair `octane` run
+    // would pay the trials and never recover them -- ADVICE r4), the second call with the same geometry re-creates the plan with the
+    // trials, every later one finds it placed.  Only the allocate-per-call form (OCTANE_VOF_CACHE=0, or a second thread while the kept
+    // plan is busy) never runs them.
     if (use_cache && g_cache_mu.try_lock()) {
         std::lock_guard<std::mutex> g(g_cache_mu, std::adopt_lock);
         if (g_cache_plan && !(g_cache_nx == nx && g_cache_ny == ny && g_cache_nc == nchan && same_params(g_cache_prm, *p))) {
             octane_vof_plan_destroy(g_cache_plan);
             g_cache_plan = nullptr;
         }
-        if (!g_cache_plan) {
+        if (g_cache_plan && !g_cache_placed) {      // first reuse: now the trials pay
+            octane_vof_plan_destroy(g_cache_plan);
+            g_cache_plan = nullptr;
             const int rc = plan_create_ex(&g_cache_plan, nx, ny, nchan, p, 8);
             if (rc != OCTANE_OK) { g_cache_plan = nullptr; return rc; }
+            g_cache_placed = true;
+        }
+        if (!g_cache_plan) {
+            const int rc = plan_create_ex(&g_cache_plan, nx, ny, nchan, p, 1);
+            if (rc != OCTANE_OK) { g_cache_plan = nullptr; return rc; }
             g_cache_prm = *p; g_cache_nx = nx; g_cache_ny = ny; g_cache_nc = nchan;
+            g_cache_placed = false;
         }
         const int rc = octane_vof_plan_solve(g_cache_plan, img1, img2, u0, v0, u, v, OCTANE_MEM_HOST, nullptr);
         if (rc != OCTANE_OK) { octane_vof_plan_destroy(g_cache_plan); g_cache_plan = nullptr; }   // do not keep a plan that failed

@@ -196,6 +196,7 @@ static octane_vof_params check_params(const octane_vof_params &p, int device)
     c.kiters = 2; c.liters = 1; c.cgiters = 6; c.device = device;
     return c;
 }
+constexpr int kCheckBandedLevels = 2;    // both levels of the check frame (kiters = 2, threshold 1 pixel) are banded
 constexpr double kCheckBar = 2e-5;      // banded against plain: two groupings of the same fp64 partial sums (bit-identical in every run so far)
 struct Candidate { int transport; bool no_dma; };
 
@@ -257,6 +258,13 @@ static int tiled_selfcheck(octane_vof_tiled *t)
     octane_vof_tiled *c = nullptr;
     rc = tiled_create_impl(&c, w, h, 1, &cp, nb, t->dev.data(), 1, false);
     if (rc != OCTANE_OK) return rc;
+    if (octane_vof_tiled_banded_levels(c) != kCheckBandedLevels) {     // a check frame without banded levels would pass every transport vacuously
+        fprintf(stderr, "octane: row-band self-check NOT RUN: the check frame (%d x %d, %d bands) has %d banded level(s), expected %d\n",
+                w, h, nb, octane_vof_tiled_banded_levels(c), kCheckBandedLevels);
+        octane_vof_tiled_destroy(c);
+        t->info.selfcheck = 0;
+        return OCTANE_OK;
+    }
     int chosen = -1;
     std::string log;
     for (size_t i = 0; i < cand.size() && chosen < 0; i++) {
@@ -314,7 +322,8 @@ static int tiled_create_impl(octane_vof_tiled **out, int nx, int ny, int nchan, 
     // pays -- banding it lowers even the total work of four bands sharing one GPU, 692 -> 646 ms per pyramid; the 1356^2 level
     // (1.8 Mpixel: a persistent solve of ~17 us per iteration) does not.  Until round 3 the threshold was 12 Mpixel.
     t->min_band_pixels = min_band_pixels > 0 ? (long)min_band_pixels : kDefaultMinBandPixels;
-    if (const char *e = getenv("OCTANE_TUNE_MIN_BAND_PIXELS")) t->min_band_pixels = atol(e);
+    // (the environment's threshold is for the caller's plan only: the self-check's small frame must keep its banded levels -- ADVICE r4)
+    if (allow_selfcheck) if (const char *e = getenv("OCTANE_TUNE_MIN_BAND_PIXELS")) t->min_band_pixels = atol(e);
     for (int b = 0; b < nbands; b++) {
         int d = devices ? devices[b] : b % ndev;
         if (d < 0 || d > ndev - 1) d = 0;                     // as the reference treats a bad -set_device (.cu:1260)
@@ -1112,8 +1121,17 @@ extern "C" int octane_vof_mp_destroy(octane_vof_mp *m)
     return OCTANE_OK;
 }
 
+static int mp_create_impl(octane_vof_mp **out, int nx, int ny, int nchan, const octane_vof_params *p, int rank, int world,
+                          long long min_band_pixels, const char *shm_name, bool check_group);
+
 extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nchan, const octane_vof_params *p, int rank, int world,
                                     long long min_band_pixels, const char *shm_name)
+{
+    return mp_create_impl(out, nx, ny, nchan, p, rank, world, min_band_pixels, shm_name, false);
+}
+
+static int mp_create_impl(octane_vof_mp **out, int nx, int ny, int nchan, const octane_vof_params *p, int rank, int world,
+                          long long min_band_pixels, const char *shm_name, bool check_group)
 {
     if (!out || !p || world < 1 || world > kMaxBands || rank < 0 || rank >= world || !shm_name || shm_name[0] != '/') {
         set_last_error("octane_vof_mp_create: invalid argument (1 <= world <= 8, shm_name like /octane_1234)");
@@ -1139,7 +1157,7 @@ extern "C" int octane_vof_mp_create(octane_vof_mp **out, int nx, int ny, int nch
     m->arena[rank] = reinterpret_cast<char *>(m->pl->arena);
     m->parts_all[rank] = m->parts;
     long minpix = min_band_pixels > 0 ? (long)min_band_pixels : kDefaultMinBandPixels;
-    if (const char *e = getenv("OCTANE_TUNE_MIN_BAND_PIXELS")) minpix = atol(e);
+    if (!check_group) if (const char *e = getenv("OCTANE_TUNE_MIN_BAND_PIXELS")) minpix = atol(e);     // never for the self-check's frame
     m->rows.resize(m->pl->lev.size());
     for (size_t k = 0; k < m->pl->lev.size(); k++) {
         const LevelInfo &li = m->pl->lev[k];
@@ -1379,7 +1397,7 @@ extern "C" int octane_vof_mp_selfcheck(octane_vof_mp *m, octane_allgather_bytes_
     if (m->ex.all_gather) cand.push_back({OCTANE_TRANSPORT_COLLECTIVE, false});
     // the check group: same ranks, same devices, same collective library, a shared-memory object of its own
     octane_vof_mp *c = nullptr;
-    int rc = octane_vof_mp_create(&c, w, h, 1, &cp, m->rank, nb, 1, (m->shm_name + "_chk").c_str());
+    int rc = mp_create_impl(&c, w, h, 1, &cp, m->rank, nb, 1, (m->shm_name + "_chk").c_str(), true);
     std::vector<unsigned char> all((size_t)nb * OCTANE_MP_HANDLE_BYTES);
     unsigned char mine[OCTANE_MP_HANDLE_BYTES] = {0};
     if (rc == OCTANE_OK && m->ex.all_gather) rc = octane_vof_mp_set_exchange(c, &m->ex);
@@ -1395,13 +1413,33 @@ extern "C" int octane_vof_mp_selfcheck(octane_vof_mp *m, octane_allgather_bytes_
         if (m->rank == 0) rc = plain_check_flow(cp, w, h, a, b2, up, vp, &its_plain);
     }
     std::vector<int> verdicts(nb);
-    int setup_ok = rc == OCTANE_OK ? 1 : 0;
-    if (ag(user, &setup_ok, verdicts.data(), sizeof(int)) != 0) setup_ok = 0;
-    for (int r = 0; r < nb; r++) setup_ok = setup_ok && verdicts[r];
+    // one word per rank: bit 0 = the check group stands, bit 1 = its IPC mappings are open, bit 2 = its frame has the banded levels it
+    // is meant to have.  The in-place and copy candidates dereference the other ranks' memory: they run only where EVERY rank of the
+    // check group has the mappings (the real group's ipc_ok says nothing about a second set of mappings -- ADVICE r4).
+    const bool banded_ok = rc == OCTANE_OK && c && octane_vof_mp_banded_levels(c) == kCheckBandedLevels;
+    int word = (rc == OCTANE_OK ? 1 : 0) | ((rc == OCTANE_OK && c && c->ipc_ok) ? 2 : 0) | (banded_ok ? 4 : 0);
+    if (ag(user, &word, verdicts.data(), sizeof(int)) != 0) { word = 0; for (int r = 0; r < nb; r++) verdicts[r] = 0; }
+    int setup_ok = 1, ipc_all = 1, banded_all = 1;
+    for (int r = 0; r < nb; r++) { setup_ok = setup_ok && (verdicts[r] & 1); ipc_all = ipc_all && (verdicts[r] & 2); banded_all = banded_all && (verdicts[r] & 4); }
     int chosen = -1;
     std::string log;
+    if (setup_ok && !banded_all) {
+        if (m->rank == 0)
+            fprintf(stderr, "octane: row-band self-check NOT RUN: the check frame (%d x %d, %d ranks) does not have %d banded levels on every rank\n", w, h, nb, kCheckBandedLevels);
+        if (c) octane_vof_mp_destroy(c);
+        TILED_TRY(hipSetDevice(m->device));
+        m->info.selfcheck = 0;
+        return OCTANE_OK;
+    }
     if (setup_ok) {
         for (size_t i = 0; i < cand.size() && chosen < 0; i++) {
+            if (cand[i].transport != OCTANE_TRANSPORT_COLLECTIVE && !ipc_all) {      // every rank skips the same candidates
+                if (m->rank == 0)
+                    log += std::string(log.empty() ? "" : "; ") + octane_vof_transport_name(cand[i].transport) + ": skipped (the check group has no IPC mappings on every rank)";
+                if (i < 4) m->info.check_rel_l2[i] = -1.;
+                m->info.candidates_tried = (int)i + 1;
+                continue;
+            }
             c->transport = cand[i].transport; c->no_dma = cand[i].no_dma;
             u.assign((size_t)w * h, 0.f); v.assign((size_t)w * h, 0.f);
             const int rrc = octane_vof_mp_run(c, a.data(), b2.data(), nullptr, nullptr, u.data(), v.data(), OCTANE_MEM_HOST);
@@ -1412,10 +1450,10 @@ extern "C" int octane_vof_mp_selfcheck(octane_vof_mp *m, octane_allgather_bytes_
                 d = flow_rel_l2(u, v, up, vp, &fin);
                 const long long its = octane_vof_mp_last_iterations(c);
                 pass = fin && d <= kCheckBar && its == its_plain;
-                log += std::string(i ? "; " : "") + octane_vof_transport_name(cand[i].transport) + (cand[i].no_dma ? " without LDS-DMA from the neighbour" : "") +
+                log += std::string(log.empty() ? "" : "; ") + octane_vof_transport_name(cand[i].transport) + (cand[i].no_dma ? " without LDS-DMA from the neighbour" : "") +
                        (pass ? ": ok" : ": rel L2 " + std::to_string(d) + ", iterations " + std::to_string(its) + " / " + std::to_string(its_plain));
             } else if (m->rank == 0) {
-                log += std::string(i ? "; " : "") + octane_vof_transport_name(cand[i].transport) + ": error (" + octane_last_error() + ")";
+                log += std::string(log.empty() ? "" : "; ") + octane_vof_transport_name(cand[i].transport) + ": error (" + octane_last_error() + ")";
             }
             if (i < 4) m->info.check_rel_l2[i] = d;
             m->info.candidates_tried = (int)i + 1;
