@@ -195,14 +195,26 @@ def level_dims(nx: int, ny: int, factor: float):
     return lx.value, ly.value
 
 
-def pix2uv(nav: Nav, t1: float, t2: float, u: np.ndarray, v: np.ndarray, pixuv: int = 0, mode: int = 0, flavour: str = "strict"):
-    """Returns (ur, vr, ur2, vr2, dT, sector_moved).  flavour "fma": the build with contracted multiply-adds."""
+P2U_SITES = ("F1 base x (float)", "F2 base y (float)", "D1 rate_x*dt+xi", "D2 (..)*xScale+xOffset", "D3 rate_y*dt+yi", "D4 (..)*yScale+yOffset",
+             "D5 sds", "D6 cos2y+k*sin2y", "D7 sin2x+cos2x*(..)", "D8 H*H-req*req", "D9 b*b-4ac", "D10 (H-sx)^2+sy^2", "H1 haversine a")
+P2U_FLOAT_SITES = 0b11          # the two float multiply-adds of the base position: what decides the shorts (profiles/r5_pix2uv_sites.txt)
+P2U_ALL_SITES = (1 << len(P2U_SITES)) - 1
+
+
+def pix2uv(nav: Nav, t1: float, t2: float, u: np.ndarray, v: np.ndarray, pixuv: int = 0, mode: int = 0, flavour: str = "strict", sites: int = 0):
+    """Returns (ur, vr, ur2, vr2, dT, sector_moved).  flavour "fma": the build with contracted multiply-adds (the compiler's choice of
+    sites); `sites` (strict build): bit mask of the multiply-add sites evaluated as ONE fused operation, pix2uv_oracle.c."""
     u = np.ascontiguousarray(u, np.float32)
     v = np.ascontiguousarray(v, np.float32)
     n = u.size
     ur, vr, ur2, vr2 = (np.zeros(n, np.int16) for _ in range(4))
     dT = C.c_float()
-    moved = lib(flavour).oct_oracle_pix2uv(C.byref(nav), t1, t2, u.ravel(), v.ravel(), pixuv, mode, ur, vr, ur2, vr2, C.byref(dT))
+    L = lib(flavour)
+    L.oct_oracle_pix2uv_fma_sites(C.c_uint(sites))
+    try:
+        moved = L.oct_oracle_pix2uv(C.byref(nav), t1, t2, u.ravel(), v.ravel(), pixuv, mode, ur, vr, ur2, vr2, C.byref(dT))
+    finally:
+        L.oct_oracle_pix2uv_fma_sites(C.c_uint(0))
     shp = u.shape
     return ur.reshape(shp), vr.reshape(shp), ur2.reshape(shp), vr2.reshape(shp), dT.value, moved
 

@@ -20,13 +20,42 @@
 #include <math.h>
 #include "vof_oracle.h"
 
+/* Round 5: WHICH multiply-add decides the shorts?  nvcc builds the reference's kernel with -fmad=true (its default,
+ * ref src/Makefile:9,20,27 pass no -fmad=false), so any `a * b + c` below MAY be one fused operation in the reference's binary.  Each
+ * such site is an explicit switch here: bit k of the site mask makes site k a fma()/fmaf(); with mask 0 every expression is the
+ * two-rounding form this file has always had (the strict build's bits do not change).  tools/pix2uv_sites.py tables, per site, how
+ * many shorts it moves (profiles/r5_pix2uv_sites.txt): only the two FLOAT sites of the base position do.
+ *   bit  0  F1  xVal = xi * xScale + xOffset            float   ref p2u:40,76,99   (base position)
+ *   bit  1  F2  yVal = yi * yScale + yOffset            float   ref p2u:41,77,100
+ *   bit  2  D1  xv[0] * dt + xi                         double  ref p2u:43,79,102  (displaced position)
+ *   bit  3  D2  (...) * xScale + xOffset                double
+ *   bit  4  D3  xv[1] * dt + yi                         double  ref p2u:44,80,103
+ *   bit  5  D4  (...) * yScale + yOffset                double
+ *   bit  6  D5  sds = xVal * xVal + yVal * yVal         double  ref p2u:105
+ *   bit  7  D6  cos^2 y + (req^2 / rpol^2) * sin^2 y    double  ref p2u:108        (only if pow(x, 2) is a product, as nvcc makes it)
+ *   bit  8  D7  sin^2 x + cos^2 x * (...)               double  ref p2u:108
+ *   bit  9  D8  c = H * H - req * req                   double  ref p2u:110
+ *   bit 10  D9  d = b * b - 4 a c                       double  ref p2u:111
+ *   bit 11  D10 e = (H - sx)^2 + sy^2                   double  ref p2u:118
+ *   bit 12  H1  a = sin^2(..) + cos cos sin^2(..)       double  ref p2u:20         (haversine)
+ * A build with -ffp-contract=fast (the "fma" flavour) additionally lets the compiler fuse what it likes: the site mask is for the
+ * strict build. */
+#define P2U_NSITES 13
+static unsigned g_sites = 0u;
+void oct_oracle_pix2uv_fma_sites(unsigned mask) { g_sites = mask; }
+int oct_oracle_pix2uv_nsites(void) { return P2U_NSITES; }
+#define SITE(k) (g_sites & (1u << (k)))
+static inline float maddf(int k, float a, float b, float c) { return SITE(k) ? fmaf(a, b, c) : a * b + c; }
+static inline double madd(int k, double a, double b, double c) { return SITE(k) ? fma(a, b, c) : a * b + c; }
+
 /* ref p2u:13-25 oct_haversine_cuda: arguments arrive as float */
 static double great_circle(float lat1, float lon1, float lat2, float lon2, double rad, double rad2)
 {
     const double earthrad = 6371000.00;
     double dlon = lon2 - lon1;
     double dlat = lat2 - lat1;
-    double a = (pow(sin(dlat * rad2), 2) + cos(lat1 * rad) * cos(lat2 * rad) * pow((sin(dlon * rad2)), 2));
+    double a = SITE(12) ? fma(cos(lat1 * rad) * cos(lat2 * rad), pow((sin(dlon * rad2)), 2), pow(sin(dlat * rad2), 2))
+                        : (pow(sin(dlat * rad2), 2) + cos(lat1 * rad) * cos(lat2 * rad) * pow((sin(dlon * rad2)), 2));
     double c = 2. * atan2(sqrt(a), sqrt(1 - a));
     return earthrad * c;
 }
@@ -40,11 +69,11 @@ static void navigate_pixel(const oct_oracle_nav *g, const double *rate, int xi, 
     double latv[2], lonv[2], sds[2] = { 0., 0. };
     for (int iv = 0; iv < 2; ++iv) {
         if (iv == 0) {
-            xVal = (xi)*g->xScale + g->xOffset;       /* float arithmetic */
-            yVal = (yi)*g->yScale + g->yOffset;
+            xVal = maddf(0, (float)(xi), g->xScale, g->xOffset);       /* float arithmetic */
+            yVal = maddf(1, (float)(yi), g->yScale, g->yOffset);
         } else {
-            xVal = (rate[0] * dt + xi) * g->xScale + g->xOffset;   /* double arithmetic */
-            yVal = (rate[1] * dt + yi) * g->yScale + g->yOffset;
+            xVal = madd(3, madd(2, rate[0], dt, xi), g->xScale, g->xOffset);   /* double arithmetic */
+            yVal = madd(5, madd(4, rate[1], dt, yi), g->yScale, g->yOffset);
         }
         if (mode == 1) {                               /* polar, ref p2u:34-66 */
             double rho = sqrt(xVal * xVal + yVal * yVal);
@@ -68,17 +97,22 @@ static void navigate_pixel(const oct_oracle_nav *g, const double *rate, int xi, 
             lonv[iv] = lonv[iv] / DTOR;
         } else {                                       /* GOES fixed grid, ref p2u:90-139 */
             double H = g->pph + g->req;
-            sds[iv] = xVal * xVal + yVal * yVal;
+            sds[iv] = SITE(6) ? fma(xVal, xVal, yVal * yVal) : xVal * xVal + yVal * yVal;
             double a = pow((sin(xVal)), 2) + pow(cos(xVal), 2) * (pow((cos(yVal)), 2) + (pow(g->req, 2)) / (pow(g->rpol, 2)) * pow((sin(yVal)), 2));
+            if (SITE(7) || SITE(8)) {      /* the same sum with one or both of its product-sums fused (pow(x, 2) == x * x correctly rounded) */
+                const double k2 = (pow(g->req, 2)) / (pow(g->rpol, 2)), s2y = pow((sin(yVal)), 2), c2y = pow((cos(yVal)), 2);
+                const double inner = SITE(7) ? fma(k2, s2y, c2y) : c2y + k2 * s2y;
+                a = SITE(8) ? fma(pow(cos(xVal), 2), inner, pow((sin(xVal)), 2)) : pow((sin(xVal)), 2) + pow(cos(xVal), 2) * inner;
+            }
             double b = -2. * H * cos(xVal) * cos(yVal);
-            double c = pow(H, 2) - pow(g->req, 2);
-            double d = (pow(b, 2) - 4. * a * c);
+            double c = SITE(9) ? fma(H, H, -pow(g->req, 2)) : pow(H, 2) - pow(g->req, 2);
+            double d = SITE(10) ? fma(b, b, -(4. * a * c)) : (pow(b, 2) - 4. * a * c);
             if (d >= 0) {
                 double rs = (-b - sqrt(d)) / (2. * a);
                 double sx = rs * cos(xVal) * cos(yVal);
                 double sy = -rs * sin(xVal);
                 double sz = rs * cos(xVal) * sin(yVal);
-                double e = (pow((H - sx), 2) + pow(sy, 2));
+                double e = SITE(11) ? fma(H - sx, H - sx, pow(sy, 2)) : (pow((H - sx), 2) + pow(sy, 2));
                 if (sz == 0 || e <= 0 || H - sx == 0) {
                     latv[iv] = -999.; lonv[iv] = -999.;
                 } else {

@@ -72,6 +72,9 @@ typedef struct oct_oracle_nav {   /* the GOESNAVVar fields ref oct_pix2uv_cuda.c
 
 /* mode: 0 geostationary fixed grid, 1 polar (-Polar), 2 mercator (-Merc).
  * Returns 0, or 1 when the sector-moved guard zeroed everything. */
+/* which multiply-add sites of the navigation are fused (bit mask, pix2uv_oracle.c; 0 = none: the strict two-rounding forms) */
+void oct_oracle_pix2uv_fma_sites(unsigned mask);
+int oct_oracle_pix2uv_nsites(void);
 int oct_oracle_pix2uv(const oct_oracle_nav *nav, double t1, double t2, const float *u, const float *v,
                       int pixuv, int mode, short *ur, short *vr, short *ur2, short *vr2, float *dT);
 

@@ -15,9 +15,11 @@ Two kinds of assertion:
   data term: a weighted Laplacian that 30 PCG iterations do not converge), and single roundings are amplified ~100 x more than on
   the lattice scenes: the oracle's OWN valid variants (FMA-contracted build, 8 x finer launch geometry) are 1e-4 ... 4e-4 apart on
   multi-level solves of this family (oracle-only, reproducible on the CPU: tools/disc_parity.py, profiles/r5_disc_parity.txt).
-  Single-level solves stay under the suite's 2e-5; multi-level ones are held to the oracle's own spread on that very case (the HIP
-  path has to be no further from the primary oracle than 3 x the furthest oracle variant), with equal iteration counts, and
-  to 2e-5 wherever the spread allows it."""
+  The bar is therefore set by the oracle itself, case by case: where its variants agree to 1e-5 the suite's 2e-5 is asserted (all
+  large single-level solves, BASELINE-sized pyramids: configs[3] at quarter scale 1.05e-5, configs[1]'s shape 3.6e-6); where they do
+  not, the HIP path has to be no further from the primary oracle than 3 x the furthest oracle variant.  Equal iteration counts
+  always.  profiles/r5_disc_parity.txt also shows the distance growing linearisation by linearisation -- for the HIP path and for the
+  oracle's FMA build alike, at the same linearisation (one solve of the finest level's first GNC step lifts both from 6e-5 to 2e-3)."""
 import numpy as np
 import pytest
 
@@ -122,7 +124,10 @@ def _flows(capi, oracle, a, b, prm, u0=None, v0=None):
     return (ug, vg, ig), (uo, vo, io), var
 
 
-def _judge(case, got, prim, var, mask, need_tight):
+def _judge(case, got, prim, var, mask):
+    """Equal iteration counts always.  The bar is set by the oracle itself, per case: where its own valid variants agree to within half of
+    the suite's 2e-5 the HIP path has to be within 2e-5 of the primary oracle (TIGHT); where they do not -- the zero background's
+    ill-conditioning at work -- it has to be no further from the primary than 3 x the furthest variant (and never beyond 2e-3)."""
     ug, vg, ig = got
     uo, vo, io = prim
     d = rel_l2(ug, vg, uo, vo)
@@ -130,44 +135,41 @@ def _judge(case, got, prim, var, mask, need_tight):
     floor = max(spread.values())
     inside = mask == 1
     di = rel_l2(ug[inside], vg[inside], uo[inside], vo[inside])
+    tight = floor <= INVESTIGATE / 2
     print(f"PARITY-DISC case={case}: d_primary={d:.3e} (inside the disc {di:.3e}) oracle_spread={ {k: f'{x:.2e}' for k, x in spread.items()} } "
-          f"iterations oracle/gpu={io}/{ig} {'TIGHT' if need_tight else 'held to 3 x the oracle spread'}")
+          f"iterations oracle/gpu={io}/{ig} {'TIGHT (2e-5)' if tight else 'ILL-CONDITIONED: held to 3 x the oracle spread'}")
     assert ig == io
-    if need_tight:
+    if tight:
         assert d < INVESTIGATE, f"{case}: {d:.3e} from the primary oracle (oracle spread {floor:.2e})"
     else:
-        assert d < max(INVESTIGATE, 3 * floor), f"{case}: {d:.3e} from the primary oracle, the oracle's own variants are within {floor:.2e}"
+        assert d < 3 * floor, f"{case}: {d:.3e} from the primary oracle, the oracle's own variants are within {floor:.2e}"
         assert d < 20 * BAR
-    return d, floor
+    return d, floor, tight
 
 
-@pytest.mark.parametrize("nx,ny,nc,prm,kw,guess", [
-    (300, 280, 1, dict(kiters=1), {}, False),
-    (300, 280, 1, dict(kiters=1, liters=1, cgiters=10), {}, True),
-    (310, 270, 2, dict(kiters=1, liters=2, cgiters=12), dict(centre=(0.35, 0.6), span=0.9), True),
-    (260, 300, 3, dict(kiters=1, liters=1, cgiters=8), {}, False),
-    (2300, 1900, 1, dict(kiters=1, liters=1, cgiters=7), {}, False),                                   # the q-recomputing LDS-DMA kernel
-    (2300, 1900, 1, dict(kiters=1, liters=1, cgiters=7), dict(centre=(0.2, 0.3), span=0.7), True),
+@pytest.mark.parametrize("nx,ny,nc,prm,kw,guess,expect_tight", [
+    (300, 280, 1, dict(kiters=1), {}, False, True),
+    (300, 280, 1, dict(kiters=1, liters=1, cgiters=10), {}, True, True),
+    (260, 300, 3, dict(kiters=1, liters=1, cgiters=8), {}, False, True),
+    (2300, 1900, 1, dict(kiters=1, liters=1, cgiters=7), {}, False, None),                             # the q-recomputing LDS-DMA kernel (spread 1.1e-5: at the line)
+    (2300, 1900, 1, dict(kiters=1, liters=1, cgiters=7), dict(centre=(0.2, 0.3), span=0.7), True, True),
+    (2090, 1730, 2, dict(kiters=2, liters=1, cgiters=6), {}, True, True),
+    # two linearisations from a first guess next to the limb: the oracle's variants are 1.5e-3 apart on ONE level (measured, round 5)
+    (310, 270, 2, dict(kiters=1, liters=2, cgiters=12), dict(centre=(0.35, 0.6), span=0.9), True, False),
+    (300, 280, 1, dict(kiters=4), {}, False, False),
+    (300, 280, 1, dict(kiters=4), dict(noise=0.0), False, None),              # no noise: the plateaus stay plateaus
+    (320, 300, 2, dict(kiters=3, liters=2, cgiters=12), {}, True, None),
+    (260, 300, 3, dict(kiters=3, liters=1, cgiters=8), {}, False, None),
+    (400, 360, 1, dict(kiters=4), dict(centre=(0.1, 0.2), span=0.6), False, None),   # the limb through a corner of the frame
 ])
-def test_disc_single_level_solves_match_the_oracle(capi, oracle, nx, ny, nc, prm, kw, guess):
-    """One level: the rounding of the sums has three GNC steps to grow in, not a pyramid -- the suite's 2e-5 holds."""
+def test_disc_solves_match_the_oracle(capi, oracle, nx, ny, nc, prm, kw, guess, expect_tight):
+    """Whole solves on the disc scene, single- and multi-level, 1 - 3 channels, with and without a first guess.  `expect_tight` pins the
+    regime that was measured when the case was added (None: the oracle's spread sits near the line): a case that was TIGHT must not
+    drift into the lenient regime unnoticed."""
     a, b = synth.disc_scene(nx, ny, seed=nx * 3 + ny, nchan=nc, **kw)
     m = synth.disc_mask(nx, ny, kw.get("centre", (0.5, 0.5)), kw.get("span", 1.0))
     u0, v0 = _guess(nx, ny, m) if guess else (None, None)
     got, prim, var = _flows(capi, oracle, a, b, prm, u0, v0)
-    _judge(f"single_{nx}x{ny}x{nc}", got, prim, var, m, need_tight=True)
-
-
-@pytest.mark.parametrize("nx,ny,nc,prm,kw,guess", [
-    (300, 280, 1, dict(kiters=4), {}, False),
-    (300, 280, 1, dict(kiters=4), dict(noise=0.0), False),                    # no noise: the plateaus stay plateaus
-    (320, 300, 2, dict(kiters=3, liters=2, cgiters=12), {}, True),
-    (260, 300, 3, dict(kiters=3, liters=1, cgiters=8), {}, False),
-    (400, 360, 1, dict(kiters=4), dict(centre=(0.1, 0.2), span=0.6), False),  # the limb through a corner of the frame
-])
-def test_disc_multi_level_solves_stay_within_the_oracles_own_spread(capi, oracle, nx, ny, nc, prm, kw, guess):
-    a, b = synth.disc_scene(nx, ny, seed=nx * 3 + ny, nchan=nc, **kw)
-    m = synth.disc_mask(nx, ny, kw.get("centre", (0.5, 0.5)), kw.get("span", 1.0))
-    u0, v0 = _guess(nx, ny, m) if guess else (None, None)
-    got, prim, var = _flows(capi, oracle, a, b, prm, u0, v0)
-    _judge(f"multi_{nx}x{ny}x{nc}", got, prim, var, m, need_tight=False)
+    d, floor, tight = _judge(f"{nx}x{ny}x{nc}_{'_'.join(f'{k}{v}' for k, v in prm.items())}", got, prim, var, m)
+    if expect_tight is not None:
+        assert tight == expect_tight, f"the oracle's spread on this case moved: {floor:.2e}"

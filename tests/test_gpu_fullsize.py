@@ -193,3 +193,48 @@ def test_r3_parameter_set_ten_levels_matches_oracle(capi, oracle):
     assert io < 10 * 3 * 10 * 30 and ig < 10 * 3 * 10 * 30
     assert abs(ig - io) <= 0.01 * io
     assert d < INVESTIGATE
+
+
+def test_r2_parameter_set_at_5000_matches_oracle(capi, oracle):
+    """Round 5: SURVEY 8d's R2 -- kiters 8, liters 10, cgiters 10: 300 PCG iterations per level, 240 assemblies -- on the
+    bench's own 5000 x 5000 pair (until round 4 a tools/ record, profiles/r4_parity_r2_r3_fullsize.txt: 1.7e-5).  ~90 s of oracle on the
+    GPU box's cores."""
+    n = 5000
+    a, b = synth.lattice_scene(n, n, seed=20240615, device="cuda")
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    prm = dict(kiters=8, liters=10, cgiters=10)
+    ug, vg, ig, tg = _plain(capi, a, b, prm)
+    assert np.isfinite(ug).all() and np.isfinite(vg).all()
+    uo, vo, io, to = _oracle(oracle, a, b, prm)
+    d = rel_l2(ug, vg, uo, vo)
+    _report("R2_5000", f"{n}x{n}", prm, d, io, ig, to, tg)
+    assert io == ig == 8 * 3 * 10 * 10
+    assert d < INVESTIGATE
+
+
+def test_config3_quarter_scale_disc_scene_four_bands_and_plain_match_oracle(capi, oracle):
+    """Round 5: BASELINE.json configs[3] is a FULL-DISK pair -- the Earth disc on exact zeros, the limb taper, counts,
+    noise, a saturated patch (synth.disc_scene; ref src/oct_navcal_cuda.cu:81-93) -- at a quarter of its linear size, R1's parameters:
+    the plain plan and four row bands (the disc edge crosses every band), both against the oracle.  The bands have to equal the plain
+    plan bit for bit (banding regroups fp64 partial sums only)."""
+    n = 2712
+    a, b = synth.disc_scene(n, n, seed=n * 3 + n)
+    prm = dict(kiters=8, liters=3, cgiters=30)
+    uo, vo, io, to = _oracle(oracle, a, b, prm)
+    uf, vf, _, _ = _oracle(oracle, a, b, prm, dot_threads=8 * oracle.REF_GRID_THREADS)     # the oracle's own spread on this case
+    up, vp, ip, tp_s = _plain(capi, a, b, prm)
+    tp = capi.TiledPlan(n, n, 1, capi.FlowParams(**prm), nbands=4, devices=capi.band_devices(4), min_band_pixels=(12 << 20) // 16)
+    try:
+        nbanded = tp.banded_levels
+        ut, vt = tp.run_host(a, b)
+        it = tp.last_iterations()
+    finally:
+        tp.close()
+    dp, dt, floor = rel_l2(up, vp, uo, vo), rel_l2(ut, vt, uo, vo), rel_l2(uf, vf, uo, vo)
+    m = synth.disc_mask(n, n) == 1
+    _report("config3_quarter_disc_plain", f"{n}x{n}", prm, dp, io, ip, to, tp_s, f"[inside the disc {rel_l2(up[m], vp[m], uo[m], vo[m]):.2e}; oracle grid x 8 vs primary {floor:.2e}]")
+    _report("config3_quarter_disc_4bands", f"{n}x{n}", prm, dt, io, it, to, 0.0, f"[banded levels {nbanded}; banded vs plain {rel_l2(ut, vt, up, vp):.2e}]")
+    assert nbanded == 2 and io == ip == it == 8 * 3 * 3 * 30
+    assert (a == 0).mean() > 0.2
+    assert dp < INVESTIGATE and dt < INVESTIGATE
+    assert rel_l2(ut, vt, up, vp) < 2e-6
