@@ -45,7 +45,7 @@ PASS_A_BYTES_PER_PIXEL = 36 + 16   # reads r(2) p(2) a1 a2 a4 wx wy, writes p(2)
 PASS_A_BYTES_PER_PIXEL_GNC0 = 28 + 16   # first GNC step (a third of the launches): wx == wy == -1, the planes are not read
 PASS_B_BYTES_PER_PIXEL = 40 + 16   # reads x(2) r(2) p(2) q(2) a1 a4, writes x(2) r(2)
 # one fused kernel per iteration: reads r q p (24) + a1 a2 a4 wx wy (20), writes r p q (24) = 68 B/pixel; x is updated by every second
-# launch only, which then also reads x and the p before last (16) and writes x (8): 92.  Mean 80 (84 with OCTANE_TUNE_DEFER_X=0).
+# launch only, which then also reads x and the p before last (16) and writes x (8): 92.  Mean 80.
 FUSED_BYTES_PER_PIXEL = 80
 FUSED_BYTES_PER_PIXEL_GNC0 = 72        # first GNC step: wx == wy == -1, not read
 FUSED_Q_BYTES_PER_PIXEL = 64           # k_pcg_fused_q_dma / k_pcg_fused_q (levels of >= 2 * 2^20 pixels): q = A p is formed again, neither written nor read
@@ -669,12 +669,12 @@ def main():
         plan.set_profiling(False)
         a_ms = pr.pass_a_ms / max(1, pr.pass_a_launches)
         b_ms = pr.pass_b_ms / max(1, pr.pass_b_launches)
-        unit_w = os.environ.get("OCTANE_TUNE_UNIT_W", "1") != "0"
+        unit_w = True      # (the product library no longer reads the OCTANE_TUNE_* tuning variables, round 5: the defaults are what runs)
         fused = pr.pass_b_launches == 0          # one kernel per PCG iteration (the default); its launches are timed as "pass A"
         if fused:
             # mean algorithmic bytes of a finest-level launch: 80 B/px, 72 in the first of the three GNC steps
-            imm = 4 if os.environ.get("OCTANE_TUNE_DEFER_X", "1") == "0" else 0     # immediate x updates move 4 B/px more on average
-            qform = os.environ.get("OCTANE_TUNE_FUSED_Q", "1") != "0" and n * n >= (2 << 20)
+            imm = 0                                # (x is updated by every second launch)
+            qform = n * n >= (2 << 20)
             b_all, b_gnc0 = ((FUSED_Q_BYTES_PER_PIXEL, FUSED_Q_BYTES_PER_PIXEL_GNC0) if qform
                              else (FUSED_BYTES_PER_PIXEL, FUSED_BYTES_PER_PIXEL_GNC0))
             bpp = ((b_gnc0 + 2 * b_all) / 3.0 if unit_w else b_all) + imm
@@ -734,7 +734,7 @@ def main():
                 "pcg_iteration_ms": round(iter_ms, 4),
                 # one whole PCG iteration on SURVEY 8(d)'s accounting (116 B/px: pass A with seven coefficient planes + pass B).
                 # This implementation moves 64 (fused kernel, five planes, x every second launch, q formed twice instead of stored;
-                # 80 with OCTANE_TUNE_FUSED_Q=0) -- the figure above counts those, the stricter one.
+                # 80 on levels below 2 Mi pixels, where q is stored) -- the figure above counts those, the stricter one.
                 # the same launch priced with the bytes rocprofv3 counted on the L2's fabric side (profiles/traffic.json;
                 # Infinity-Cache hits included): what "rocprof achieved GB/s against the roofline" reads
                 "rocprof_traffic_gbs": round(traffic / (dms * 1e-3) / 1e9, 1) if traffic else None,

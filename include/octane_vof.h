@@ -144,9 +144,20 @@ int octane_vof_plan_get_profile(octane_vof_plan *plan, octane_vof_profile *out);
  * launch, the first GNC step's weights are the constant -1 and are not read): bench.py prices each kind on its own bytes.  Returns
  * the number of launches recorded; writes min(that, cap) values. */
 int octane_vof_plan_get_launch_times(octane_vof_plan *plan, float *ms, int cap);
-/* Developer knob (what the OCTANE_TUNE_* environment variables set): key in {overlap, persist, persist_p, small_max, pass_a, max_blocks, reverse_b, xcd, nt,
- * defer_x, small, unit_w, fused, fused_q, fused_rows}.  Results agree for every setting to the last bits of the PCG
- * scalars (the grouping of the fp64 partial sums follows the grid); only speed changes. */
+/* Developer knob, per plan: key in {overlap, persist, persist_p, persist_step, persist_max_g, lane_mode, small, small_max, pass_a,
+ * max_blocks, reverse_b, xcd, nt, defer_x, unit_w, fused, fused_q, fused_rows, q_dma, asm_fast, trace_levels}.  Results agree for every
+ * setting to the last bits of the PCG scalars (the grouping of the fp64 partial sums follows the grid); only speed changes.
+ *
+ * ENVIRONMENT.  The product library reads exactly these variables (none is needed):
+ *   OCTANE_VOF_CACHE=0            one-shot entry: allocate per call            OCTANE_VOF_BANDS=n           C++ shim: n row bands
+ *   OCTANE_TILED_TRANSPORT=...    row bands: force a transport                 OCTANE_TILED_SELFCHECK=0     ... skip the first-contact check
+ *   OCTANE_TUNE_MIN_BAND_PIXELS=n row bands: banding threshold                 OCTANE_MP_TIMEOUT_S=s        process form: boundary time-out
+ *   OCTANE_PIX2UV_FMAD=0|1|2      which build of the navigation kernel         OCTANE_TUNE_PERSIST_MAXG=g   processes SHARING a GPU: workgroups a
+ *   OCTANE_TUNE_Q_DMA=0, OCTANE_TUNE_PERSIST=0   the bisect pair: the finest levels' kernel              persistent solve may hold
+ *       without LDS-DMA / one launch per PCG iteration on the mid-size levels -- the first two things to switch off when a result is in doubt.
+ * Every other OCTANE_TUNE_* variable of rounds 1-4 (about thirty tuning switches) is read by the DIAGNOSTIC library only
+ * (liboctane_vof_diag.so, `make -C octane_amd/csrc DIAG=1`; tools/ load it): in the product they do not exist, so a stray variable in a
+ * production environment cannot change which kernels run. */
 int octane_vof_tune(octane_vof_plan *plan, const char *key, int value);
 /* Which sub-domain grid the persistent mid-level solve (pcg_persist.hip) takes for a level of w x h pixels on a device with `ncu`
  * compute units: out5 = {columns of sub-domains, rows of sub-domains, rows per sub-domain, slots of 8 rows per thread, workgroups}.
@@ -325,13 +336,19 @@ typedef struct octane_nav {      /* the GOESNAVVar fields oct_pix2uv_cuda.cu rea
 #define OCTANE_NAV_GEOS  0   /* GOES-R fixed grid (default)   */
 #define OCTANE_NAV_POLAR 1   /* -Polar                         */
 #define OCTANE_NAV_MERC  2   /* -Merc                          */
-/* Or into `mode`: run the build of the navigation kernel in which a * b + c is fused wherever the compiler may (float and double), as
- * nvcc's default -fmad=true builds the reference's kernel (ref src/Makefile sets no -fmad flag; ref p2u:40-44 xi * xScale + xOffset and
- * the projection formulas).  Without it every product and sum is rounded on its own -- the build the oracle's strict flavour and the
- * bit-exactness tests are defined on.  The two differ in 2.3 % of the navigated shorts, by 1 cm/s (profiles/r4_pix2uv_fmad_exposure.txt);
- * which of them a given CUDA build of the reference equals depends on that build's flags and cannot be checked here (no CUDA).
- * OCTANE_PIX2UV_FMAD=0|1 in the environment overrides (the C++ shim oct_pix2uv_cuda has no argument for it). */
-#define OCTANE_NAV_FMAD  0x100
+/* Or ONE of these into `mode`: which build of the navigation kernel runs.  nvcc's default -fmad=true builds the reference's kernel (ref
+ * src/Makefile:9,20,27 set no -fmad flag), so every a * b + c of ref p2u:13-25,40-44,99-118 MAY be one fused operation in the
+ * reference's binary.  Counted site by site on the oracle (tools/pix2uv_sites.py, profiles/r5_pix2uv_sites.txt; 13 sites, 50.7 M
+ * shorts): only the two FLOAT multiply-adds of the base position (xi * xScale + xOffset, yi * yScale + yOffset, ref p2u:40-41,99-100)
+ * move shorts -- 2.3 % of them, by 1 cm/s -- and the eleven double sites together move one short in 50.7 M.  Hence three builds:
+ *   (none)                  strict: every product and sum rounded on its own -- the oracle's strict flavour;
+ *   OCTANE_NAV_FMAD_FLOAT   strict + exactly the two float sites fused: what a -fmad=true CUDA build computes up to ~2e-8 of the
+ *                           shorts, whatever a compiler contracts elsewhere -- the default of the oct_pix2uv_cuda C++ shim;
+ *   OCTANE_NAV_FMAD         a * b + c fused wherever THIS compiler may (float and double; -ffp-contract=fast).
+ * Which of them a given CUDA build of the reference equals cannot be checked here (no CUDA); a reference built with -fmad=false is
+ * the first.  OCTANE_PIX2UV_FMAD=0|1|2 in the environment (strict | all | float sites) overrides mode and shim default alike. */
+#define OCTANE_NAV_FMAD        0x100
+#define OCTANE_NAV_FMAD_FLOAT  0x200
 /* Host buffers.  pixuv != 0 reproduces -pd (ur/vr = (short)(100*u), ur2/vr2 untouched).
  * *sector_moved is set to 1 when the x/yOffset guard (oct_pix2uv_cuda.cu:295) zeroed the outputs. */
 int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, const float *u, const float *v,

@@ -19,6 +19,7 @@ OK, E_INVALID, E_NODEVICE, E_HIP, E_TOOSMALL, E_NOMEM = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1
 NAV_GEOS, NAV_POLAR, NAV_MERC = 0, 1, 2
 NAV_FMAD = 0x100      # or into mode: the navigation kernel built with fused multiply-adds (include/octane_vof.h)
+NAV_FMAD_FLOAT = 0x200   # or into mode: the strict build with exactly the two float sites of the base position fused (the C++ shim's default)
 
 # the diagnostic library (make -C octane_amd/csrc DIAG=1: stamped copies of two kernels for tools/probe_stamps.py / probe_mid_stamps.py and
 # one GPU test; never the product) and what it exports on top of EXPORTS

@@ -88,7 +88,11 @@ void oct_pix2uv_cuda(GOESVar &g, double t2, float *uarr, float *varr, short *ur,
             dev = 0;
         }
     }
-    const int mode = args.dopolar == 1 ? OCTANE_NAV_POLAR : (args.domerc == 1 ? OCTANE_NAV_MERC : OCTANE_NAV_GEOS);
+    // Which build of the navigation kernel stands in for "the reference CUDA path": nvcc builds the reference's kernel with -fmad=true
+    // (ref src/Makefile:9,20,27), and of the 13 multiply-add sites that may fuse only the two float ones of the base position move any
+    // short (profiles/r5_pix2uv_sites.txt) -- the shim runs the strict build with exactly those two fused (include/octane_vof.h,
+    // OCTANE_NAV_FMAD_FLOAT; OCTANE_PIX2UV_FMAD=0 in the environment selects the unfused build, for a reference built with -fmad=false).
+    const int mode = (args.dopolar == 1 ? OCTANE_NAV_POLAR : (args.domerc == 1 ? OCTANE_NAV_MERC : OCTANE_NAV_GEOS)) | OCTANE_NAV_FMAD_FLOAT;
     float dT = 0.f;
     int moved = 0;
     const int rc = octane_pix2uv_run(&nav, g.t, t2, uarr, varr, args.pixuv, mode, ur, vr, ur2, vr2, &dT, &moved, dev);

@@ -13,6 +13,13 @@
 // are likelier the second kind's; tools/pix2uv_fmad_exposure.py counts what that is worth: 2.3 % of the navigated shorts differ by
 // 1 cm/s between the two builds of one source (profiles/r4_pix2uv_fmad_exposure.txt).  OCTANE_NAV_FMAD in `mode` (or
 // OCTANE_PIX2UV_FMAD=1 in the environment) selects the fused build.
+//
+// Round 5: WHICH multiply-adds decide the shorts was counted site by site on the oracle (tools/pix2uv_sites.py,
+// profiles/r5_pix2uv_sites.txt: 13 sites nvcc may fuse, 50.7 M shorts): only the two FLOAT sites of the base position -- xi * xScale +
+// xOffset, yi * yScale + yOffset, ref p2u:40-41,76-77,99-100 -- move anything (2.3 % of the shorts by 1 cm/s); the eleven double sites
+// together move ONE short in 50.7 M.  So "the reference CUDA path" has two candidate outputs, and the strict TU carries the second one
+// as a third instance: k_pix2uv<true> = the strict build with exactly those two sites as fmaf (launch_pix2uv_fsites,
+// OCTANE_NAV_FMAD_FLOAT), independent of what any compiler chooses to contract elsewhere.  It is what the oct_pix2uv_cuda shim runs.
 #include "vof_kernels.hpp"
 
 #ifdef PIX2UV_FMAD
@@ -34,6 +41,7 @@ __device__ static double great_circle(float lat1, float lon1, float lat2, float 
     return earthrad * c;
 }
 
+template <bool FSITES>
 __device__ static void navigate_pixel(const NavArgs &g, const double *rate, int xi, int yi, double dt,
                                       double *r, double DTOR, double DTOR2, int mode)
 {
@@ -42,8 +50,13 @@ __device__ static void navigate_pixel(const NavArgs &g, const double *rate, int 
     double latv[2], lonv[2], sds[2] = {0., 0.};
     for (int iv = 0; iv < 2; ++iv) {
         if (iv == 0) {
-            xVal = (xi)*g.xScale + g.xOffset;     // float arithmetic, as in the reference
-            yVal = (yi)*g.yScale + g.yOffset;
+            if (FSITES) {                          // the two float multiply-adds as ONE fused operation each (nvcc -fmad=true)
+                xVal = __builtin_fmaf((float)(xi), g.xScale, g.xOffset);
+                yVal = __builtin_fmaf((float)(yi), g.yScale, g.yOffset);
+            } else {
+                xVal = (xi)*g.xScale + g.xOffset;     // float arithmetic, as in the reference
+                yVal = (yi)*g.yScale + g.yOffset;
+            }
         } else {
             xVal = (rate[0] * dt + xi) * g.xScale + g.xOffset;
             yVal = (rate[1] * dt + yi) * g.yScale + g.yOffset;
@@ -104,6 +117,7 @@ __device__ static void navigate_pixel(const NavArgs &g, const double *rate, int 
     }
 }
 
+template <bool FSITES>
 __global__ __launch_bounds__(256) void k_pix2uv(NavArgs nav, double t1, double t2,
                                                 const float *__restrict__ u, const float *__restrict__ v, int mode,
                                                 short *__restrict__ ur, short *__restrict__ vr,
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(256) void k_pix2uv(NavArgs nav, double t1, double t
             double rate[2], wind[2];
             rate[0] = u1 / (t2 - t1);
             rate[1] = v1 / (t2 - t1);
-            navigate_pixel(nav, rate, ii + nav.minX, jj + nav.minY, t2 - t1, wind, rad, rad2, mode);
+            navigate_pixel<FSITES>(nav, rate, ii + nav.minX, jj + nav.minY, t2 - t1, wind, rad, rad2, mode);
             ur[k] = (short)(100 * (wind[0]));
             vr[k] = (short)(100 * (wind[1]));
         } else {
@@ -138,7 +152,18 @@ void launch_pix2uv(hipStream_t s, const NavArgs &nav, double t1, double t2, cons
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_pix2uv, dim3((unsigned)blocks), dim3(256), 0, s, nav, t1, t2, u, v, mode, ur, vr, ur2, vr2, n);
+    hipLaunchKernelGGL(k_pix2uv<false>, dim3((unsigned)blocks), dim3(256), 0, s, nav, t1, t2, u, v, mode, ur, vr, ur2, vr2, n);
 }
+
+#ifndef PIX2UV_FMAD
+void launch_pix2uv_fsites(hipStream_t s, const NavArgs &nav, double t1, double t2, const float *u, const float *v,
+                          int mode, short *ur, short *vr, short *ur2, short *vr2, long n)
+{
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_pix2uv<true>, dim3((unsigned)blocks), dim3(256), 0, s, nav, t1, t2, u, v, mode, ur, vr, ur2, vr2, n);
+}
+#endif
 
 }  // namespace octane

@@ -535,7 +535,7 @@ int assemble_grid_size(int w, int h)
 
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid)
 {
-    static const bool generic_only = [] { const char *e = getenv("OCTANE_TUNE_ASM_GENERIC"); return e && atoi(e) != 0; }();   // developer knob: A/B timing
+    static const bool generic_only = [] { const char *e = tune_env("OCTANE_TUNE_ASM_GENERIC"); return e && atoi(e) != 0; }();   // developer knob: A/B timing
     if (generic_only) { hipLaunchKernelGGL((k_assemble<0, -1, -1, -1>), dim3(grid), dim3(kAsmThreads), 0, s, L, P); return; }
     const int mode = P.al1 == 1.0 ? 0 : (P.al1 == 0.0 ? 2 : 1);
     const int z = P.dozim ? 1 : 0, hn = P.lambdac != 0.f ? 1 : 0;
@@ -585,7 +585,7 @@ int assemble_fast_math_bits(double alpha)
 {
     static std::mutex mu;
     static std::map<double, int> known;
-    if (const char *e = getenv("OCTANE_TUNE_ASM_FAST")) { if (atoi(e) == 0) return 0; }
+    if (const char *e = tune_env("OCTANE_TUNE_ASM_FAST")) { if (atoi(e) == 0) return 0; }
     if (!(alpha > 0.) || !std::isfinite(alpha)) return 0;
     std::lock_guard<std::mutex> g(mu);
     auto it = known.find(alpha);

@@ -4,8 +4,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace octane {
+
+// Environment knobs.  The PRODUCT library reads only the ones include/octane_vof.h documents (OCTANE_VOF_CACHE, OCTANE_VOF_BANDS,
+// OCTANE_TILED_TRANSPORT, OCTANE_TILED_SELFCHECK, OCTANE_MP_TIMEOUT_S, OCTANE_PIX2UV_FMAD, OCTANE_TUNE_MIN_BAND_PIXELS,
+// OCTANE_TUNE_PERSIST_MAXG and the bisect pair OCTANE_TUNE_Q_DMA / OCTANE_TUNE_PERSIST).  Every other OCTANE_TUNE_* variable is a
+// developer knob of the DIAGNOSTIC library (make DIAG=1, liboctane_vof_diag.so: what tools/ loads) and does not exist in the
+// product: a stray variable in a production environment cannot change which kernels run.
+inline const char *tune_env(const char *name)
+{
+#ifdef OCTANE_DIAG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // A 2-D float plane in HBM: w x h pixels, rows `pitch` floats apart (pitch % 64 == 0 for
 // planes the library owns, so every row starts on a 256-byte boundary).
@@ -185,6 +201,8 @@ struct NavArgs {
 void launch_pix2uv(hipStream_t s, const NavArgs &nav, double t1, double t2, const float *u, const float *v,
                    int mode, short *ur, short *vr, short *ur2, short *vr2, long n);
 // the same source compiled with fused multiply-adds, as nvcc's default -fmad=true builds the reference (pix2uv_kernel.hip)
+void launch_pix2uv_fsites(hipStream_t s, const NavArgs &nav, double t1, double t2, const float *u, const float *v,
+                          int mode, short *ur, short *vr, short *ur2, short *vr2, long n);   // strict build, the two float sites fused
 void launch_pix2uv_fmad(hipStream_t s, const NavArgs &nav, double t1, double t2, const float *u, const float *v,
                         int mode, short *ur, short *vr, short *ur2, short *vr2, long n);
 

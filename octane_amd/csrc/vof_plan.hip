@@ -264,35 +264,35 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     pl->pitch0 = round_up(nx, 64);
     pl->plane0 = (size_t)pl->pitch0 * ny;
     pl->tol = (float)(0.0001 * 0.0001);          // ref .cu:1353
-    if (const char *e = getenv("OCTANE_TUNE_MAXBLOCKS")) set_max_blocks(atoi(e));   // developer tuning knobs
-    if (const char *e = getenv("OCTANE_TUNE_REVERSE_B")) pl->reverse_b = atoi(e) != 0;
-    if (const char *e = getenv("OCTANE_TUNE_PASS_A")) set_pass_a_variant(atoi(e));
-    if (const char *e = getenv("OCTANE_TUNE_XCD")) pl->xcd_bands = atoi(e);
-    if (const char *e = getenv("OCTANE_TUNE_SMALL")) pl->use_small = atoi(e) != 0;
-    if (const char *e = getenv("OCTANE_TUNE_SMALL_MAX")) pl->small_max_pixels = atol(e);
-    if (const char *e = getenv("OCTANE_TUNE_NT")) pl->nt_hints = atoi(e);
-    if (const char *e = getenv("OCTANE_TUNE_DEFER_X")) pl->defer_x = atoi(e) != 0;
-    if (const char *e = getenv("OCTANE_TUNE_GRAPH")) pl->use_graph = atoi(e) != 0;
-    if (const char *e = getenv("OCTANE_TUNE_UNIT_W")) pl->use_unit_w = atoi(e) != 0;
-    if (const char *e = getenv("OCTANE_TUNE_FUSED")) pl->use_fused = atoi(e) != 0;
-    if (const char *e = getenv("OCTANE_TUNE_FUSED_ROWS")) set_fused_rows(atoi(e));
-    if (const char *e = getenv("OCTANE_TUNE_FUSED_Q")) set_fused_q(atoi(e));
-    if (const char *e = getenv("OCTANE_TUNE_FUSED_Q_MIN")) set_fused_q_min(atol(e));
+    if (const char *e = tune_env("OCTANE_TUNE_MAXBLOCKS")) set_max_blocks(atoi(e));   // developer tuning knobs
+    if (const char *e = tune_env("OCTANE_TUNE_REVERSE_B")) pl->reverse_b = atoi(e) != 0;
+    if (const char *e = tune_env("OCTANE_TUNE_PASS_A")) set_pass_a_variant(atoi(e));
+    if (const char *e = tune_env("OCTANE_TUNE_XCD")) pl->xcd_bands = atoi(e);
+    if (const char *e = tune_env("OCTANE_TUNE_SMALL")) pl->use_small = atoi(e) != 0;
+    if (const char *e = tune_env("OCTANE_TUNE_SMALL_MAX")) pl->small_max_pixels = atol(e);
+    if (const char *e = tune_env("OCTANE_TUNE_NT")) pl->nt_hints = atoi(e);
+    if (const char *e = tune_env("OCTANE_TUNE_DEFER_X")) pl->defer_x = atoi(e) != 0;
+    if (const char *e = tune_env("OCTANE_TUNE_GRAPH")) pl->use_graph = atoi(e) != 0;
+    if (const char *e = tune_env("OCTANE_TUNE_UNIT_W")) pl->use_unit_w = atoi(e) != 0;
+    if (const char *e = tune_env("OCTANE_TUNE_FUSED")) pl->use_fused = atoi(e) != 0;
+    if (const char *e = tune_env("OCTANE_TUNE_FUSED_ROWS")) set_fused_rows(atoi(e));
+    if (const char *e = tune_env("OCTANE_TUNE_FUSED_Q")) set_fused_q(atoi(e));
+    if (const char *e = tune_env("OCTANE_TUNE_FUSED_Q_MIN")) set_fused_q_min(atol(e));
     if (const char *e = getenv("OCTANE_TUNE_Q_DMA")) set_q_dma(atoi(e));
     if (const char *e = getenv("OCTANE_TUNE_PERSIST")) pl->use_persist = atoi(e) != 0;
-    if (const char *e = getenv("OCTANE_TUNE_PERSIST_STEP")) pl->persist_step = atoi(e);
-    if (const char *e = getenv("OCTANE_TUNE_PERSIST_P")) pl->persist_p = atoi(e);
-    if (const char *e = getenv("OCTANE_TUNE_PERSIST_MINP")) set_mid_min_p(atoi(e));
-    if (const char *e = getenv("OCTANE_TUNE_OVERLAP")) pl->use_overlap = atoi(e) != 0;
-    if (const char *e = getenv("OCTANE_TUNE_PERSIST_MAX")) pl->persist_max_pixels = atol(e);
+    if (const char *e = tune_env("OCTANE_TUNE_PERSIST_STEP")) pl->persist_step = atoi(e);
+    if (const char *e = tune_env("OCTANE_TUNE_PERSIST_P")) pl->persist_p = atoi(e);
+    if (const char *e = tune_env("OCTANE_TUNE_PERSIST_MINP")) set_mid_min_p(atoi(e));
+    if (const char *e = tune_env("OCTANE_TUNE_OVERLAP")) pl->use_overlap = atoi(e) != 0;
+    if (const char *e = tune_env("OCTANE_TUNE_PERSIST_MAX")) pl->persist_max_pixels = atol(e);
     if (const char *e = getenv("OCTANE_TUNE_PERSIST_MAXG")) pl->persist_max_g = atoi(e);
     {
         hipDeviceProp_t prop;
         pl->ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
     }
-    if (const char *e = getenv("OCTANE_TUNE_UNIT_W_CAP")) set_unit_w_cap(atoi(e));
+    if (const char *e = tune_env("OCTANE_TUNE_UNIT_W_CAP")) set_unit_w_cap(atoi(e));
     {
-        const char *ea = getenv("OCTANE_TUNE_CAP_A"), *eb = getenv("OCTANE_TUNE_CAP_B");
+        const char *ea = tune_env("OCTANE_TUNE_CAP_A"), *eb = tune_env("OCTANE_TUNE_CAP_B");
         if (ea || eb) set_pass_caps(ea ? atoi(ea) : 768, eb ? atoi(eb) : 1024);
     }
     pcg_small_configure();
@@ -342,9 +342,9 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     pl->has_bset = pl->use_overlap ? 1 : 0;
     const size_t nplanes = (size_t)(2 * nc + 2) + 2 * nc + 7 * nc + 6 + 17 + 1 + 6 + (pl->has_bset ? (size_t)(9 * nc + 2) : 0);
     size_t skew = 0;                              // developer knob: stagger the planes' base addresses (floats)
-    if (const char *e = getenv("OCTANE_TUNE_SKEW")) skew = (size_t)atol(e) / 64 * 64;
+    if (const char *e = tune_env("OCTANE_TUNE_SKEW")) skew = (size_t)atol(e) / 64 * 64;
     size_t align_f = 0;                           // developer knob: round the plane stride up to a multiple (bytes)
-    if (const char *e = getenv("OCTANE_TUNE_PLANE_ALIGN")) align_f = (size_t)atol(e) / 4;
+    if (const char *e = tune_env("OCTANE_TUNE_PLANE_ALIGN")) align_f = (size_t)atol(e) / 4;
     size_t stride = pl->plane0;
     if (align_f) stride = (stride + align_f - 1) / align_f * align_f;
     stride += skew;
@@ -434,9 +434,9 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     // candidate arenas are therefore allocated, a few PCG iterations are timed on each, the fastest is kept and the
     // others are freed.
     int trials = placement_trials;
-    if (const char *e = getenv("OCTANE_TUNE_PLACEMENT_TRIALS")) trials = atoi(e) < trials ? atoi(e) : trials;
+    if (const char *e = tune_env("OCTANE_TUNE_PLACEMENT_TRIALS")) trials = atoi(e) < trials ? atoi(e) : trials;
     constexpr int kMaxTrials = 8;
-    if (const char *e = getenv("OCTANE_TUNE_PLACEMENT_TRIALS_FORCE")) trials = atoi(e);       // experiments: more than the caller's default
+    if (const char *e = tune_env("OCTANE_TUNE_PLACEMENT_TRIALS_FORCE")) trials = atoi(e);       // experiments: more than the caller's default
     if (trials > kMaxTrials) trials = kMaxTrials;
     {   // the candidates exist side by side while they are timed: keep that within 48 GB
         const long fit = (long)(((size_t)48 << 30) / pl->arena_bytes);
@@ -447,11 +447,11 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         double ms[kMaxTrials] = {0};
         int ncand = 1;
         // experiment (OCTANE_TUNE_ARENA_CONTIG=1): odd candidates ask for physically contiguous memory
-        const bool try_contig = getenv("OCTANE_TUNE_ARENA_CONTIG") && atoi(getenv("OCTANE_TUNE_ARENA_CONTIG")) != 0;
+        const bool try_contig = tune_env("OCTANE_TUNE_ARENA_CONTIG") && atoi(tune_env("OCTANE_TUNE_ARENA_CONTIG")) != 0;
         for (int t = 1; t < trials; t++) {
             hipError_t ae = (try_contig && (t & 1)) ? hipExtMallocWithFlags((void **)&cand[t], pl->arena_bytes, hipDeviceMallocContiguous)
                                                     : hipMalloc((void **)&cand[t], pl->arena_bytes);
-            if (ae != hipSuccess && try_contig && (t & 1)) { (void)hipGetLastError(); ae = hipMalloc((void **)&cand[t], pl->arena_bytes); if (getenv("OCTANE_TUNE_VERBOSE")) fprintf(stderr, "[octane] contiguous candidate %d refused\n", t); }
+            if (ae != hipSuccess && try_contig && (t & 1)) { (void)hipGetLastError(); ae = hipMalloc((void **)&cand[t], pl->arena_bytes); if (tune_env("OCTANE_TUNE_VERBOSE")) fprintf(stderr, "[octane] contiguous candidate %d refused\n", t); }
             if (ae != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
             ncand = t + 1;
         }
@@ -461,7 +461,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
             ms[t] = probe_placement(pl);
             if (ms[t] > 0 && (ms[best] <= 0 || ms[t] < ms[best])) best = t;
         }
-        if (getenv("OCTANE_TUNE_VERBOSE")) {
+        if (tune_env("OCTANE_TUNE_VERBOSE")) {
             fprintf(stderr, "[octane] placement trials, ms per PCG iteration:");
             for (int t = 0; t < ncand; t++) fprintf(stderr, " %.4f@%p", ms[t], (void *)cand[t]);
             fprintf(stderr, " -> candidate %d\n", best);
@@ -1208,7 +1208,7 @@ extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const 
     // Beyond 64 Mpixel one lane.
     const long px = (long)nx * ny;
     int lanes = px <= (64L << 20) ? 2 : 1;
-    if (const char *e = getenv("OCTANE_TUNE_BATCH_LANES")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
+    if (const char *e = tune_env("OCTANE_TUNE_BATCH_LANES")) lanes = atoi(e) > 0 ? atoi(e) : lanes;
     const int nworkers = ndevices * lanes;
     std::vector<int> rcs(nworkers, OCTANE_OK);
     std::vector<std::string> errs(nworkers);
@@ -1246,9 +1246,10 @@ extern "C" int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, co
                                  int pixuv, int mode, short *ur, short *vr, short *ur2, short *vr2,
                                  float *dT, int *sector_moved, int device)
 {
-    bool fmad = (mode & OCTANE_NAV_FMAD) != 0;          // the kernel built with fused multiply-adds (pix2uv_kernel.hip)
-    mode &= ~OCTANE_NAV_FMAD;
-    if (const char *e = getenv("OCTANE_PIX2UV_FMAD")) fmad = atoi(e) != 0;
+    // which build of the kernel (pix2uv_kernel.hip): 0 strict, 1 every multiply-add the compiler may fuse, 2 the two float sites only
+    int build = (mode & OCTANE_NAV_FMAD) ? 1 : (mode & OCTANE_NAV_FMAD_FLOAT) ? 2 : 0;
+    mode &= ~(OCTANE_NAV_FMAD | OCTANE_NAV_FMAD_FLOAT);
+    if (const char *e = getenv("OCTANE_PIX2UV_FMAD")) build = (atoi(e) >= 0 && atoi(e) <= 2) ? atoi(e) : build;
     if (!nav || !u || !v || !ur || !vr || nav->nx < 1 || nav->ny < 1 || mode < 0 || mode > 2 ||
         (pixuv == 0 && (!ur2 || !vr2))) {
         g_last_error = "octane_pix2uv_run: invalid argument";
@@ -1289,7 +1290,7 @@ extern "C" int octane_pix2uv_run(const octane_nav *nav, double t1, double t2, co
         a.xScale = nav->xScale; a.xOffset = nav->xOffset; a.yScale = nav->yScale; a.yOffset = nav->yOffset;
         a.lat1 = nav->lat1; a.lon1 = nav->lon1; a.lon0 = nav->lon0; a.R = nav->R;
         a.minX = nav->minX; a.minY = nav->minY; a.nx = nav->nx; a.ny = nav->ny;
-        (fmad ? launch_pix2uv_fmad : launch_pix2uv)(s, a, t1, t2, du, dv, mode, dout, dout + n, dout + 2 * n, dout + 3 * n, n);
+        (build == 1 ? launch_pix2uv_fmad : build == 2 ? launch_pix2uv_fsites : launch_pix2uv)(s, a, t1, t2, du, dv, mode, dout, dout + n, dout + 2 * n, dout + 3 * n, n);
         if (hipGetLastError() != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMemcpyAsync(ur, dout, n * sizeof(short), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
         if (hipMemcpyAsync(vr, dout + n, n * sizeof(short), hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OCTANE_E_HIP; break; }
@@ -1729,6 +1730,7 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "persist_max_g") pl->persist_max_g = value;
     else if (k == "lane_mode") { if (value) plan_lane_mode(pl); else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 1536; } }
     else if (k == "fused_rows") set_fused_rows(value);
+    else if (k == "asm_fast") pl->asm_fast = value ? assemble_fast_math_bits(pl->prm.alpha) : 0;    // 0: IEEE divisions throughout (same bits)
     else return OCTANE_E_INVALID;
     return OCTANE_OK;
 }

@@ -988,6 +988,105 @@ extern "C" int octane_vof_tiled_run(octane_vof_tiled *t, const float *img1, cons
     return rc;
 }
 
+#ifdef OCTANE_DIAG
+// ---- solo-band timing (diagnostic library only; round 5) --------------------------------------------------------
+// The pool this is developed on gives one GPU per box, so an N-GPU solve of one frame cannot be timed.  What CAN be measured on
+// hardware is the compute term of the scaling model: band b's OWN launch sequence of an N-band solve -- the replicated level set-ups and
+// coarse levels, its band's assemblies, PCG launches, flow updates, event records at every phase boundary -- with the neighbours' rows
+// and partial blocks left static (every "other band" is mapped onto this band's own arena and partial block: the kernels read the
+// same number of bytes from the same row offsets they would read from a neighbour, only the values are wrong).  Wrong flow, right
+// timeline.  The arena is zeroed first (the creation poison is NaN: a NaN in a halo row would trip the stop test and empty the launches),
+// and the run is only a measurement if every solve ran its full iteration count, which is returned for the caller to check.
+// What it cannot show: the cost of waiting for the slowest band at a boundary, xGMI latency of the in-kernel peer reads, and the
+// peer copies (their bytes are counted and returned for tools/tiled_model.py to price).
+struct SoloNet : BandNet {
+    octane_vof_plan *pl = nullptr;
+    double *mir = nullptr;
+    hipEvent_t ev = nullptr;
+    int band = 0, rc = OCTANE_OK;
+    bool bad = false;
+    std::string error;
+    long long peer_bytes = 0, boundaries = 0;
+    octane_vof_plan *plan(int) override { return pl; }
+    bool failed() override { return bad; }
+    void fail(int, int code, const std::string &msg) override { if (!bad) { bad = true; rc = code; error = msg; } }
+    double *mirror(int) override { return mir; }
+    void sync(int b) override
+    {   // what a boundary costs THIS band's host thread and stream when nobody is late: record, then a wait that is already satisfied
+        BandNet &N = *this;
+        boundaries++;
+        BAND_HIP(hipEventRecord(ev, pl->own_stream));
+        BAND_HIP(hipStreamWaitEvent(pl->own_stream, ev, 0));
+    }
+    hipError_t copy(int, void *, int, const void *, size_t bytes) override { peer_bytes += (long long)bytes; return hipSuccess; }   // would cross xGMI: counted, not made
+    hipError_t pull(int, void *, int, const void *, size_t bytes) override { peer_bytes += (long long)bytes; return hipSuccess; }
+};
+
+extern "C" int octane_vof_solo_band_time(int nx, int ny, int nchan, const octane_vof_params *p, int nbands, int band, long long min_band_pixels,
+                                         const float *img1, const float *img2, int mem, int reps, double *ms_out,
+                                         long long *iterations, long long *peer_copy_bytes, long long *boundaries, int *banded_levels,
+                                         int *band_rows_finest)
+{
+    if (!p || !img1 || !img2 || !ms_out || nbands < 1 || nbands > kMaxBands || band < 0 || band >= nbands || reps < 1) return OCTANE_E_INVALID;
+    octane_vof_plan *pl = nullptr;
+    int rc = plan_create_ex(&pl, nx, ny, nchan, p, 8, true);
+    if (rc != OCTANE_OK) return rc;
+    SoloNet N;
+    N.pl = pl; N.band = band; N.nb = nbands; N.prm = *p;
+    std::vector<std::vector<BandRows>> rows(pl->lev.size());
+    const long minpix = min_band_pixels > 0 ? (long)min_band_pixels : kDefaultMinBandPixels;
+    int nbanded = 0;
+    for (size_t k = 0; k < pl->lev.size(); k++) {
+        const LevelInfo &li = pl->lev[k];
+        int edges[kMaxBands + 1];
+        if ((long)li.w * li.h < minpix || octane_vof_band_partition(li.h, nbands, edges) != 1) continue;
+        std::vector<BandRows> r(nbands);
+        for (int b = 0; b < nbands; b++) { r[b].y0 = edges[b]; r[b].y1 = edges[b + 1]; }
+        rows[k] = r; nbanded++;
+    }
+    N.rows = &rows;
+    double *parts = nullptr;
+    auto cleanup = [&]() {
+        if (parts) (void)hipFree(parts);
+        if (N.mir) (void)hipFree(N.mir);
+        if (N.ev) (void)hipEventDestroy(N.ev);
+        octane_vof_plan_destroy(pl);
+    };
+    if (hipSetDevice(pl->device) != hipSuccess ||
+        hipMalloc((void **)&parts, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
+        hipMemset(parts, 0, (size_t)2 * kPartBlock * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&N.mir, (size_t)nbands * 2 * kPartBlock * sizeof(double)) != hipSuccess ||
+        hipMemset(N.mir, 0, (size_t)nbands * 2 * kPartBlock * sizeof(double)) != hipSuccess ||
+        hipEventCreateWithFlags(&N.ev, hipEventDisableTiming) != hipSuccess ||
+        hipMemset(pl->arena, 0, pl->arena_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        set_last_error("octane_vof_solo_band_time: device allocation failed");
+        cleanup();
+        return OCTANE_E_NOMEM;
+    }
+    for (int c = 0; c < kMaxBands; c++) { N.arena[c] = reinterpret_cast<char *>(pl->arena); N.parts[c] = parts; }
+    N.transport = OCTANE_TRANSPORT_INPLACE;
+    rc = plan_load_inputs(pl, img1, img2, nullptr, nullptr, mem, pl->own_stream);
+    if (rc == OCTANE_OK && hipStreamSynchronize(pl->own_stream) != hipSuccess) rc = OCTANE_E_HIP;
+    for (int r = 0; r < reps && rc == OCTANE_OK; r++) {
+        N.peer_bytes = 0; N.boundaries = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        band_worker(N, band);
+        if (band != 0) (void)hipMemcpyAsync(pl->h_iters, pl->d_iters, sizeof(long long), hipMemcpyDeviceToHost, pl->own_stream);
+        if (hipStreamSynchronize(pl->own_stream) != hipSuccess) rc = OCTANE_E_HIP;
+        ms_out[r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (N.bad) { set_last_error("octane_vof_solo_band_time: " + N.error); rc = N.rc; }
+        if (rc == OCTANE_OK && persist_check(pl) != OCTANE_OK) rc = OCTANE_E_HIP;
+    }
+    if (iterations) *iterations = rc == OCTANE_OK ? *pl->h_iters : -1;
+    if (peer_copy_bytes) *peer_copy_bytes = N.peer_bytes;
+    if (boundaries) *boundaries = N.boundaries;
+    if (banded_levels) *banded_levels = nbanded;
+    if (band_rows_finest) *band_rows_finest = rows.back().empty() ? pl->lev.back().h : rows.back()[band].y1 - rows.back()[band].y0;
+    cleanup();
+    return rc;
+}
+#endif
+
 // =====================================================================================================================
 // One band per PROCESS (the one-process-per-GPU launch): octane_vof_mp_*.
 //

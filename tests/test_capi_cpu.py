@@ -299,3 +299,23 @@ def test_the_checker_catches_a_wait_that_is_too_weak(tmp_path, loads, wait, cond
     ok, lines, nk = chk.check(obj)
     print("\n".join(lines))
     assert nk == 1 and ok == safe, lines
+
+
+def test_product_library_reads_only_the_documented_environment_variables():
+    """Round 5: the ~30 OCTANE_TUNE_* tuning variables of rounds 1-4 exist in the diagnostic library only.  The product
+    library's text may name exactly the variables include/octane_vof.h documents -- a stray variable in a production environment cannot
+    change which kernels run."""
+    import re
+    import subprocess
+    from octane_amd import capi
+    allowed = {"OCTANE_VOF_CACHE", "OCTANE_TILED_TRANSPORT", "OCTANE_TILED_SELFCHECK", "OCTANE_MP_TIMEOUT_S", "OCTANE_PIX2UV_FMAD",
+               "OCTANE_TUNE_MIN_BAND_PIXELS", "OCTANE_TUNE_PERSIST_MAXG", "OCTANE_TUNE_Q_DMA", "OCTANE_TUNE_PERSIST"}
+    txt = subprocess.run(["strings", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = set(re.findall(r"^(OCTANE_[A-Z0-9_]+)$", txt, re.M))
+    assert names == allowed, sorted(names ^ allowed)
+    header = open(os.path.join(ROOT, "include", "octane_vof.h")).read()
+    for n in allowed:
+        assert n in header, n
+    if os.path.exists(capi.DIAG_LIB_PATH):       # the tuning variables live on in the diagnostic build
+        dtxt = subprocess.run(["strings", capi.DIAG_LIB_PATH], capture_output=True, text=True, check=True).stdout
+        assert len(set(re.findall(r"^(OCTANE_TUNE_[A-Z0-9_]+)$", dtxt, re.M))) > 25

@@ -33,20 +33,19 @@ def test_fast_forms_are_used_only_where_they_are_exact_on_every_float(capi, alph
 
 
 def test_fast_forms_do_not_change_a_bit_of_the_flow(capi):
-    """Same pair, the assembly with and without the fast forms (OCTANE_TUNE_ASM_FAST=0: IEEE divisions throughout), all three GNC steps,
+    """Same pair, the assembly with and without the fast forms (tune("asm_fast", 0): IEEE divisions throughout), all three GNC steps,
     Zimmer and Brox data terms: the flows have to be the same bits (the coefficient planes are compared with the oracle bit for bit in
     test_gpu_parity.py, which runs with the fast forms on)."""
     nx, ny = 333, 217
     a, b = synth.lattice_scene(nx, ny, seed=44)
     for prm in (dict(kiters=3, liters=2, cgiters=10), dict(kiters=2, liters=1, cgiters=8, dozim=0, alpha=12.0, lambda_=0.25)):
         outs = []
-        for fast in ("1", "0"):
-            os.environ["OCTANE_TUNE_ASM_FAST"] = fast
+        for fast in (1, 0):
+            pl = capi.Plan(nx, ny, 1, capi.FlowParams(**prm))
             try:
-                pl = capi.Plan(nx, ny, 1, capi.FlowParams(**prm))
+                pl.tune("asm_fast", fast)
                 outs.append(pl.run_host(a, b))
-                pl.close()
             finally:
-                del os.environ["OCTANE_TUNE_ASM_FAST"]
+                pl.close()
         assert np.isfinite(outs[0][0]).all()
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), prm

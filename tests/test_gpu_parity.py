@@ -311,19 +311,17 @@ def test_deferred_x_update_is_bitwise_identical(capi, cgiters):
     """Pass B applies x += alpha p for two iterations at once (every second launch) in the reference's order of
     operations; the result must equal the every-iteration form bit for bit, for even and odd iteration counts
     (an odd count leaves one update pending for the flow-update kernel)."""
-    import os
     nx, ny = 310, 240           # finest level above the single-workgroup solver's size
     a, b = synth.lattice_scene(nx, ny, seed=17)
     prm = capi.FlowParams(kiters=2, liters=1, cgiters=cgiters)
     outs = []
-    for mode in ("0", "1"):
-        os.environ["OCTANE_TUNE_DEFER_X"] = mode
+    for mode in (0, 1):
+        pl = capi.Plan(nx, ny, 1, prm)
         try:
-            pl = capi.Plan(nx, ny, 1, prm)
+            pl.tune("defer_x", mode)       # (until round 4 an environment variable; the product library no longer reads the tuning variables)
             outs.append(pl.run_host(a, b))
-            pl.close()
         finally:
-            del os.environ["OCTANE_TUNE_DEFER_X"]
+            pl.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 

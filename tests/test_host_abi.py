@@ -88,9 +88,20 @@ def test_cpp_host_path_equals_the_python_binding(host_demo, capi, tmp_path):
     assert np.array_equal(u, ue) and np.array_equal(v, ve)
     nav = capi.Nav(pph=35786023.0, req=6378137.0, rpol=6356752.31414, lam0=-1.308996939, xScale=5.6e-05, xOffset=-0.101332,
                    yScale=-5.6e-05, yOffset=0.128212, g2xOffset=-0.101332, g2yOffset=0.128212, nx=nx, ny=ny)
-    want = capi.pix2uv(nav, 1000.0, 1300.0, ue, ve)
+    # the shim navigates with the strict build + the two float multiply-adds of the base position fused (what nvcc's -fmad=true makes of
+    # the reference's kernel, include/octane_vof.h OCTANE_NAV_FMAD_FLOAT) ...
+    want = capi.pix2uv(nav, 1000.0, 1300.0, ue, ve, 0, capi.NAV_GEOS | capi.NAV_FMAD_FLOAT)
     for i in range(4):
         assert np.array_equal(shorts[i], want[i])
+    # ... and OCTANE_PIX2UV_FMAD=0 in the environment makes it the unfused build (a reference compiled with -fmad=false)
+    import os
+    r = subprocess.run([host_demo, "--run", str(nx), str(ny), str(inp), str(outp), "-i1", "x", "-i2", "y", "-kiters", "3", "-alpha", "6"],
+                       capture_output=True, text=True, env=dict(os.environ, OCTANE_PIX2UV_FMAD="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    shorts0 = np.frombuffer(open(outp, "rb").read(), np.int16, 4 * n, 8 * n).reshape(4, ny, nx)
+    strict = capi.pix2uv(nav, 1000.0, 1300.0, ue, ve)
+    for i in range(4):
+        assert np.array_equal(shorts0[i], strict[i])
 
 
 @pytest.mark.gpu

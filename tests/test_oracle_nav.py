@@ -112,3 +112,33 @@ def test_projected_navigation_known_answers(oracle):
         xScale=10000.0, xOffset=0.0, yScale=10000.0, yOffset=0.0, lon0=-45.0, lat1=90.0, R=R, donav=1, mode=1, minx=0, maxx=3, miny=0, maxy=3))
     assert np.isnan(far[1][0, 0])                                          # 7000 km from the pole on the plane: off the disc
     assert not p[3].any() and np.array_equal(p[4], x) and np.array_equal(p[5], y)
+
+
+def test_pix2uv_fma_site_switches(oracle):
+    """Round 5: every multiply-add of the navigation that nvcc's -fmad=true may fuse is an explicit switch of the oracle
+    (oracle/pix2uv_oracle.c).  No site fused = the strict build's shorts (what every earlier test pins); the two float sites of the base
+    position fused = what the compiler-contracted flavour gives (gcc fuses the double sites too: they move nothing here); each float site
+    alone moves some shorts, by 1 cm/s; the eleven double sites together move none on this frame."""
+    nx, ny = 300, 200
+    nav = _nav(oracle, nx, ny)
+    rng = np.random.RandomState(4)
+    u = (rng.randn(ny, nx) * 3).astype(np.float32)
+    v = (rng.randn(ny, nx) * 3).astype(np.float32)
+    assert oracle.lib().oct_oracle_pix2uv_nsites() == len(oracle.P2U_SITES)
+    base = oracle.pix2uv(nav, 0.0, 300.0, u, v)
+    same = oracle.pix2uv(nav, 0.0, 300.0, u, v, sites=0)
+    fl = oracle.pix2uv(nav, 0.0, 300.0, u, v, sites=oracle.P2U_FLOAT_SITES)
+    al = oracle.pix2uv(nav, 0.0, 300.0, u, v, sites=oracle.P2U_ALL_SITES)
+    dbl = oracle.pix2uv(nav, 0.0, 300.0, u, v, sites=oracle.P2U_ALL_SITES & ~oracle.P2U_FLOAT_SITES)
+    gcc = oracle.pix2uv(nav, 0.0, 300.0, u, v, flavour="fma")
+
+    def diff(a, b):
+        return int((a[0] != b[0]).sum() + (a[1] != b[1]).sum())
+    assert diff(same, base) == 0 and diff(dbl, base) == 0
+    assert 0 < diff(fl, base) < 0.06 * 2 * nx * ny
+    assert diff(al, fl) == 0 and diff(gcc, fl) == 0
+    for k in (0, 1):
+        one = oracle.pix2uv(nav, 0.0, 300.0, u, v, sites=1 << k)
+        assert diff(one, base) > 0
+        assert max(np.abs(one[0].astype(int) - base[0]).max(), np.abs(one[1].astype(int) - base[1]).max()) == 1
+    assert np.array_equal(oracle.pix2uv(nav, 0.0, 300.0, u, v)[0], base[0])        # the switch does not stick

@@ -1,5 +1,6 @@
 """Slots per thread of the persistent mid-level solve: time per PCG iteration of a one-level solve with sub-domains of at least 1 / 2 / 4 slots
 of 8 rows (OCTANE_TUNE_PERSIST_MINP), and the distance of each result to the CPU oracle (the checker).   usage: mid_minp.py [size ...]"""
+import os; os.environ.setdefault("OCTANE_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "octane_amd", "liboctane_vof_diag.so"))  # the OCTANE_TUNE_* tuning variables exist in the diagnostic library only (round 5)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 """Level setup on a side stream (OCTANE_TUNE_OVERLAP=1, the default) against everything on one stream: ms per pyramid and whether the flow has the same bits.
 usage: overlap_ab.py [size kiters [nchan [lambdac]]] ..."""
+import os; os.environ.setdefault("OCTANE_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "octane_amd", "liboctane_vof_diag.so"))  # the OCTANE_TUNE_* tuning variables exist in the diagnostic library only (round 5)
 import os, sys, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("OCTANE_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "octane_amd", "liboctane_vof_diag.so"))  # the OCTANE_TUNE_* tuning variables exist in the diagnostic library only (round 5)
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch

@@ -4,6 +4,7 @@ alpha, ...) and with IEEE divisions throughout (OCTANE_TUNE_ASM_FAST=0); each in
 With --nc the same for 1, 2 and 3 channels (round 4: template instances for two and three channels; OCTANE_TUNE_ASM_GENERIC=1 forces
 the generic instance, any channel count and every switch at run time, for the comparison).
 usage: time_assembly.py [--nc] [size ...]"""
+import os; os.environ.setdefault("OCTANE_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "octane_amd", "liboctane_vof_diag.so"))  # the OCTANE_TUNE_* tuning variables exist in the diagnostic library only (round 5)
 import json
 import os
 import subprocess
