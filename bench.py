@@ -14,10 +14,14 @@ fresh child processes, before this process has touched the GPU) and exits with t
 driver's launch) the ranks come from the environment and --gpus has to agree with WORLD_SIZE.
 
 The JSON line also carries
-  value_with_transfers -- SURVEY 8d's primary metric: one oct_variational_optical_flow-shaped call on HOST buffers
-                   (H2D + all levels + D2H through octane_vof_run), pageable and pinned; never `value`;
+  value_drop_in -- SURVEY 8d's primary metric, the drop-in call: one oct_variational_optical_flow-shaped call on the caller's pageable
+                   HOST buffers without a first guess (H2D + all levels + D2H through octane_vof_solve); never `value`;
+  value_with_transfers -- the same call in its other forms (with a first guess, pinned buffers);
+  secondary_multi_gpu -- N > 1 only: after the pair headline the same ranks measure BASELINE.json configs[3] (one 10848^2 frame, one
+                   row band per rank, with its transport block and parity against the plain plan) and configs[4] (64 pairs of
+                   2000^2 sharded) as bounded, non-fatal side legs;
   placement_trials -- min / median / max over the candidate arenas the plan timed when it was created (the headline is a
-                   best-of-n-placements figure).  A trial is a few PCG launches with the stop test held open
+                   best-of-n-placements figure, EXPERIMENTS.md 8).  A trial is a few PCG launches with the stop test held open
                    (varying weights, x work every second launch: 64 B/pixel), each timed by an event pair;
   roofline      -- dominant kernel (the fused, q-recomputing PCG iteration at the finest level, k_pcg_fused_q_dma): its
                    algorithmic bytes per launch (r p a1 a2 a4 wx wy read, r p written = 52 B/pixel; every second launch
@@ -155,7 +159,7 @@ def pair_lanes(args, capi, shard, synth, torch, dist, world, rank, dev, n, prm):
         dist.destroy_process_group()
 
 
-def batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev):
+def batch64_leg(args, capi, shard, synth, torch, dist, world, rank, local, dev):
     """BASELINE.json configs[4]: 64 independent 2000x2000 pairs (kiters=6) over the ranks, pair b on rank b % world;
     each GPU runs two lanes (two plans, each on its private stream, one host thread each) so one pair's
     latency-bound coarse levels overlap the others' bandwidth-bound fine levels.  Strong scaling: the work is fixed
@@ -212,15 +216,23 @@ def batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         step()
     barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev if os.environ.get("OCTANE_BENCH_BACKEND", "nccl") == "nccl" else None)
+    for p in plans:
+        p.close()
+    if rank != 0:
+        return None
+    return {"metric": "Mpix/s (full pyramid), batch of 64 pairs of 2000x2000", "value": round(npairs * n * n * args.steps / elapsed / 1e6, 3),
+            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"64 independent 2000x2000 pairs, kiters=6 liters={args.liters} cgiters={args.cgiters} "
+                                   f"(BASELINE.json configs[4]); pair b on rank b % {world}, {lanes} lanes per GPU",
+                       "sharding": "independent pairs, no data-path collective"},
+            "roofline": None, "cpu_baseline": None}
+
+
+def batch64(args, capi, shard, synth, torch, dist, world, rank, local, dev):
+    out = batch64_leg(args, capi, shard, synth, torch, dist, world, rank, local, dev)
     if rank == 0:
-        out = {"metric": "Mpix/s (full pyramid), batch of 64 pairs of 2000x2000", "value": round(npairs * n * n * args.steps / elapsed / 1e6, 3),
-               "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"64 independent 2000x2000 pairs, kiters=6 liters={args.liters} cgiters={args.cgiters} "
-                                      f"(BASELINE.json configs[4]); pair b on rank b % {world}, {lanes} lanes per GPU",
-                          "sharding": "independent pairs, no data-path collective"},
-               "roofline": None, "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -320,8 +332,11 @@ def tiled(args, capi, synth, torch):
     print(json.dumps(out), flush=True)
 
 
-def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
-    """BASELINE.json configs[3] under the one-process-per-GPU launch (torchrun): rank r owns row band r of the ONE frame
+def tiled_mp_leg(args, capi, shard, synth, torch, dist, world, rank, local, dev):
+    """Returns (the JSON object on rank 0 / None elsewhere, exit code: 0 ok, 3 no transport reproduces the plain plan, 4 the timed solves
+    are not valid).  Collective: every rank walks the same control flow whatever happens.
+
+    BASELINE.json configs[3] under the one-process-per-GPU launch (torchrun): rank r owns row band r of the ONE frame
     (octane_vof_mp_*).  torch.distributed carries the rendezvous, the handle all-gather, the timing -- and, registered with the
     library as its collective transport (octane_amd/exchange.py: backend nccl = RCCL over xGMI on device buffers, gloo staged through
     the host), the bands' exchange itself whenever HIP IPC mappings are not available or the first-contact self-check finds the
@@ -329,6 +344,11 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
     is timed, and the bench falls back (copy, then collective) by itself instead of failing.  Every rank holds the whole pair."""
     from octane_amd import exchange as xch
     n = args.size
+    t_leg = time.perf_counter()
+
+    def note(msg):      # progress on stderr: a leg that hangs on a node has to say where (rank 0 speaks for all)
+        if rank == 0:
+            print(f"bench.py tiled [{time.perf_counter() - t_leg:6.1f} s] {msg}", file=sys.stderr, flush=True)
     a, b = synth.lattice_scene(n, n, seed=TILED_SEED, device=dev)          # same seed on every rank: the same frame
     u = torch.zeros(n, n, device=dev)
     v = torch.zeros(n, n, device=dev)
@@ -349,6 +369,7 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         torch.cuda.synchronize()
         plain_its = pl.last_iterations()
         pl.close()
+    note(f"{n}x{n} frame on every rank, plain plan solved on rank 0 ({plain_its} iterations)")
     dist.barrier()
     ex = xch.TorchExchange(dev)
     first = os.environ.get("OCTANE_TILED_TRANSPORT")
@@ -362,8 +383,10 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         verdict = [None]
         try:
             mp = capi.MpPlan(n, n, 1, prm, rank, world, "/octane_bench_%s" % nonce[0], all_gather, exchange=ex)
+            note(f"band plans created and connected (transport {mp.transport_info()['transport_used']}, self-check {mp.transport_info()['selfcheck']})")
             mp.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr())
             torch.cuda.synchronize()
+            note("first banded solve done")
             info = mp.transport_info()
             if rank == 0:
                 parity = flow_distance(torch, (u, v), (pu, pv))
@@ -387,12 +410,9 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         if mp is not None:
             mp.close(); mp = None
     if not attempts[-1]["ok"]:
-        if rank == 0:
-            print(json.dumps({"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n), "value": None, "n_gpus": world,
-                              "error": "no transport reproduces the plain plan", "attempts": attempts}), flush=True)
         dist.barrier()
-        dist.destroy_process_group()
-        raise SystemExit(3)
+        return ({"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n), "value": None, "n_gpus": world,
+                 "error": "no transport reproduces the plain plan", "attempts": attempts} if rank == 0 else None), 3
     if rank == 0:
         del pu, pv
         info = mp.transport_info()
@@ -413,6 +433,7 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         mp.run_device(a.data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr())     # blocking and collective
     barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device=dev if os.environ.get("OCTANE_BENCH_BACKEND", "nccl") == "nccl" else None)
+    note(f"{args.steps} timed solves done: {elapsed * 1e3 / args.steps:.1f} ms each")
     # the verdict on the TIMED solves is formed on rank 0 before anything is printed and shared with every rank: a run whose last
     # solve was abandoned (-2) or ran another number of iterations than the configuration names reports no value and fails on all
     # ranks, as the thread form (tiled) does
@@ -422,6 +443,7 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         timed = [{"iterations": iters, "expected": expect,
                   "ok": bool(iters >= 0 and (iters == expect or args.allow_early_exit))}]
     dist.broadcast_object_list(timed, src=0)
+    out = None
     if rank == 0:
         workload = (f"{n}x{n} pair, kiters={args.kiters} liters={args.liters} cgiters={args.cgiters} nchan=1 alpha=5 "
                     f"lambda=1 (BASELINE.json configs[3]), {iters} PCG iterations per pyramid (expected {expect}); "
@@ -429,9 +451,9 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
         if not timed[0]["ok"]:
             print(f"bench.py tiled: the timed solves ran {iters} PCG iterations per pyramid, expected {expect}"
                   + (" (a persistent solve was abandoned)" if iters < 0 else ""), file=sys.stderr)
-            print(json.dumps({"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n), "value": None, "n_gpus": world,
-                              "error": "the timed solves are not valid: %d PCG iterations per pyramid, expected %d" % (iters, expect),
-                              "config": {"workload": workload}, "attempts": attempts}), flush=True)
+            out = {"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n), "value": None, "n_gpus": world,
+                   "error": "the timed solves are not valid: %d PCG iterations per pyramid, expected %d" % (iters, expect),
+                   "config": {"workload": workload}, "attempts": attempts}
         else:
             out = {"metric": "Mpix/s (full pyramid) at %dx%d, one frame as row bands" % (n, n),
                    "value": round(n * n * args.steps / elapsed / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -446,12 +468,20 @@ def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
                    "parity_vs_plain": {"rel_l2": attempts[-1]["rel_l2"], "bar": TILED_PARITY_BAR, "iterations_plain": plain_its,
                                        "iterations_banded": attempts[-1]["iterations_banded"], "ok": bool(attempts[-1]["ok"])},
                    "roofline": None, "cpu_baseline": None}
-            print(json.dumps(out), flush=True)
     mp.close()
     dist.barrier()
+    return out, (0 if timed[0]["ok"] else 4)
+
+
+def tiled_mp(args, capi, shard, synth, torch, dist, world, rank, local, dev):
+    """--workload tiled under torchrun: the leg above, printed; a run whose banded solve is not the plain plan's under any transport
+    (3) or whose timed solves are not valid (4) reports no value and fails on all ranks, as the thread form (tiled) does."""
+    out, code = tiled_mp_leg(args, capi, shard, synth, torch, dist, world, rank, local, dev)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     dist.destroy_process_group()
-    if not timed[0]["ok"]:
-        raise SystemExit(4)
+    if code:
+        raise SystemExit(code)
 
 
 def _free_port():
@@ -824,6 +854,7 @@ def main():
         except (OSError, ValueError):
             pass
 
+    out = None
     if rank == 0:
         dstate = device_state(torch, dev)
         if roof is not None and dstate.get("copy_1gib_gbs"):
@@ -831,7 +862,10 @@ def main():
             # algorithmic bytes per second over what a plain 1 GiB device copy (1 read + 1 write stream) delivered in this process
             roof["measured_copy_gbs"] = dstate["copy_1gib_gbs"]
             roof["frac_of_measured_copy"] = round(roof["achieved"] / dstate["copy_1gib_gbs"], 4)
-        out = {"metric": "Mpix/s (full pyramid) at %dx%d" % (n, n), "value": round(value, 3), "unit": "Mpix/s",
+        drop_in = None
+        if transfers:       # the call the reference's host code makes (pageable buffers, no first guess): octane_vof_solve as oct_optical_flow() calls it
+            drop_in = transfers["pageable"]["no_first_guess"]["mpix_s"]
+        out = {"metric": "Mpix/s (full pyramid, pair resident in HBM) at %dx%d" % (n, n), "value": round(value, 3), "unit": "Mpix/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
@@ -839,8 +873,11 @@ def main():
                                       f"alpha=5 lambda=1 ({run_name(n, args.kiters, args.liters, args.cgiters) if args.nchan == 1 else 'R1-shaped, NOT a BASELINE configuration: ' + str(args.nchan) + ' channels'}), "
                                       f"{iters} PCG iterations per pyramid (expected {expect}), one pair per GPU",
                           "sharding": "independent pairs, no data-path collective"},
-               # the whole call on host buffers (H2D + all levels + D2H): SURVEY 8d's primary metric; `value` above is the
-               # device-resident figure the bench contract asks for
+               # the drop-in call: one oct_variational_optical_flow-shaped call on the caller's pageable host buffers without a first guess
+               # (H2D + all levels + D2H through octane_vof_solve, what the oct_optical_flow() shim costs per pair): SURVEY 8d's primary
+               # metric, never `value` (which is device-resident, as the bench contract asks)
+               "value_drop_in": drop_in,
+               # the same call in its other forms (with a first guess uploaded, pinned buffers)
                "value_with_transfers": transfers,
                # SURVEY 8d's runs R2 and R3 (the metric string's "300 warps") on the same pair, 3 timed steps each; the headline stays R1
                "secondary": secondary,
@@ -848,9 +885,73 @@ def main():
                "placement_trials": trials_ms,
                "device": dstate,
                "roofline": roof, "cpu_baseline": cpu}
+    # N > 1: after the timed pair headline the same ranks measure the two multi-GPU configurations of BASELINE.json -- configs[3] (one
+    # full-disk frame, one row band per rank: the first time RCCL / IPC mappings see N real devices) and configs[4] (64 pairs sharded) --
+    # as bounded, NON-FATAL side legs: whatever happens in them, the headline line above is printed.
+    if world > 1 and not args.no_secondary and args.nchan == 1 and (args.kiters, args.liters, args.cgiters) == (8, 3, 30):
+        plan.close()
+        del a, b, u, v
+        torch.cuda.empty_cache()
+
+        def emit(side):
+            if rank == 0:
+                out["secondary_multi_gpu"] = side
+                print(json.dumps(out), flush=True)
+        side = multi_gpu_legs(args, capi, shard, synth, torch, dist, world, rank, local, dev, emit)
+        emit(side)
+    elif rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def multi_gpu_legs(args, capi, shard, synth, torch, dist, world, rank, local, dev, emit):
+    """The side legs of an N-rank default run.  Each leg is collective; a leg that raises on some rank is reported and ends the sequence
+    (the ranks may be out of step afterwards); a leg that HANGS (a rank gone inside a collective, a transport that never returns) is
+    ended by a watchdog after OCTANE_BENCH_SECONDARY_BUDGET_S seconds (default 300): rank 0 prints the headline with what finished,
+    and every rank leaves with exit code 0 -- the headline is a valid measurement whatever the side legs do."""
+    import threading
+    import types
+    budget = float(os.environ.get("OCTANE_BENCH_SECONDARY_BUDGET_S", "300"))
+    done = threading.Event()
+    result = {}
+
+    def watchdog():
+        if not done.wait(budget):
+            result["error"] = f"the multi-GPU side legs did not finish within {budget:.0f} s (a rank stuck inside a collective?); legs above this line finished"
+            try:
+                emit(dict(result))
+            finally:
+                os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    size3 = int(os.environ.get("OCTANE_BENCH_SECONDARY_TILED_SIZE", "10848"))
+    legs = (
+        ("configs3_one_frame_as_row_bands", lambda: tiled_mp_leg(types.SimpleNamespace(size=size3, kiters=8, liters=3, cgiters=30, steps=2, warmup=2, allow_early_exit=False),
+                                                                 capi, shard, synth, torch, dist, world, rank, local, dev)),
+        ("configs4_batch_of_64_pairs", lambda: (batch64_leg(types.SimpleNamespace(liters=3, cgiters=30, steps=2, warmup=1),
+                                                            capi, shard, synth, torch, dist, world, rank, local, dev), 0)),
+    )
+    for name, fn in legs:
+        mine_ok = True
+        t0 = time.perf_counter()
+        try:
+            leg, code = fn()
+        except (Exception, SystemExit) as e:
+            leg, code, mine_ok = {"error": f"rank {rank}: {type(e).__name__}: {e}"}, 1, False
+            print(f"bench.py: side leg {name} failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        flags = [None] * world
+        dist.all_gather_object(flags, (mine_ok, None if mine_ok else leg["error"]))
+        if rank == 0:
+            bad = [f[1] for f in flags if not f[0]]
+            if bad:
+                leg = {"error": "; ".join(bad)}
+            leg = dict(leg or {}, exit_code=code, leg_seconds=round(time.perf_counter() - t0, 1))
+            result[name] = leg
+        if not all(f[0] for f in flags):
+            break
+        torch.cuda.empty_cache()
+    done.set()
+    return result
 
 
 if __name__ == "__main__":

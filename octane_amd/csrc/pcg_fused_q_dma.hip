@@ -55,7 +55,7 @@
                         // folds the 7 x gridDim.x partial sums -- same order as the fold at the head of a launch, same bits -- and publishes seven doubles
                         // in the last slot of each kind; launch k + 1 loads those instead of folding 3584 values per workgroup.  Whole levels only.
                         // Arrival is counted in the `pad` word of the state slot this launch only reads (the next launch rewrites that slot: pad = 0).
-                        // Measured: DESIGN 8.  Off in the product.
+                        // Measured: EXPERIMENTS.md 8.  Off in the product.
 #endif
 #ifndef Q_ROT
 #define Q_ROT 1         // rotate the tile columns by the round number when the column count divides the grid

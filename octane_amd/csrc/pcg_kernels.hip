@@ -23,7 +23,7 @@
 //
 // Pass A comes in three forms chosen per level (pass_a_choice): a latency-oriented tiled form below 1 Mpixel, 128 x 16
 // tiles, and k_pcg_pass_a_ring, a marching form with 8 % instead of 30 % re-fetch that wins at 4-12 Mpixel only
-// (DESIGN.md 8).  The tiled and marching forms skip the wx / wy planes in the first GNC step, where every weight is -1,
+// (EXPERIMENTS.md 8).  The tiled and marching forms skip the wx / wy planes in the first GNC step, where every weight is -1,
 // and the tiled form can work on a row band of the level (vof_tiled.hip).
 // Also here: k_pcg_solve_small (a whole solve in one workgroup for the coarsest levels) and k_flow_update.
 #include "vof_kernels.hpp"
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256, 3) void k_pcg_pass_a_ring(LevelPtrs L, int k, 
 //          (r.z)_k = (r.z)_{k-1} - 2 alpha (q.z)_{k-1} + alpha^2 (q.M^-1 q)_{k-1}          (M^-1 is diagonal)
 //          (r.r)_k = (r.r)_{k-1} - 2 alpha (r.q)_{k-1} + alpha^2 (q.q)_{k-1}
 // are plain algebra on sums the previous kernel can form while it has q in registers -- no symmetry or orthogonality of
-// the operator is assumed (the single-reduction CG variants that do assume it diverge here).  The base
+// the operator is assumed (the single-reduction CG variants that do assume it diverge here, EXPERIMENTS.md 8).  The base
 // values (r.z)_{k-1}, (r.r)_{k-1} are the DIRECT sums the previous kernel formed over the residual it wrote, so nothing
 // is chained: the recurrence value differs from a direct sum over r_k only by the rounding of r_k's elements (~1e-10
 // relative), far below what the reference's own float atomics do to the same numbers.  Element by element x, r, p and q
@@ -971,7 +971,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused(LevelPtrs L, int k, int npart
 //   phase 2   tile groups: q_k (stencil on the second LDS tile) and the seven partial sums; q_k is NOT stored
 // The second LDS tile has two buffers used alternately, so a tile costs two barriers, not three.  r_k and p_k leave with
 // streaming stores (nothing of a launch this size is still cached when the next one reads it); the file is built with
-// LLVM's max-ilp scheduling (Makefile).  What else was tried on this kernel, and what it did: DESIGN.md 8.
+// LLVM's max-ilp scheduling (Makefile).  What else was tried on this kernel, and what it did: EXPERIMENTS.md 8.
 // Everything else (scalars from the previous launch's sums, double-buffered r / partials, triple-buffered p, deferred x)
 // is k_pcg_fused's.  In row bands (BANDED) the two rows beyond a band edge are read from the neighbour's planes in place.
 // ---------------------------------------------------------------------------------------------------------------------

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(LevelPtrs L, AssembleP
       // The thread marches through kAsmRows consecutive rows.  Its 3 x 3 windows of u and v roll with it: the centre row becomes the
       // southern one, the northern the centre, and only the new northern row is loaded (the frame's last row mirrors: its "north" is
       // the row below it, which the window already holds).  And the north edge's psi'_s of one row is the south edge's of the next:
-      // Un(i, j) and Us(i, j + 1) are the same four squares added in the same order (the inner sums commute), see DESIGN 8.
+      // Un(i, j) and Us(i, j + 1) are the same four squares added in the same order (the inner sums commute), see EXPERIMENTS.md 8.
       float use = 0.f, us = 0.f, usw = 0.f, ue = 0.f, uc = 0.f, uw = 0.f, une = 0.f, un = 0.f, unw = 0.f;
       float vse = 0.f, vs = 0.f, vsw = 0.f, ve = 0.f, vc = 0.f, vw = 0.f, vne = 0.f, vn = 0.f, vnw = 0.f;
       float ps_south = 0.f;

@@ -430,7 +430,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     }
     // Placement trials.  Where the arena lands in physical memory decides how the concurrent streams of a PCG kernel
     // spread over the HBM channels: arenas come in two kinds, 0.41 or 0.45-0.46 ms per fused iteration at 5000^2, and
-    // consecutive allocations of one process tend to be of the same kind.  For large frames up to eight
+    // consecutive allocations of one process tend to be of the same kind (EXPERIMENTS.md 8).  For large frames up to eight
     // candidate arenas are therefore allocated, a few PCG iterations are timed on each, the fastest is kept and the
     // others are freed.
     int trials = placement_trials;

@@ -527,6 +527,7 @@ struct BandNet {
     int transport = OCTANE_TRANSPORT_INPLACE;
     bool no_dma = false;
     int brk = 0;       // diagnostic library only: OCTANE_TEST_BREAK_TRANSPORT, the drill of the self-check's downgrade
+    bool solo = false; // diagnostic library only: solo-band timing (SoloNet): the "neighbours' rows" are this band's own rows, mirrored at its edges
     float *peer(int c, int b, float *plane_of_b) const
     {
         return reinterpret_cast<float *>(arena[c] + (reinterpret_cast<char *>(plane_of_b) - arena[b]));
@@ -630,8 +631,12 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
     }
     const int up = b > 0 ? b - 1 : b, dn = b < nb - 1 ? b + 1 : b;
     const int rup = cp ? b : up, rdn = cp ? b : dn;    // whose planes the kernels read the rows beyond the band's edges from
-    L.ru_up = N.peer(rup, b, pl->ru); L.rv_up = N.peer(rup, b, pl->rv);
-    L.ru_dn = N.peer(rdn, b, pl->ru); L.rv_dn = N.peer(rdn, b, pl->rv);
+    // (solo-band timing, diagnostic library: every "other band" is this band's own arena; reading row y0 - k of the band above then means
+    // reading this band's row y0 - k + 2, i.e. its own edge rows again, and row y1 + k of the band below its row y1 + k - 2 -- the same
+    // number of bytes at the same distance from the edge, values that stay finite and move with the solve instead of never-written rows)
+    const ptrdiff_t sh_up = (N.solo && b > 0) ? (ptrdiff_t)2 * li.pitch : 0, sh_dn = (N.solo && b < nb - 1) ? -(ptrdiff_t)2 * li.pitch : 0;
+    L.ru_up = N.peer(rup, b, pl->ru) + sh_up; L.rv_up = N.peer(rup, b, pl->rv) + sh_up;
+    L.ru_dn = N.peer(rdn, b, pl->ru) + sh_dn; L.rv_dn = N.peer(rdn, b, pl->rv) + sh_dn;
     int maxrows = 0;
     for (int c = 0; c < nb; c++) maxrows = rows[c].y1 - rows[c].y0 > maxrows ? rows[c].y1 - rows[c].y0 : maxrows;
     // every band launches the same grids, so that the blocks hold the same number of partials (idle workgroups
@@ -644,19 +649,19 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
     L.q_form = (fused && pcg_fused_q_form(li.w, maxrows, li.h)) ? 1 : 0;
     if (fused && !L.q_form)   // q of the neighbouring bands' edge rows is read from their planes (both halves of the double buffer)
         for (int i = 0; i < 2; i++) {
-            L.qup_u[i] = N.peer(rup, b, L.qb_u[i]); L.qup_v[i] = N.peer(rup, b, L.qb_v[i]);
-            L.qdn_u[i] = N.peer(rdn, b, L.qb_u[i]); L.qdn_v[i] = N.peer(rdn, b, L.qb_v[i]);
+            L.qup_u[i] = N.peer(rup, b, L.qb_u[i]) + sh_up; L.qup_v[i] = N.peer(rup, b, L.qb_v[i]) + sh_up;
+            L.qdn_u[i] = N.peer(rdn, b, L.qb_u[i]) + sh_dn; L.qdn_v[i] = N.peer(rdn, b, L.qb_v[i]) + sh_dn;
         }
     if (L.q_form) {           // q is recomputed: r on the row beyond an edge, p on the two rows beyond it, wy of the row above the upper one
         for (int i = 0; i < 2; i++) {
-            L.rup_u[i] = N.peer(rup, b, L.rb_u[i]); L.rup_v[i] = N.peer(rup, b, L.rb_v[i]);
-            L.rdn_u[i] = N.peer(rdn, b, L.rb_u[i]); L.rdn_v[i] = N.peer(rdn, b, L.rb_v[i]);
+            L.rup_u[i] = N.peer(rup, b, L.rb_u[i]) + sh_up; L.rup_v[i] = N.peer(rup, b, L.rb_v[i]) + sh_up;
+            L.rdn_u[i] = N.peer(rdn, b, L.rb_u[i]) + sh_dn; L.rdn_v[i] = N.peer(rdn, b, L.rb_v[i]) + sh_dn;
         }
         for (int i = 0; i < 3; i++) {
-            L.pup_u[i] = N.peer(rup, b, L.pf_u[i]); L.pup_v[i] = N.peer(rup, b, L.pf_v[i]);
-            L.pdn_u[i] = N.peer(rdn, b, L.pf_u[i]); L.pdn_v[i] = N.peer(rdn, b, L.pf_v[i]);
+            L.pup_u[i] = N.peer(rup, b, L.pf_u[i]) + sh_up; L.pup_v[i] = N.peer(rup, b, L.pf_v[i]) + sh_up;
+            L.pdn_u[i] = N.peer(rdn, b, L.pf_u[i]) + sh_dn; L.pdn_v[i] = N.peer(rdn, b, L.pf_v[i]) + sh_dn;
         }
-        L.wy_up = N.peer(rup, b, pl->wy);
+        L.wy_up = N.peer(rup, b, pl->wy) + sh_up;
     }
 #ifdef OCTANE_DIAG
     // Drill of the self-check's downgrade (diagnostic library only, OCTANE_TEST_BREAK_TRANSPORT): bit 0 -- the in-place transport
@@ -1018,7 +1023,18 @@ struct SoloNet : BandNet {
         BAND_HIP(hipEventRecord(ev, pl->own_stream));
         BAND_HIP(hipStreamWaitEvent(pl->own_stream, ev, 0));
     }
-    hipError_t copy(int, void *, int, const void *, size_t bytes) override { peer_bytes += (long long)bytes; return hipSuccess; }   // would cross xGMI: counted, not made
+    // A send to a neighbouring band would cross xGMI: counted, not made.  The two rows of u, v a band SENDS per inner edge after a flow
+    // update are also what it would RECEIVE there: the same rows are copied into its own halo rows beyond that edge (a local copy of the
+    // same size), so that the next assembly reads a flow that moves with the band instead of the previous level's.  (Halo sends are two
+    // rows, < 1 MB; the flow bands gathered at the end of a level are whole bands and are only counted.)
+    hipError_t copy(int b, void *dst, int dband, const void *src, size_t bytes) override
+    {
+        peer_bytes += (long long)bytes;
+        if (bytes >= ((size_t)1 << 20) || (dband != b - 1 && dband != b + 1)) return hipSuccess;
+        char *halo = const_cast<char *>(static_cast<const char *>(src)) + (dband < b ? -(ptrdiff_t)bytes : (ptrdiff_t)bytes);
+        (void)dst;
+        return hipMemcpyAsync(halo, src, bytes, hipMemcpyDeviceToDevice, pl->own_stream);
+    }
     hipError_t pull(int, void *, int, const void *, size_t bytes) override { peer_bytes += (long long)bytes; return hipSuccess; }
 };
 
@@ -1032,7 +1048,7 @@ extern "C" int octane_vof_solo_band_time(int nx, int ny, int nchan, const octane
     int rc = plan_create_ex(&pl, nx, ny, nchan, p, 8, true);
     if (rc != OCTANE_OK) return rc;
     SoloNet N;
-    N.pl = pl; N.band = band; N.nb = nbands; N.prm = *p;
+    N.pl = pl; N.band = band; N.nb = nbands; N.prm = *p; N.solo = true;
     std::vector<std::vector<BandRows>> rows(pl->lev.size());
     const long minpix = min_band_pixels > 0 ? (long)min_band_pixels : kDefaultMinBandPixels;
     int nbanded = 0;

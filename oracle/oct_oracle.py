@@ -302,3 +302,54 @@ def srsal(u, v, cth):
     L.oct_oracle_srsal.restype = None
     L.oct_oracle_srsal(uu.ravel(), vv.ravel(), cc.ravel(), nx, ny, uo.ravel(), vo.ravel())
     return uo, vo
+
+
+# ---- the CROSS-CHECK build of the reference's CUDA translation units (oracle/Makefile `refhip`, oracle/ref_hip_wrap.cc) ------------
+# hipify-perl + hipcc on the reference's own kernel text, out of tree; a tool stand-in that pins nothing (the oracle stays "parity
+# unpinned") but the only independent witness of the restatement.  Needs a GPU to run; None where the library was not built.
+def refhip_path() -> str:
+    return os.path.join(_HERE, "_ref", "liboct_ref_hip.so")
+
+
+def refhip_lib():
+    p = refhip_path()
+    if not os.path.exists(p) and os.path.isdir("/root/reference/src"):
+        subprocess.call(["make", "-C", _HERE, "-s", "refhip"])
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    L.oct_refhip_vof.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, _F, _F, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.oct_refhip_pix2uv.argtypes = [C.c_double] * 4 + [C.c_float] * 10 + [C.c_int] * 4 + [C.c_double, C.c_double, _F, _F, C.c_int, C.c_int,
+                                                                                         _S, _S, _S, _S, C.POINTER(C.c_float), C.c_int]
+    return L
+
+
+def refhip_flow(img1, img2, prm: "FlowParams | None" = None, u0=None, v0=None, device: int = 0):
+    """The reference's own kernel (hipified) on the GPU: returns (u, v).  Prints what the reference prints."""
+    L = refhip_lib()
+    prm = prm or FlowParams()
+    a = np.ascontiguousarray(img1, dtype=np.float32)
+    b = np.ascontiguousarray(img2, dtype=np.float32)
+    if a.ndim == 2:
+        a, b = a[None], b[None]
+    nc, ny, nx = a.shape
+    u = np.zeros((ny, nx), np.float32) if u0 is None else np.array(u0, dtype=np.float32, order="C", copy=True)
+    v = np.zeros((ny, nx), np.float32) if v0 is None else np.array(v0, dtype=np.float32, order="C", copy=True)
+    p = prm.c()
+    L.oct_refhip_vof(a, b, nx, ny, nc, u, v, p.alpha, p.lambda_, p.lambdac, p.scaleF, 400.0, p.kiters, p.liters, p.cgiters, p.dozim, device)
+    return u, v
+
+
+def refhip_pix2uv(nav: Nav, t1: float, t2: float, u, v, pixuv: int = 0, mode: int = 0, device: int = 0):
+    L = refhip_lib()
+    u = np.array(u, np.float32, order="C", copy=True)
+    v = np.array(v, np.float32, order="C", copy=True)
+    n = u.size
+    ur, vr, ur2, vr2 = (np.zeros(n, np.int16) for _ in range(4))
+    dT = C.c_float()
+    L.oct_refhip_pix2uv(nav.pph, nav.req, nav.rpol, nav.lam0, nav.xScale, nav.xOffset, nav.yScale, nav.yOffset, nav.g2xOffset, nav.g2yOffset,
+                        nav.lat1, nav.lon1, nav.lon0, nav.R, nav.minX, nav.minY, nav.nx, nav.ny, t1, t2, u.ravel(), v.ravel(), pixuv, mode,
+                        ur, vr, ur2, vr2, C.byref(dT), device)
+    shp = u.shape
+    return ur.reshape(shp), vr.reshape(shp), ur2.reshape(shp), vr2.reshape(shp), dT.value

@@ -82,7 +82,7 @@ def test_product_library_carries_no_diagnostics(capi):
 
 def test_sub_domain_grid_of_the_persistent_solve(capi):
     """Host arithmetic only (no GPU): which grid of 64-column sub-domains the persistent mid-level solve takes on a 256-CU device.
-    The smallest slot count that fits; one- and two-slot sub-domains only up to 128 workgroups."""
+    The smallest slot count that fits; one- and two-slot sub-domains only up to 128 workgroups (EXPERIMENTS.md 8, round 3)."""
     L = capi.lib()
     L.octane_vof_mid_geometry.restype = C.c_int
     L.octane_vof_mid_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]

@@ -128,11 +128,15 @@ def test_every_build_of_the_kernel_equals_the_oracle_with_the_matching_sites_fus
     """Round 5.  Of the 13 multiply-add sites nvcc's -fmad=true may fuse in the reference's kernel only the two float
     sites of the base position move shorts (oracle-only count: profiles/r5_pix2uv_sites.txt), so "the reference CUDA path" has two
     candidate outputs.  The library carries three builds; each against the oracle with the matching site switches:
-      strict                    == oracle, no site fused                      (0 mismatches)
-      NAV_FMAD_FLOAT (the shim) == oracle, sites F1 + F2 fused                (0 mismatches)
+      strict                    == oracle, no site fused                      (0 mismatches up to 1 Mpixel; see below)
+      NAV_FMAD_FLOAT (the shim) == oracle, sites F1 + F2 fused                (the same)
       NAV_FMAD (the compiler's own contraction) vs oracle, all 13 fused       (<= 2e-6 of the shorts: the compilers' choices at the
                                                                                double sites, which move ~2e-8 of the shorts)
-    on the CONUS window, the full disk with limb and space pixels, and a 2000 x 1500 frame."""
+    on the CONUS window, the full disk with limb and space pixels, and a 2000 x 1500 frame.  On that last one ONE short of 6 M differs
+    between the strict kernel and the strict oracle (measured, round 5): the kernel's sin / cos / atan are the device library's (ocml),
+    the oracle's are glibc's, they differ in the last bit of a double now and then, and a wind that sits within 1e-13 of a whole cm/s
+    truncates the other way.  The CUDA reference (libdevice) is exposed to the same: "bit-exact" navigation holds up to ~2e-7 of the
+    shorts, by 1 cm/s, between ANY two correctly working builds.  Asserted: 0 on frames below 1 Mpixel, <= 1e-6 of the shorts above."""
     rng = np.random.RandomState(5)
     cases = []
     nx, ny = 500, 300
@@ -160,7 +164,10 @@ def test_every_build_of_the_kernel_equals_the_oracle_with_the_matching_sites_fus
         d = dict(strict=diff(g_strict, o_strict), float_sites=diff(g_float, o_float), all_vs_all=diff(g_all, o_all), all_vs_float=diff(g_all, o_float),
                  float_vs_strict=diff(g_float, g_strict))
         print(f"PIX2UV-SITES {nav.nx}x{nav.ny}: of {n} shorts {d}")
-        assert d["strict"] == 0 and d["float_sites"] == 0
+        libm = 0 if u.size < 1_000_000 else max(1, int(1e-6 * n))      # device library vs glibc transcendentals, see above
+        assert d["strict"] <= libm and d["float_sites"] <= libm
+        for g, o in ((g_strict, o_strict), (g_float, o_float)):
+            assert max(np.abs(g[0].astype(int) - o[0]).max(), np.abs(g[1].astype(int) - o[1]).max()) <= 1
         assert d["all_vs_all"] <= max(1, int(2e-6 * n)) and d["all_vs_float"] <= max(1, int(2e-6 * n))
         assert d["float_vs_strict"] > 0
         for k in (2, 3):

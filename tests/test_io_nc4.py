@@ -117,7 +117,8 @@ def test_octane_command_line_end_to_end(io_demo, capi, tmp_path, extra, method):
                    lam0=float(LAM0), xScale=5.6e-05, xOffset=-0.031332, yScale=-5.6e-05,
                    yOffset=0.081212, g2xOffset=-0.031332, g2yOffset=0.081212, nx=nx, ny=ny)
     assert im1.min() > 0 and np.abs(u).mean() > 0.5                      # on the disc, and something moves
-    want = capi.pix2uv(nav, 7.1e8, 7.1e8 + 300.0, u, v, pixuv=1 if method == "vof_pd" else 0)
+    # (the oct_pix2uv_cuda shim navigates with the two float multiply-adds of the base position fused, include/octane_vof.h OCTANE_NAV_FMAD_FLOAT)
+    want = capi.pix2uv(nav, 7.1e8, 7.1e8 + 300.0, u, v, pixuv=1 if method == "vof_pd" else 0, mode=capi.NAV_GEOS | capi.NAV_FMAD_FLOAT)
     assert np.array_equal(_read(io_demo, out, "U", "short", tmp_path).reshape(ny, nx), want[0])
     assert np.array_equal(_read(io_demo, out, "V", "short", tmp_path).reshape(ny, nx), want[1])
     assert d["U"]["atts"]["units"] == ("x-pixels" if method == "vof_pd" else "meters per second")
@@ -321,7 +322,7 @@ def test_octane_command_line_on_remapped_images(io_demo, capi, tmp_path, proj):
     else:
         nav = capi.Nav(xScale=geo["xs"], xOffset=geo["xo"], yScale=geo["ys"], yOffset=geo["yo"], g2xOffset=geo["xo"], g2yOffset=geo["yo"],
                        lon1=geo["lon"], R=geo["R"], nx=nx, ny=ny)
-        want = capi.pix2uv(nav, 7.1e8, 7.1e8 + 600.0, u, v, mode=capi.NAV_MERC)
+        want = capi.pix2uv(nav, 7.1e8, 7.1e8 + 600.0, u, v, mode=capi.NAV_MERC | capi.NAV_FMAD_FLOAT)
         assert np.abs(want[0]).max() > 100                                 # several m/s somewhere
         assert np.array_equal(gu, want[0].astype(np.float64)) and np.array_equal(gv, want[1].astype(np.float64))
         assert abs(float(d["U"]["atts"]["scale_factor"]) - 0.01) < 1e-9 and d["U"]["atts"]["grid_mapping"] == "Mercator Sphere"

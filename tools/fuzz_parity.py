@@ -2,7 +2,11 @@
 (first guess and hint term included), with the criterion of tests/test_gpu_parity.py (distance to the primary oracle
 below 2e-5; cases on which the oracle's own variants are further apart than half of that are reported as CHAOTIC).  A development tool, not part of the test suite:
    python tools/fuzz_parity.py [cases] [seed] [only_case [forms]]     needs a GPU; prints one line per case and a summary;
-   with only_case just that case is run, with a fifth argument the three forms of the PCG iteration are compared on it."""
+   with only_case just that case is run, with a fifth argument the three forms of the PCG iteration are compared on it.
+   OCTANE_FUZZ_FAMILY=disc|mixed (default lattice): draw the scenes from synth.disc_scene -- the Earth disc on exact zeros, limb taper,
+   int16 counts, noise, a saturated patch, random centre and span (round 5) -- or alternate between the two families.  The zero
+   background makes the systems ill-conditioned, so on that family most multi-level cases come out as CHAOTIC (the oracle's own
+   variants further apart than 1e-5): the criterion that counts there is "never BAD" (within 3 x the oracle's own spread, equal counts)."""
 import os
 import sys
 
@@ -49,7 +53,17 @@ def main():
             v0 = (1.5 * rng.randn(ny, nx)).astype(np.float32)
         if only >= 0 and case != only:
             continue
-        a, b = synth.lattice_scene(nx, ny, seed=scene_seed, nchan=nc)
+        fam = os.environ.get("OCTANE_FUZZ_FAMILY", "lattice")
+        disc = fam == "disc" or (fam == "mixed" and case % 2 == 1)
+        if disc:
+            drng = np.random.RandomState(scene_seed)
+            a, b = synth.disc_scene(nx, ny, seed=scene_seed, nchan=nc, centre=(float(drng.uniform(0.1, 0.9)), float(drng.uniform(0.1, 0.9))),
+                                    span=float(drng.uniform(0.5, 1.1)), noise=float(drng.choice([0.0, 0.6, 1.5])), saturate=bool(drng.rand() < 0.7))
+            if u0 is not None:      # a first guess is zero in space, as a -firstguess file's is
+                m = a[0] != 0
+                u0 = (u0 * m).astype(np.float32); v0 = (v0 * m).astype(np.float32)
+        else:
+            a, b = synth.lattice_scene(nx, ny, seed=scene_seed, nchan=nc)
         if forms:
             res = {}
             pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm))
@@ -97,11 +111,11 @@ def main():
         d_other = min([rel_l2(ug, vg, x, y) for x, y in [(u2, v2), (us, vs)] + others if x is not None] or [float("nan")])
         bar = 2e-5
         fine = bool(np.isfinite(ug).all()) and its_g == its_o
-        verdict = "ok " if (fine and d < bar) else ("CHAOTIC" if (fine and floor > bar / 2) else "BAD")
+        verdict = "ok " if (fine and d < bar) else ("CHAOTIC" if (fine and floor > bar / 2 and (not disc or d < 3 * floor)) else "BAD")
         worst = max(worst, d / bar)
         bad += 1 if verdict == "BAD" else 0
         chaotic += 1 if verdict == "CHAOTIC" else 0
-        print(f"{verdict} {nx}x{ny}x{nc} {prm} guess={u0 is not None}: d_primary {d:.2e} (bar {bar:.0e}; oracle spread {floor:.1e}, nearest other oracle variant {d_other:.1e}) its {its_g}/{its_o}", flush=True)
+        print(f"{verdict} {'disc' if disc else 'lattice'} {nx}x{ny}x{nc} {prm} guess={u0 is not None}: d_primary {d:.2e} (bar {bar:.0e}; oracle spread {floor:.1e}, nearest other oracle variant {d_other:.1e}) its {its_g}/{its_o}", flush=True)
     print(f"{ncases} cases, {bad} bad, {chaotic} chaotic (would need an allow-list entry), worst distance / bar = {worst:.2f}")
     return 1 if bad else 0
 

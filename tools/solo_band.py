@@ -57,7 +57,7 @@ def main():
     ts = []
     for r in range(reps + 1):
         t0 = time.perf_counter()
-        pl.run_device(a.data_ptr(), b.data_ptr(), ou.data_ptr(), ov.data_ptr())
+        pl.solve_device(a.data_ptr(), b.data_ptr(), ou.data_ptr(), ov.data_ptr())       # zero first guess
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     assert pl.last_iterations() == expect
