@@ -507,9 +507,17 @@ class MpPlan:
         self._h = C.c_void_p()
         self._exchange = exchange
         p = params.c()
+        import time as _time
+        _t0 = _time.perf_counter()
+
+        def _note(what):     # OCTANE_MP_TRACE=1: where a creation that takes long spends its time (every rank speaks)
+            if os.environ.get("OCTANE_MP_TRACE") == "1":
+                import sys as _sys
+                print(f"octane MpPlan rank {rank} [{_time.perf_counter() - _t0:7.2f} s] {what}", file=_sys.stderr, flush=True)
         rc = lib().octane_vof_mp_create(C.byref(self._h), nx, ny, nchan, C.byref(p), rank, world, min_band_pixels, shm_name.encode())
         if rc != OK:
             raise OctaneError(rc, "octane_vof_mp_create")
+        _note("band plan created")
         if exchange is not None:
             rc = lib().octane_vof_mp_set_exchange(self._h, C.byref(exchange.c_struct()))
             if rc != OK:
@@ -520,9 +528,11 @@ class MpPlan:
             raise OctaneError(rc, "octane_vof_mp_handles")
         blobs = all_gather(buf.raw)
         assert len(blobs) == world and all(len(b) == MP_HANDLE_BYTES for b in blobs)
+        _note("handles gathered")
         rc = lib().octane_vof_mp_connect(self._h, C.create_string_buffer(b"".join(blobs), MP_HANDLE_BYTES * world))
         if rc != OK:
             raise OctaneError(rc, "octane_vof_mp_connect")
+        _note("connected (IPC mappings opened or declined)")
 
         def _ag(user, mine, allp, nbytes):          # the library's byte all-gather, carried by the host program's
             try:
@@ -537,6 +547,7 @@ class MpPlan:
             rc = lib().octane_vof_mp_selfcheck(self._h, self._ag, None)
             if rc != OK:
                 raise OctaneError(rc, "octane_vof_mp_selfcheck")
+            _note("first-contact self-check done")
 
     def transport_info(self) -> dict:
         ti = TransportInfo()

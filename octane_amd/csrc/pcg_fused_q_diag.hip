@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_pcg_fused_q_diag(LevelPtrs L, int k, in
         rr = (float)(rrd - 2. * a * rq + a * a * qq);
         beta = rz_new / prev.rz;
     }
-    const bool active = rr > tol;                    // ref .cu:1131
+    const bool active = rr > tol || OCT_STOP_HELD_OPEN(tol);   // ref .cu:1131 (held open only by the diagnostic library's solo-band timing)
     if (blockIdx.x == 0 && tid == 0) {
         PcgState n; n.rz = rz_new; n.stopped = active ? 0 : 1; n.iters = prev.iters + (active ? 1 : 0); n.pad = 0;
         L.st[(k + 1) & 1] = n;

@@ -13,6 +13,15 @@ namespace octane {
 // OCTANE_TUNE_PERSIST_MAXG and the bisect pair OCTANE_TUNE_Q_DMA / OCTANE_TUNE_PERSIST).  Every other OCTANE_TUNE_* variable is a
 // developer knob of the DIAGNOSTIC library (make DIAG=1, liboctane_vof_diag.so: what tools/ loads) and does not exist in the
 // product: a stray variable in a production environment cannot change which kernels run.
+// Solo-band timing (vof_tiled.hip, diagnostic library only) runs a band's launch sequence on inconsistent neighbour data; a negative
+// tolerance then keeps every launch of the fused PCG kernels working whatever the sums say (a NaN included), so that the timeline is
+// the real one.  In the product the macro is `false` and the kernels' text is what it was.
+#ifdef OCTANE_DIAG
+#define OCT_STOP_HELD_OPEN(tol) ((tol) < 0.f)
+#else
+#define OCT_STOP_HELD_OPEN(tol) false
+#endif
+
 inline const char *tune_env(const char *name)
 {
 #ifdef OCTANE_DIAG

@@ -637,6 +637,14 @@ int octane::plan_level_setup(octane_vof_plan *pl, hipStream_t s, int k, int &cur
 // solves are serialised with theirs (persist_launch below), so only the tiny levels keep them (<= 16 workgroups: 157^2 and below)
 // and everything one workgroup can hold goes to the single-workgroup solve, whose launches overlap freely.
 static void plan_lane_mode(octane_vof_plan *pl) { pl->persist_max_g = 16; pl->small_max_pixels = 6144; }
+// TWO plans side by side on one device (the two lanes of octane_vof_batch_run, bench.py --workload batch64 / --lanes 2; round 5): each
+// caps its persistent solves at HALF the compute units and launches them WITHOUT waiting for the other's -- 2 x ncu / 2 workgroups are
+// always co-resident, so the two solves run concurrently instead of queueing behind each other.  Measured, two lanes of 2000^2 pairs
+// (tools/lanes_concurrent.py, profiles/r5_lanes_concurrent.txt): serialised + uncapped (rounds 2-4) 200.2 Mpix/s, concurrent + capped at
+// half 219.1 (+9.4 %), serialised + capped 195.3, concurrent + uncapped 163.3 (a solve is abandoned now and then: 2 x 240 workgroups do
+// not always become resident beside the other lane's streaming kernels).  The cap changes the sub-domain grid of the mid-size levels and
+// with it the grouping of their fp64 partial sums: flows equal the default plan's to the last bits of the PCG scalars, not bit for bit.
+static void plan_lane_pair_mode(octane_vof_plan *pl) { pl->persist_max_g = pl->ncu > 1 ? pl->ncu / 2 : 128; pl->persist_chain = 0; }
 static std::mutex g_persist_mu;
 #ifdef OCTANE_DIAG
 static int g_persist_diag = 0;      // octane_vof_tune(plan, "persist_diag", 1): the stamped build of the persistent solve (diagnostic library only)
@@ -646,6 +654,15 @@ static int persist_launch(octane_vof_plan *pl, hipStream_t s, const LevelPtrs &L
 {
     std::lock_guard<std::mutex> g(g_persist_mu);
     const int d = pl->device & 63;
+    if (!pl->persist_chain) {      // EXPERIMENT (round 5, tune "persist_chain" 0): this plan's persistent launches neither wait for nor hold up the others'
+#ifdef OCTANE_DIAG
+        hipError_t e0 = (g_persist_diag ? launch_pcg_solve_mid_diag : launch_pcg_solve_mid)(s, L, mg, pl->d_mid, seq, k0, k1, kcap, nparts_asm, pl->tol);
+#else
+        hipError_t e0 = launch_pcg_solve_mid(s, L, mg, pl->d_mid, seq, k0, k1, kcap, nparts_asm, pl->tol);
+#endif
+        if (e0 != hipSuccess) { g_last_error = std::string("persistent solve: ") + hipGetErrorString(e0); return OCTANE_E_HIP; }
+        return OCTANE_OK;
+    }
     if (!g_persist_ev[d]) {
         if (hipEventCreateWithFlags(&g_persist_ev[d], hipEventDisableTiming) != hipSuccess) { g_last_error = "persistent solve: hipEventCreate failed"; return OCTANE_E_HIP; }
     } else if (hipStreamWaitEvent(s, g_persist_ev[d], 0) != hipSuccess) {
@@ -1226,6 +1243,7 @@ extern "C" int octane_vof_batch_run(int npairs, const float *const *img1, const 
             // more than two lanes (OCTANE_TUNE_BATCH_LANES): a persistent solve holds its CUs for a whole solve and such launches are
             // serialised per device, so only the tiny levels keep it then (plan_lane_mode)
             if (rc == OCTANE_OK && lanes > 2 && !getenv("OCTANE_TUNE_PERSIST_MAXG")) plan_lane_mode(pl);
+            if (rc == OCTANE_OK && lanes == 2 && !getenv("OCTANE_TUNE_PERSIST_MAXG")) plan_lane_pair_mode(pl);      // round 5: concurrent, each on half the CUs
             for (int b = first; rc == OCTANE_OK && b < npairs; b += step)
                 rc = octane_vof_plan_run(pl, img1[b], img2[b], u[b], v[b], OCTANE_MEM_HOST, nullptr);
             if (rc != OCTANE_OK) errs[wk] = g_last_error;
@@ -1728,7 +1746,12 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
     else if (k == "persist_fault") set_mid_fault(value);            // the fault drill's hook exists in the diagnostic library only
 #endif
     else if (k == "persist_max_g") pl->persist_max_g = value;
-    else if (k == "lane_mode") { if (value) plan_lane_mode(pl); else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 1536; } }
+    else if (k == "persist_chain") pl->persist_chain = value != 0;   // 0: persistent launches of this plan are not serialised with other plans' (experiment)
+    else if (k == "lane_mode") {      // 1: beside two or more other plans; 2: beside ONE other plan (the two lanes of a batch); 0: alone
+        if (value == 2) plan_lane_pair_mode(pl);
+        else if (value) plan_lane_mode(pl);
+        else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 1536; pl->persist_chain = 1; }
+    }
     else if (k == "fused_rows") set_fused_rows(value);
     else if (k == "asm_fast") pl->asm_fast = value ? assemble_fast_math_bits(pl->prm.alpha) : 0;    // 0: IEEE divisions throughout (same bits)
     else return OCTANE_E_INVALID;

@@ -74,6 +74,7 @@ struct octane_vof_plan {
     int use_persist = 1, persist_step = 0, persist_p = 0;
     long small_max_pixels = 1536;           // levels of up to this many pixels (three per thread) run the single-workgroup solve; larger ones, up to the 6144 it can hold, only when the persistent solve is off
     int persist_max_g = 1 << 20;   // cap on the workgroups (= CUs held for a whole solve) of one persistent launch: lanes of a batch lower it
+    int persist_chain = 1;           // persistent launches are serialised per device among the plans of this process (vof_plan.hip, persist_launch)
     long persist_max_pixels = 2L << 20;
     int ncu = 0;                   // compute units of the device
     void *d_mid = nullptr;         // workspace of the persistent solve (abort word, granules of partial sums and edge pixels)

@@ -524,6 +524,7 @@ struct BandNet {
     // collective transport (process form only): the host program's collective library moves the bytes (octane_vof_exchange)
     virtual int xchg_all_gather(int, const void *, void *const *, size_t) { return -1; }
     virtual int xchg_sendrecv(int, int, const octane_vof_xfer *) { return -1; }
+    virtual void level_mark(int, int) {}                           // band b is about to start level k (k == levels: the pyramid is issued); solo-band timing records an event
     int transport = OCTANE_TRANSPORT_INPLACE;
     bool no_dma = false;
     int brk = 0;       // diagnostic library only: OCTANE_TEST_BREAK_TRANSPORT, the drill of the self-check's downgrade
@@ -811,6 +812,7 @@ static void band_worker(BandNet &N, int b)
     int cur = 0;
     LevelCtx ctx;
     for (int k = 0; k < nlev; k++) {
+        N.level_mark(b, k);
         if (!N.failed()) {
             const int rc = plan_level_setup(pl, pl->own_stream, k, cur, ctx);
             if (rc) N.fail(b, rc, "plan_level_setup failed");
@@ -827,6 +829,7 @@ static void band_worker(BandNet &N, int b)
             solve_level_banded(N, b, k, cur, ctx, k == nlev - 1);
         }
     }
+    N.level_mark(b, nlev);
     if (b == 0) BAND_HIP(hipMemcpyAsync(pl->h_iters, pl->d_iters, sizeof(long long), hipMemcpyDeviceToHost, pl->own_stream));
     if (persist_end_run(pl, pl->own_stream) != OCTANE_OK) N.fail(b, OCTANE_E_HIP, "fetching the persistent solve's abort word failed");
     BAND_HIP(hipGetLastError());
@@ -1012,6 +1015,13 @@ struct SoloNet : BandNet {
     bool bad = false;
     std::string error;
     long long peer_bytes = 0, boundaries = 0;
+    std::vector<hipEvent_t> lev_ev;            // one timing event per level start + one at the end of the pyramid
+    void level_mark(int, int k) override
+    {
+        if ((int)lev_ev.size() <= k) { lev_ev.resize(k + 1, nullptr); }
+        if (!lev_ev[k] && hipEventCreate(&lev_ev[k]) != hipSuccess) { lev_ev[k] = nullptr; return; }
+        (void)hipEventRecord(lev_ev[k], pl->own_stream);
+    }
     octane_vof_plan *plan(int) override { return pl; }
     bool failed() override { return bad; }
     void fail(int, int code, const std::string &msg) override { if (!bad) { bad = true; rc = code; error = msg; } }
@@ -1041,7 +1051,7 @@ struct SoloNet : BandNet {
 extern "C" int octane_vof_solo_band_time(int nx, int ny, int nchan, const octane_vof_params *p, int nbands, int band, long long min_band_pixels,
                                          const float *img1, const float *img2, int mem, int reps, double *ms_out,
                                          long long *iterations, long long *peer_copy_bytes, long long *boundaries, int *banded_levels,
-                                         int *band_rows_finest)
+                                         int *band_rows_finest, double *level_ms /* [32]: GPU time of each level (coarsest first) in the LAST repetition, or NULL */)
 {
     if (!p || !img1 || !img2 || !ms_out || nbands < 1 || nbands > kMaxBands || band < 0 || band >= nbands || reps < 1) return OCTANE_E_INVALID;
     octane_vof_plan *pl = nullptr;
@@ -1049,6 +1059,7 @@ extern "C" int octane_vof_solo_band_time(int nx, int ny, int nchan, const octane
     if (rc != OCTANE_OK) return rc;
     SoloNet N;
     N.pl = pl; N.band = band; N.nb = nbands; N.prm = *p; N.solo = true;
+    pl->tol = -1.f;        // OCT_STOP_HELD_OPEN: the band's fused PCG launches all do their work, whatever the inconsistent sums say
     std::vector<std::vector<BandRows>> rows(pl->lev.size());
     const long minpix = min_band_pixels > 0 ? (long)min_band_pixels : kDefaultMinBandPixels;
     int nbanded = 0;
@@ -1093,6 +1104,14 @@ extern "C" int octane_vof_solo_band_time(int nx, int ny, int nchan, const octane
         if (N.bad) { set_last_error("octane_vof_solo_band_time: " + N.error); rc = N.rc; }
         if (rc == OCTANE_OK && persist_check(pl) != OCTANE_OK) rc = OCTANE_E_HIP;
     }
+    if (level_ms) {
+        for (int k = 0; k < 32; k++) level_ms[k] = -1.;
+        for (size_t k = 0; k + 1 < N.lev_ev.size() && k < 32; k++) {
+            float ms = 0.f;
+            if (N.lev_ev[k] && N.lev_ev[k + 1] && hipEventElapsedTime(&ms, N.lev_ev[k], N.lev_ev[k + 1]) == hipSuccess) level_ms[k] = ms;
+        }
+    }
+    for (auto &e : N.lev_ev) if (e) (void)hipEventDestroy(e);
     if (iterations) *iterations = rc == OCTANE_OK ? *pl->h_iters : -1;
     if (peer_copy_bytes) *peer_copy_bytes = N.peer_bytes;
     if (boundaries) *boundaries = N.boundaries;

@@ -311,12 +311,27 @@ def refhip_path() -> str:
     return os.path.join(_HERE, "_ref", "liboct_ref_hip.so")
 
 
+def _one_hip_runtime() -> None:
+    """One HIP runtime per process (as octane_amd/capi.py does for the product library): the PyTorch-ROCm wheel bundles its own
+    libamdhip64.so; a library that pulled in /opt/rocm's copy first would leave whichever runtime initialises second without a GPU."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def refhip_lib():
     p = refhip_path()
     if not os.path.exists(p) and os.path.isdir("/root/reference/src"):
         subprocess.call(["make", "-C", _HERE, "-s", "refhip"])
     if not os.path.exists(p):
         return None
+    _one_hip_runtime()
     L = C.CDLL(p)
     L.oct_refhip_vof.argtypes = [_F, _F, C.c_int, C.c_int, C.c_int, _F, _F, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]

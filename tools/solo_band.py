@@ -26,10 +26,12 @@ def solo(L, n, prm, nb, band, mbp, a, b, reps):
     ms = (C.c_double * reps)()
     its, pbytes, bnd = C.c_longlong(), C.c_longlong(), C.c_longlong()
     nbanded, rows = C.c_int(), C.c_int()
+    lev = (C.c_double * 32)()
     rc = L.octane_vof_solo_band_time(n, n, 1, C.byref(prm.c()), nb, band, mbp, a.data_ptr(), b.data_ptr(), 1, reps, ms,
-                                     C.byref(its), C.byref(pbytes), C.byref(bnd), C.byref(nbanded), C.byref(rows))
+                                     C.byref(its), C.byref(pbytes), C.byref(bnd), C.byref(nbanded), C.byref(rows), lev)
     if rc != 0:
         raise capi.OctaneError(rc, "octane_vof_solo_band_time")
+    solo.levels = [x for x in lev if x >= 0]
     return list(ms), its.value, pbytes.value, bnd.value, nbanded.value, rows.value
 
 
@@ -46,7 +48,7 @@ def main():
     vp = C.c_void_p
     L.octane_vof_solo_band_time.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(capi.VofParams), C.c_int, C.c_int, C.c_longlong, vp, vp, C.c_int, C.c_int,
                                             C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
-                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     dev = torch.device("cuda:0")
     a, b = synth.lattice_scene(n, n, seed=20240615, device=dev)
     ou, ov = torch.empty(n, n, device=dev), torch.empty(n, n, device=dev)
@@ -67,7 +69,8 @@ def main():
           f"(best of {reps}); solo times are best of {reps}", flush=True)
     # N = 1 through the band machinery (one band = the whole frame, nothing banded): what the band code itself costs
     ms, its, pb, bnd, nbd, rows = solo(L, n, prm, 1, 0, mbp, a, b, reps)
-    print(f"N=1 band 0: {min(ms):8.2f} ms  (banded levels {nbd}, boundaries {bnd}, iterations {its}/{expect})", flush=True)
+    print(f"N=1 band 0: {min(ms):8.2f} ms  (banded levels {nbd}, boundaries {bnd}, iterations {its}/{expect}); GPU ms per level, coarsest first: "
+          f"{' '.join(f'{x:.2f}' for x in solo.levels)}", flush=True)
     for nb in bands:
         kinds = sorted({0, nb // 2, nb - 1})
         worst = 0.0
@@ -77,7 +80,7 @@ def main():
             worst = max(worst, min(ms))
             print(f"N={nb} band {band} ({'first' if band == 0 else 'last' if band == nb - 1 else 'inner'}, {rows} rows of the finest level): {min(ms):8.2f} ms "
                   f"(all reps {', '.join(f'{x:.2f}' for x in ms)}); banded levels {nbd}; phase boundaries {bnd}; peer copies {pb / 1e6:.1f} MB; "
-                  f"iterations {its}/{expect} {ok}", flush=True)
+                  f"iterations {its}/{expect} {ok}; GPU ms per level, coarsest first: {' '.join(f'{x:.2f}' for x in solo.levels)}", flush=True)
         print(f"N={nb}: slowest band {worst:.2f} ms -> compute-only speed-up {t_plain / worst:.2f} x, efficiency {t_plain / worst / nb:.3f} "
               f"(an upper bound: boundaries' waiting, xGMI latency and peer copies come on top)", flush=True)
 
