@@ -83,6 +83,7 @@ extern "C" int octane_vof_plan_destroy(octane_vof_plan *pl)
     if (pl->ev_s1) (void)hipEventDestroy(pl->ev_s1);
     if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
     if (pl->arena) (void)hipFree(pl->arena);
+    if (pl->xarena) (void)hipFree(pl->xarena);
     if (pl->d_taps) (void)hipFree(pl->d_taps);
     if (pl->d_parts) (void)hipFree(pl->d_parts);
     if (pl->d_state) (void)hipFree(pl->d_state);
@@ -348,22 +349,30 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     size_t stride = pl->plane0;
     if (align_f) stride = (stride + align_f - 1) / align_f * align_f;
     stride += skew;
-    pl->arena_bytes = nplanes * stride * sizeof(float) + (size_t)(4 << 20);
+    // band plans: the 30 planes from U[0] on (flow, operator, CG vectors: what neighbouring bands read) live in `xarena`, see vof_plan.hpp
+    constexpr size_t kSharedPlanes = 6 + 17 + 1 + 6;
+    constexpr size_t kGuardFloats = (size_t)1 << 20;      // 4 MB in front of the shared planes: an access just below U[0] stays inside the allocation
+    const size_t head_planes = band_plan ? nplanes - kSharedPlanes : nplanes;
+    pl->arena_bytes = head_planes * stride * sizeof(float) + (size_t)(4 << 20);
     hipError_t e = hipMalloc((void **)&pl->arena, pl->arena_bytes);
+    if (e == hipSuccess && band_plan) {
+        pl->xarena_bytes = (kGuardFloats + kSharedPlanes * stride) * sizeof(float) + (size_t)(4 << 20);
+        e = hipMalloc((void **)&pl->xarena, pl->xarena_bytes);
+    }
     if (e != hipSuccess) {
         g_last_error = std::string("hipMalloc of the plan arena failed: ") + hipGetErrorString(e);
-        delete pl;
+        octane_vof_plan_destroy(pl);
         return OCTANE_E_NOMEM;
     }
     // Poison the arena with NaNs: a kernel that consumed a value nobody wrote would show up as a
     // NaN flow field instead of a silently run-dependent one (tests rely on this).
-    if (hipMemset(pl->arena, 0xFF, pl->arena_bytes) != hipSuccess) {
+    if (hipMemset(pl->arena, 0xFF, pl->arena_bytes) != hipSuccess || (pl->xarena && hipMemset(pl->xarena, 0xFF, pl->xarena_bytes) != hipSuccess)) {
         g_last_error = "hipMemset of the plan arena failed";
         octane_vof_plan_destroy(pl);
         return OCTANE_E_HIP;
     }
-    // plane pointers for an arena starting at `base`
-    auto carve = [&](float *base) {
+    // plane pointers for an arena starting at `base` (and, for a band plan, shared planes starting in the allocation `xbase`)
+    auto carve = [&](float *base, float *xbase) {
         // planes sit at the same OFFSETS in every arena (row bands address a neighbour's plane as "my pointer moved by the
         // distance between the arena bases", BandNet::peer), so nothing here may depend on the absolute address
         float *cur = base;
@@ -373,6 +382,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         pl->lev1 = take(nc); pl->lev2 = take(nc);
         pl->gx1 = take(nc); pl->gy1 = take(nc); pl->gx2 = take(nc); pl->gy2 = take(nc);
         pl->gxx = take(nc); pl->gxy = take(nc); pl->gyy = take(nc);
+        if (xbase) cur = xbase + kGuardFloats;       // band plan: from here on the planes neighbouring bands read
         pl->U[0] = take(1); pl->U[1] = take(1); pl->V[0] = take(1); pl->V[1] = take(1);
         pl->ut = take(1); pl->vt = take(1);
         pl->a1 = take(1); pl->a2 = take(1); pl->a4 = take(1); pl->wx = take(1); pl->wy = take(1); pl->mu = take(1); pl->mv = take(1);
@@ -393,7 +403,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
             pl->gxxb = pl->gxx; pl->gxyb = pl->gxy; pl->gyyb = pl->gyy;
         }
     };
-    carve(pl->arena);
+    carve(pl->arena, pl->xarena);
 
     int rc = OCTANE_OK;
     do {
@@ -438,26 +448,29 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     constexpr int kMaxTrials = 8;
     if (const char *e = tune_env("OCTANE_TUNE_PLACEMENT_TRIALS_FORCE")) trials = atoi(e);       // experiments: more than the caller's default
     if (trials > kMaxTrials) trials = kMaxTrials;
+    // (a band plan's candidates are candidates for its SHARED allocation -- the operator and the CG vectors are what a PCG launch streams)
+    const size_t trial_bytes = pl->shared_bytes();
     {   // the candidates exist side by side while they are timed: keep that within 48 GB
-        const long fit = (long)(((size_t)48 << 30) / pl->arena_bytes);
+        const long fit = (long)(((size_t)48 << 30) / trial_bytes);
         if (trials > fit) trials = (int)fit;
     }
     if (trials > 1 && (long)nx * ny >= (1L << 22)) {
-        float *cand[kMaxTrials] = {pl->arena};
+        float *cand[kMaxTrials] = {pl->shared_base()};
         double ms[kMaxTrials] = {0};
         int ncand = 1;
         // experiment (OCTANE_TUNE_ARENA_CONTIG=1): odd candidates ask for physically contiguous memory
         const bool try_contig = tune_env("OCTANE_TUNE_ARENA_CONTIG") && atoi(tune_env("OCTANE_TUNE_ARENA_CONTIG")) != 0;
         for (int t = 1; t < trials; t++) {
-            hipError_t ae = (try_contig && (t & 1)) ? hipExtMallocWithFlags((void **)&cand[t], pl->arena_bytes, hipDeviceMallocContiguous)
-                                                    : hipMalloc((void **)&cand[t], pl->arena_bytes);
-            if (ae != hipSuccess && try_contig && (t & 1)) { (void)hipGetLastError(); ae = hipMalloc((void **)&cand[t], pl->arena_bytes); if (tune_env("OCTANE_TUNE_VERBOSE")) fprintf(stderr, "[octane] contiguous candidate %d refused\n", t); }
+            hipError_t ae = (try_contig && (t & 1)) ? hipExtMallocWithFlags((void **)&cand[t], trial_bytes, hipDeviceMallocContiguous)
+                                                    : hipMalloc((void **)&cand[t], trial_bytes);
+            if (ae != hipSuccess && try_contig && (t & 1)) { (void)hipGetLastError(); ae = hipMalloc((void **)&cand[t], trial_bytes); if (tune_env("OCTANE_TUNE_VERBOSE")) fprintf(stderr, "[octane] contiguous candidate %d refused\n", t); }
             if (ae != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
             ncand = t + 1;
         }
+        auto carve_cand = [&](float *c) { if (pl->xarena) carve(pl->arena, c); else carve(c, nullptr); };
         int best = 0;
         for (int t = 0; t < ncand; t++) {
-            carve(cand[t]);
+            carve_cand(cand[t]);
             ms[t] = probe_placement(pl);
             if (ms[t] > 0 && (ms[best] <= 0 || ms[t] < ms[best])) best = t;
         }
@@ -470,9 +483,9 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
         for (int t = 0; t < ncand; t++) pl->trial_ms[t] = ms[t];
         for (int t = 0; t < ncand; t++)
             if (t != best) (void)hipFree(cand[t]);
-        pl->arena = cand[best];
-        carve(pl->arena);
-        if (hipMemset(pl->arena, 0xFF, pl->arena_bytes) != hipSuccess) {      // restore the poison the probe disturbed
+        if (pl->xarena) pl->xarena = cand[best]; else pl->arena = cand[best];
+        carve_cand(cand[best]);
+        if (hipMemset(cand[best], 0xFF, trial_bytes) != hipSuccess) {      // restore the poison the probe disturbed
             g_last_error = "hipMemset of the plan arena failed";
             octane_vof_plan_destroy(pl);
             return OCTANE_E_HIP;
@@ -490,7 +503,7 @@ int octane::plan_create_ex(octane_vof_plan **out, int nx, int ny, int nchan, con
     return OCTANE_OK;
 }
 
-extern "C" size_t octane_vof_plan_device_bytes(const octane_vof_plan *pl) { return pl ? pl->arena_bytes : 0; }
+extern "C" size_t octane_vof_plan_device_bytes(const octane_vof_plan *pl) { return pl ? pl->arena_bytes + pl->xarena_bytes : 0; }
 
 extern "C" int octane_vof_plan_placement_trials(const octane_vof_plan *pl, double *ms, int cap)
 {

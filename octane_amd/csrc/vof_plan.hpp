@@ -27,6 +27,17 @@ struct octane_vof_plan {
     std::vector<LevelInfo> lev;
     float *arena = nullptr;
     size_t arena_bytes = 0;
+    // Band plans (one band of a row-band solve) keep the planes the NEIGHBOURING bands read -- the flow, the operator, the CG vectors: the
+    // 30 planes from U[0] on -- in an allocation of their own, and only that one is peer-addressed / exported over HIP IPC.  Round 5: with
+    // ONE 18.9 GiB arena per band the process form of a 10848^2 frame never got past octane_vof_mp_connect (two ranks on one GPU: no return
+    // from the IPC mapping within 200 s, twice; a 19 GiB allocation did not open within 400 s in tools/ipc_probe.py either, while 1 ... 17
+    // GiB open in < 1 ms, profiles/r5_ipc_probe.txt).  The shared part is 13.2 GiB there and the same two ranks connect in 1 s.  Mapping
+    // only what is read also keeps a neighbour's stray pointer out of this band's inputs.  The band's private planes (inputs, level images,
+    // gradients) stay in `arena`.  Plain plans: xarena == nullptr, everything in `arena`, layout unchanged.
+    float *xarena = nullptr;
+    size_t xarena_bytes = 0;
+    float *shared_base() const { return xarena ? xarena : arena; }
+    size_t shared_bytes() const { return xarena ? xarena_bytes : arena_bytes; }
     // planes (all plane0 floats unless noted)
     float *img1p, *img2p, *uh, *vh, *lev1, *lev2;
     float *gx1, *gy1, *gx2, *gy2, *gxx, *gxy, *gyy;

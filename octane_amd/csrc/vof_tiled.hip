@@ -459,7 +459,7 @@ extern "C" long long octane_vof_tiled_last_copies(octane_vof_tiled *t) { return 
 
 extern "C" size_t octane_vof_tiled_device_bytes(const octane_vof_tiled *t)
 {
-    return t ? t->pl[0]->arena_bytes + (size_t)2 * kPartBlock * sizeof(double) : 0;
+    return t ? t->pl[0]->arena_bytes + t->pl[0]->xarena_bytes + (size_t)2 * kPartBlock * sizeof(double) : 0;
 }
 
 // ---- how a band reaches the others ---------------------------------------------------------------------------------
@@ -847,7 +847,7 @@ struct ThreadNet : BandNet {
     explicit ThreadNet(octane_vof_tiled *t_) : t(t_)
     {
         nb = t->nbands; prm = t->prm; rows = &t->rows;
-        for (int b = 0; b < nb; b++) { arena[b] = reinterpret_cast<char *>(t->pl[b]->arena); parts[b] = t->parts[b]; }
+        for (int b = 0; b < nb; b++) { arena[b] = reinterpret_cast<char *>(t->pl[b]->shared_base()); parts[b] = t->parts[b]; }
         transport = t->transport; no_dma = t->no_dma; brk = test_break_bits();
     }
     double *mirror(int b) override { return t->mirror[b]; }
@@ -1085,12 +1085,13 @@ extern "C" int octane_vof_solo_band_time(int nx, int ny, int nchan, const octane
         hipMalloc((void **)&N.mir, (size_t)nbands * 2 * kPartBlock * sizeof(double)) != hipSuccess ||
         hipMemset(N.mir, 0, (size_t)nbands * 2 * kPartBlock * sizeof(double)) != hipSuccess ||
         hipEventCreateWithFlags(&N.ev, hipEventDisableTiming) != hipSuccess ||
-        hipMemset(pl->arena, 0, pl->arena_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        hipMemset(pl->arena, 0, pl->arena_bytes) != hipSuccess || (pl->xarena && hipMemset(pl->xarena, 0, pl->xarena_bytes) != hipSuccess) ||
+        hipDeviceSynchronize() != hipSuccess) {
         set_last_error("octane_vof_solo_band_time: device allocation failed");
         cleanup();
         return OCTANE_E_NOMEM;
     }
-    for (int c = 0; c < kMaxBands; c++) { N.arena[c] = reinterpret_cast<char *>(pl->arena); N.parts[c] = parts; }
+    for (int c = 0; c < kMaxBands; c++) { N.arena[c] = reinterpret_cast<char *>(pl->shared_base()); N.parts[c] = parts; }
     N.transport = OCTANE_TRANSPORT_INPLACE;
     rc = plan_load_inputs(pl, img1, img2, nullptr, nullptr, mem, pl->own_stream);
     if (rc == OCTANE_OK && hipStreamSynchronize(pl->own_stream) != hipSuccess) rc = OCTANE_E_HIP;
@@ -1288,7 +1289,7 @@ static int mp_create_impl(octane_vof_mp **out, int nx, int ny, int nchan, const 
         octane_vof_mp_destroy(m);
         return OCTANE_E_NOMEM;
     }
-    m->arena[rank] = reinterpret_cast<char *>(m->pl->arena);
+    m->arena[rank] = reinterpret_cast<char *>(m->pl->shared_base());      // what the other ranks map: the band's SHARED planes only (vof_plan.hpp)
     m->parts_all[rank] = m->parts;
     long minpix = min_band_pixels > 0 ? (long)min_band_pixels : kDefaultMinBandPixels;
     if (!check_group) if (const char *e = getenv("OCTANE_TUNE_MIN_BAND_PIXELS")) minpix = atol(e);     // never for the self-check's frame
@@ -1360,7 +1361,7 @@ extern "C" int octane_vof_mp_handles(octane_vof_mp *m, void *buf)
     TILED_TRY(hipSetDevice(m->device));
     MpHandles h;
     std::memset(&h, 0, sizeof h);
-    TILED_TRY(hipIpcGetMemHandle(&h.arena, m->pl->arena));
+    TILED_TRY(hipIpcGetMemHandle(&h.arena, m->pl->shared_base()));
     TILED_TRY(hipIpcGetMemHandle(&h.parts, m->parts));
     std::memcpy(buf, &h, sizeof h);
     if (m->rank == 0) {                          // the object is ready for the others once the nonce is in place
