@@ -910,7 +910,7 @@ def main():
         dist.destroy_process_group()
 
 
-def multi_gpu_legs(args, capi, shard, synth, torch, dist, world, rank, local, dev, emit):
+def multi_gpu_legs(args, capi, shard, synth, torch, dist, world, rank, local, dev, emit, legs=None):
     """The side legs of an N-rank default run.  Each leg is collective; a leg that raises on some rank is reported and ends the sequence
     (the ranks may be out of step afterwards); a leg that HANGS (a rank gone inside a collective, a transport that never returns) is
     ended by a watchdog after OCTANE_BENCH_SECONDARY_BUDGET_S seconds (default 300): rank 0 prints the headline with what finished,
@@ -930,7 +930,7 @@ def multi_gpu_legs(args, capi, shard, synth, torch, dist, world, rank, local, de
                 os._exit(0)
     threading.Thread(target=watchdog, daemon=True).start()
     size3 = int(os.environ.get("OCTANE_BENCH_SECONDARY_TILED_SIZE", "10848"))
-    legs = (
+    legs = legs if legs is not None else (      # (tests/test_bench_side_legs_gloo.py passes its own legs: the mechanism without a GPU)
         ("configs3_one_frame_as_row_bands", lambda: tiled_mp_leg(types.SimpleNamespace(size=size3, kiters=8, liters=3, cgiters=30, steps=2, warmup=2, allow_early_exit=False),
                                                                  capi, shard, synth, torch, dist, world, rank, local, dev)),
         ("configs4_batch_of_64_pairs", lambda: (batch64_leg(types.SimpleNamespace(liters=3, cgiters=30, steps=2, warmup=1),

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -53,6 +54,10 @@ def build(force: bool = False) -> None:
     ref = os.environ.get("OCT_REFERENCE", "/root/reference")
     if os.path.isdir(os.path.join(ref, "src")):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + ["ref", f"REF={ref}"])
+        # the cross-check build of the reference's CUDA translation units (hipify-perl + hipcc, out of tree; tests/test_gpu_refhip.py
+        # skips without it): best effort, it pins nothing and must not fail the build
+        if subprocess.call(["make", "-C", _HERE, "-s", "refhip", f"REF={ref}"], stderr=subprocess.DEVNULL) != 0:
+            print("oracle: the hipified cross-check library (make refhip) did not build; tests/test_gpu_refhip.py will skip", file=sys.stderr)
 
 
 def ref_helpers_path() -> str:
