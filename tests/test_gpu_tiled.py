@@ -48,6 +48,19 @@ def test_one_band_is_the_plain_plan(capi):
     assert np.array_equal(up, ut) and np.array_equal(vp, vt)
 
 
+def test_one_band_alone_on_its_device_runs_the_placement_trials_of_its_shared_allocation(capi):
+    """Round 5: a band plan keeps the planes its neighbours read in an allocation of their own (vof_plan.hpp), and a band that has its
+    device to itself -- every band of a real multi-GPU node -- times up to eight candidates of THAT allocation at creation.  On a
+    one-GPU box only a single-band plan takes that path: 4.4 Mpixel (trials start at 4 Mi pixels), flow bit-equal to the plain plan's."""
+    nx, ny = 2300, 1900
+    a, b = synth.lattice_scene(nx, ny, seed=6)
+    prm = dict(kiters=2, liters=1, cgiters=7)
+    up, vp, ip = _plain(capi, a, b, prm)
+    ut, vt, info = _tiled(capi, a, b, prm, 1)
+    assert info["banded"] == 0 and info["its"] == ip
+    assert np.array_equal(up, ut) and np.array_equal(vp, vt)
+
+
 @pytest.mark.parametrize("nbands", [2, 3, 4])
 def test_bands_match_plain_plan_and_oracle(capi, oracle, nbands):
     nx, ny = 300, 420
