@@ -136,7 +136,10 @@ def test_pix2uv_fma_site_switches(oracle):
         return int((a[0] != b[0]).sum() + (a[1] != b[1]).sum())
     assert diff(same, base) == 0 and diff(dbl, base) == 0
     assert 0 < diff(fl, base) < 0.06 * 2 * nx * ny
-    assert diff(al, fl) == 0 and diff(gcc, fl) == 0
+    assert diff(al, fl) == 0
+    from conftest import SANITIZE
+    if not SANITIZE:        # (which products the compiler fuses by itself depends on its flags: the -O1 sanitizer build leaves some of the float ones alone)
+        assert diff(gcc, fl) == 0
     for k in (0, 1):
         one = oracle.pix2uv(nav, 0.0, 300.0, u, v, sites=1 << k)
         assert diff(one, base) > 0
