@@ -7,7 +7,9 @@ kernels) and (3) the CPU ORACLE (oracle/vof_oracle.c, OpenMP, launch-geometry su
 analytic truth for each, and the distances between them.  ~6 minutes of oracle at 10848^2 on 16 cores; a heartbeat file keeps the
 GPU box's watchdog quiet.  With a third argument the frame is also solved as that many row bands -- with the converging seed 20240615
 this is BASELINE configs[3] at FULL size against the oracle, once, as a record (too long for the test suite).
-usage: runaway_check.py [n] [seed] [bands]"""
+With a fourth argument `disc` the pair is the DATA-SHAPED scene of round 5 (synth.disc_scene: the Earth disc on exact zeros, limb taper, int16
+counts, noise, saturated patch) -- configs[3] is a full-disk pair -- and the errors against the truth are taken inside the disc.
+usage: runaway_check.py [n] [seed] [bands] [disc]"""
 import os
 import sys
 import threading
@@ -36,9 +38,13 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10848
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20240616
     prm = dict(kiters=8, liters=3, cgiters=30)
-    a, b = synth.lattice_scene(n, n, seed=seed, device="cuda")
+    disc = len(sys.argv) > 4 and sys.argv[4] == "disc"
+    a, b = (synth.disc_scene if disc else synth.lattice_scene)(n, n, seed=seed, device="cuda")
     a, b = a.cpu().numpy(), b.cpu().numpy()
+    torch.cuda.empty_cache()
     tu, tv = synth.true_lattice_flow(n, n)
+    if disc:
+        print(f"disc scene: {float((a == 0).mean()):.3f} of the pixels are exact zeros (space)", flush=True)
     print(f"{n} x {n}, seed {seed}, {prm}", flush=True)
     res = {}
     for name, persist in (("HIP, default plan", 1), ("HIP, persistent solve off", 0)):
