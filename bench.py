@@ -17,9 +17,10 @@ The JSON line also carries
   value_drop_in -- SURVEY 8d's primary metric, the drop-in call: one oct_variational_optical_flow-shaped call on the caller's pageable
                    HOST buffers without a first guess (H2D + all levels + D2H through octane_vof_solve); never `value`;
   value_with_transfers -- the same call in its other forms (with a first guess, pinned buffers);
-  secondary_multi_gpu -- N > 1 only: after the pair headline the same ranks measure BASELINE.json configs[3] (one 10848^2 frame, one
-                   row band per rank, with its transport block and parity against the plain plan) and configs[4] (64 pairs of
-                   2000^2 sharded) as bounded, non-fatal side legs;
+  secondary_multi_gpu -- N > 1 only: after the pair headline rank 0 measures BASELINE.json configs[3] (one 10848^2 frame, one row band
+                   per rank, with its transport block and parity against the plain plan) and configs[4] (64 pairs of 2000^2 sharded)
+                   as bounded, non-fatal side legs -- CHILD jobs of N fresh ranks each, so that not even a GPU fault in a leg can
+                   cost the headline;
   placement_trials -- min / median / max over the candidate arenas the plan timed when it was created (the headline is a
                    best-of-n-placements figure, EXPERIMENTS.md 8).  A trial is a few PCG launches with the stop test held open
                    (varying weights, x work every second launch: 64 B/pixel), each timed by an event pair;
@@ -890,72 +891,100 @@ def main():
                "placement_trials": trials_ms,
                "device": dstate,
                "roofline": roof, "cpu_baseline": cpu}
-    # N > 1: after the timed pair headline the same ranks measure the two multi-GPU configurations of BASELINE.json -- configs[3] (one
-    # full-disk frame, one row band per rank: the first time RCCL / IPC mappings see N real devices) and configs[4] (64 pairs sharded) --
-    # as bounded, NON-FATAL side legs: whatever happens in them, the headline line above is printed.
+    # N > 1: after the timed pair headline rank 0 measures the two multi-GPU configurations of BASELINE.json -- configs[3] (one full-disk
+    # frame, one row band per rank: the first time RCCL / IPC mappings see N real devices) and configs[4] (64 pairs sharded) -- as
+    # bounded, NON-FATAL side legs in CHILD jobs of N fresh ranks each: whatever happens in them -- an error, a hang, a GPU fault that
+    # kills a rank --, the headline line is printed and this job leaves with exit code 0.
     if world > 1 and not args.no_secondary and args.nchan == 1 and (args.kiters, args.liters, args.cgiters) == (8, 3, 30):
         plan.close()
         del a, b, u, v
         torch.cuda.empty_cache()
-
-        def emit(side):
-            if rank == 0:
-                out["secondary_multi_gpu"] = side
-                print(json.dumps(out), flush=True)
-        side = multi_gpu_legs(args, capi, shard, synth, torch, dist, world, rank, local, dev, emit)
-        emit(side)
-    elif rank == 0:
+        side = multi_gpu_legs(dist, world, rank)
+        if rank == 0:
+            out["secondary_multi_gpu"] = side
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def multi_gpu_legs(args, capi, shard, synth, torch, dist, world, rank, local, dev, emit, legs=None):
-    """The side legs of an N-rank default run.  Each leg is collective; a leg that raises on some rank is reported and ends the sequence
-    (the ranks may be out of step afterwards); a leg that HANGS (a rank gone inside a collective, a transport that never returns) is
-    ended by a watchdog after OCTANE_BENCH_SECONDARY_BUDGET_S seconds (default 300): rank 0 prints the headline with what finished,
-    and every rank leaves with exit code 0 -- the headline is a valid measurement whatever the side legs do."""
-    import threading
-    import types
-    budget = float(os.environ.get("OCTANE_BENCH_SECONDARY_BUDGET_S", "300"))
-    done = threading.Event()
-    result = {}
-
-    def watchdog():
-        if not done.wait(budget):
-            result["error"] = f"the multi-GPU side legs did not finish within {budget:.0f} s (a rank stuck inside a collective?); legs above this line finished"
-            try:
-                emit(dict(result))
-            finally:
-                os._exit(0)
-    threading.Thread(target=watchdog, daemon=True).start()
-    size3 = int(os.environ.get("OCTANE_BENCH_SECONDARY_TILED_SIZE", "10848"))
-    legs = legs if legs is not None else (      # (tests/test_bench_side_legs_gloo.py passes its own legs: the mechanism without a GPU)
-        ("configs3_one_frame_as_row_bands", lambda: tiled_mp_leg(types.SimpleNamespace(size=size3, kiters=8, liters=3, cgiters=30, steps=2, warmup=2, allow_early_exit=False),
-                                                                 capi, shard, synth, torch, dist, world, rank, local, dev)),
-        ("configs4_batch_of_64_pairs", lambda: (batch64_leg(types.SimpleNamespace(liters=3, cgiters=30, steps=2, warmup=1),
-                                                            capi, shard, synth, torch, dist, world, rank, local, dev), 0)),
+def side_leg_commands(world):
+    """The child jobs of an N-rank default run: this script under torch.distributed.run with N fresh ranks, one job per configuration."""
+    size3 = os.environ.get("OCTANE_BENCH_SECONDARY_TILED_SIZE", "10848")
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1"]
+    me = os.path.abspath(__file__)
+    return (
+        ("configs3_one_frame_as_row_bands", launch + ["--master-port", str(_free_port()), me, "--gpus", str(world), "--workload", "tiled",
+                                                      "--size", size3, "--steps", "2", "--warmup", "2"], 240.0),
+        ("configs4_batch_of_64_pairs", launch + ["--master-port", str(_free_port()), me, "--gpus", str(world), "--workload", "batch64",
+                                                 "--steps", "2", "--warmup", "1"], 150.0),
     )
-    for name, fn in legs:
-        mine_ok = True
-        t0 = time.perf_counter()
-        try:
-            leg, code = fn()
-        except (Exception, SystemExit) as e:
-            leg, code, mine_ok = {"error": f"rank {rank}: {type(e).__name__}: {e}"}, 1, False
-            print(f"bench.py: side leg {name} failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-        flags = [None] * world
-        dist.all_gather_object(flags, (mine_ok, None if mine_ok else leg["error"]))
-        if rank == 0:
-            bad = [f[1] for f in flags if not f[0]]
-            if bad:
-                leg = {"error": "; ".join(bad)}
-            leg = dict(leg or {}, exit_code=code, leg_seconds=round(time.perf_counter() - t0, 1))
+
+
+def multi_gpu_legs(dist, world, rank, legs=None):
+    """The side legs of an N-rank default run.  Rank 0 starts each leg as a CHILD job (N fresh ranks of this script on the same GPUs,
+    which the parents have emptied and now leave idle), bounded by a time-out (the child's whole process group is killed), and takes
+    the last JSON line of its stdout; the other parent ranks wait on the rendezvous store -- a CPU-side wait, no collective kernel spins
+    on the GPUs the children are using.  A leg that fails, hangs or crashes is REPORTED in `secondary_multi_gpu` and costs nothing else:
+    the parents never share a process, a communicator or a GPU context with it.  Returns the dictionary on rank 0, None elsewhere."""
+    import signal
+    import subprocess
+    store = None
+    try:
+        from torch.distributed import distributed_c10d
+        store = distributed_c10d._get_default_store()
+    except Exception:       # (a torch without that accessor: fall back to a barrier, which on nccl spins a kernel -- correct, only less tidy)
+        store = None
+    result = None
+    if rank == 0:
+        result = {}
+        legs = legs if legs is not None else side_leg_commands(world)
+        drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_RUN_ID",
+                "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_ERROR_FILE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "NCCL_ASYNC_ERROR_HANDLING")
+        env = {k: v for k, v in os.environ.items() if k not in drop}
+        for name, cmd, limit in legs:
+            t0 = time.perf_counter()
+            leg = {}
+            try:
+                p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+                try:
+                    so, se = p.communicate(timeout=limit)
+                except subprocess.TimeoutExpired:
+                    os.killpg(p.pid, signal.SIGKILL)
+                    so, se = p.communicate()
+                    leg["error"] = f"the leg did not finish within {limit:.0f} s and was killed"
+                lines = [ln for ln in (so or "").splitlines() if ln.startswith("{")]
+                if lines:
+                    try:
+                        leg.update(json.loads(lines[-1]))
+                    except ValueError:
+                        leg.setdefault("error", "the leg's JSON line could not be parsed")
+                elif "error" not in leg:
+                    leg["error"] = "the leg printed no JSON line"
+                leg["exit_code"] = p.returncode
+                if p.returncode != 0 or "error" in leg:
+                    leg["stderr_tail"] = [ln for ln in (se or "").splitlines() if "amdgpu.ids" not in ln and "socket.cpp" not in ln][-8:]
+                progress = [ln for ln in (se or "").splitlines() if ln.startswith("bench.py tiled [")]
+                if progress:
+                    leg["progress"] = progress[-6:]
+            except Exception as e:      # the launcher itself could not be started
+                leg = {"error": f"{type(e).__name__}: {e}"}
+            leg["leg_seconds"] = round(time.perf_counter() - t0, 1)
             result[name] = leg
-        if not all(f[0] for f in flags):
-            break
-        torch.cuda.empty_cache()
-    done.set()
+            print(f"bench.py: side leg {name}: {'value ' + str(leg.get('value')) if leg.get('value') is not None else leg.get('error', 'no value')} "
+                  f"({leg['leg_seconds']} s, exit code {leg.get('exit_code')})", file=sys.stderr, flush=True)
+        if store is not None:
+            store.set("octane_side_legs_done", "1")
+    if store is not None:
+        if rank != 0:
+            import datetime
+            try:
+                store.wait(["octane_side_legs_done"], datetime.timedelta(seconds=600))
+            except Exception:
+                pass
+    else:
+        dist.barrier()
     return result
 
 
