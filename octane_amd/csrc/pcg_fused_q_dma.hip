@@ -31,32 +31,8 @@
 #ifndef Q_VMCNT_U
 #define Q_VMCNT_U 10    // ... 5 per slot where the weights are the constant -1
 #endif
-#ifndef Q_TOUCH
-#define Q_TOUCH 0       // "use" (an empty asm) every register the tile's own loads wrote on the COLD paths that never consume them: a slot
-                        // beyond the ragged edge, a launch past the stop test.  Otherwise the compiler carries those loads as pending
-                        // into the next trip of the tile loop and -- not counting the inline-asm DMAs issued in between -- puts a
-                        // near-full `s_waitcnt vmcnt` at the TOP of the loop, before the next tile's own loads are even issued, and
-                        // `vmcnt(0)` into both arms of the a2 load: the 18 own loads of a tile then go out in three round trips
-#endif
-#ifndef Q_ABL
-#define Q_ABL 0         // ablation builds for tools/time_variants.py (wrong results, same memory pattern): 1 = no arithmetic (every LDS
-                        // and global access kept, sums of the loaded values instead of the operator, the reciprocals and the seven
-                        // sums): the ceiling of this access pattern; 2 = no ring (neither its DMA nor its groups); 4 = no phase 2; 8 = no tiles at
-                        // all (what a launch costs before and after its tile loop: the fold of the partial sums, the final reduction)
-#endif
-// see Q_TOUCH: an empty asm that takes every register the own loads of a slot wrote as an input
-#define Q_TOUCH_SLOT(slot) asm volatile("" :: "v"(*(const f4v *)c3[slot].a1), "v"(*(const f4v *)c3[slot].a2), "v"(*(const f4v *)c3[slot].a4), \
-                                        "v"(*(const f4v *)c3[slot].wx), "v"(*(const f4v *)c3[slot].wy), "v"(*(const f4v *)c3[slot].wys), "v"(c3[slot].wxw), \
-                                        "v"(*(const f4v *)r3u[slot]), "v"(*(const f4v *)r3v[slot]))
 #define Q_STR2(x) #x
 #define Q_STR(x) Q_STR2(x)
-#ifndef Q_LASTFOLD
-#define Q_LASTFOLD 0    // EXPERIMENT (round 4; tools/build_variants.sh "lastfold:-DQ_LASTFOLD=1 ..."): the last workgroup to finish launch k
-                        // folds the 7 x gridDim.x partial sums -- same order as the fold at the head of a launch, same bits -- and publishes seven doubles
-                        // in the last slot of each kind; launch k + 1 loads those instead of folding 3584 values per workgroup.  Whole levels only.
-                        // Arrival is counted in the `pad` word of the state slot this launch only reads (the next launch rewrites that slot: pad = 0).
-                        // Measured: EXPERIMENTS.md 8.  Off in the product.
-#endif
 #ifndef Q_ROT
 #define Q_ROT 1         // rotate the tile columns by the round number when the column count divides the grid
 #endif
@@ -95,7 +71,6 @@ __device__ __forceinline__ void st4_if(float *p, float4 v, bool nt) { if (nt) st
 // instructions instead of the division's eleven: four reciprocals per pixel and launch, 32 of the kernel's 236 lane-instructions.
 __device__ __forceinline__ float direction(float r, float pold, float diag, float beta, bool first)
 {
-    if (Q_ABL & 1) return r + pold + diag;
     float z = rcp_exact(diag) * r;
     return first ? z : beta * pold + z;
 }
@@ -120,14 +95,6 @@ __device__ __forceinline__ void stencil_group(const float *s_u, const float *s_v
     *(float4 *)nu = ld4(&s_u[(lrow + 1) * kQCols + lcol]); *(float4 *)nv = ld4(&s_v[(lrow + 1) * kQCols + lcol]);
     const float uwest = s_u[lrow * kQCols + lcol - 1], vwest = s_v[lrow * kQCols + lcol - 1];
     const float ueast = s_u[lrow * kQCols + lcol + 4], veast = s_v[lrow * kQCols + lcol + 4];
-    if (Q_ABL & 1) {       // every value read above takes part, nothing else is computed
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            qu[e] = cu[e] + su[e] + nu[e] + c.a1[e] + c.a2[e] + c.wx[e] + c.wys[e] + (e == 0 ? uwest + c.wxw : 0.f) + (e == 3 ? ueast : 0.f);
-            qv[e] = cv[e] + sv[e] + nv[e] + c.a4[e] + c.wy[e] + (e == 0 ? vwest : 0.f) + (e == 3 ? veast : 0.f);
-        }
-        return;
-    }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int i = x0 + e;
@@ -254,7 +221,6 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     __shared__ __attribute__((aligned(16))) float s_ring[kRingOps * kRingGroups * 4];
     const int tid = threadIdx.x;
     const bool first = (k == 0);
-    if (Q_ABL & 16) return;                                   // (ablation: what an empty launch of this grid costs)
 
     const PcgState prev = L.st[k & 1];
     if (prev.stopped) {
@@ -269,12 +235,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
         rz_new = (float)t[0]; rr = (float)t[1];
     } else {
         double t[kPartKinds];
-        if (Q_ABL & 32) { t[0] = 4.; t[1] = 4.; t[2] = 1.; t[3] = 1.; t[4] = 1.; t[5] = 1.; t[6] = 1.; }      // (ablation: no fold)
-        else if (Q_LASTFOLD && !BANDED) {
-#pragma unroll
-            for (int j = 0; j < kPartKinds; j++) t[j] = L.band_parts[0][pin_off + j * kMaxParts + (kMaxParts - 1)];    // published by the previous launch's last workgroup
-        }
-        else fold_band_partials_multi_256<kPartKinds>(L.band_parts, pin_off, kMaxParts, nparts_prev, L.nbands, s_red, t);
+        fold_band_partials_multi_256<kPartKinds>(L.band_parts, pin_off, kMaxParts, nparts_prev, L.nbands, s_red, t);
         const double rzd = t[0], rrd = t[1], pq = t[2], qz = t[3], qmq = t[4], rq = t[5], qq = t[6];
         alpha = prev.rz / (float)pq;                 // ref .cu:1169
         nalpha = (float)(-1. * (double)alpha);       // ref .cu:1174
@@ -311,8 +272,8 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     float *__restrict__ pout_u = L.pf_u[k % 3];
     float *__restrict__ pout_v = L.pf_v[k % 3];
     const bool defer = L.defer_x != 0;
-    const bool x_two = !(Q_ABL & 64) && defer && !first && (k & 1) == 0;            // (ablation 64: the x work compiled out)
-    const bool x_one = !(Q_ABL & 64) && !first && (!defer || ((k & 1) == 1 && !active));
+    const bool x_two = defer && !first && (k & 1) == 0;
+    const bool x_one = !first && (!defer || ((k & 1) == 1 && !active));
     const bool x_read = x_two ? (k > 2) : (defer ? (k >= 3) : (k > 1));
     const float alpha2 = x_two ? L.alpha[(k - 2) & 1] : 0.f;
     double acc_pq = 0., acc_qz = 0., acc_qmq = 0., acc_rq = 0., acc_qq = 0., acc_rz = 0., acc_rr = 0.;
@@ -341,10 +302,10 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
         dma_cur = tile_is_interior(ftx0, fty0, w, h, y1);
         if (dma_cur) {
             dma_p_tile<BANDED>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ftx0, fty0, pitch, lane, wv);
-            if (!(Q_ABL & 2)) dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ftx0, fty0, pitch, lane, wv);
+            dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ftx0, fty0, pitch, lane, wv);
         }
     }
-    for (int t = (Q_ABL & 8) ? tr.end : tr.first; t < tr.end; t += tr.step, parity ^= 1, round++) {
+    for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1, round++) {
         float *const s_nu = s_nu2 + parity * NSZ, *const s_nv = s_nv2 + parity * NSZ;
         const int tx0 = ((t % tiles_x + (rotate ? round : 0)) % tiles_x) * TX, ty0 = y0 + (t / tiles_x) * TY;
         // ---- loads of the thread's two tile groups first (r_{k-1} and the operator; addresses of groups beyond a ragged
@@ -430,13 +391,13 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
                 dma_next = tile_is_interior(ntx0, nty0, w, h, y1);
                 if (dma_next) {
                     dma_p_tile<BANDED>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);
-                    if (!(Q_ABL & 2)) dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ntx0, nty0, pitch, lane, wv);
+                    dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ntx0, nty0, pitch, lane, wv);
                 }
             }
             dma_cur = dma_next;
         }
         // ---- phase 2: q_k on the tile and the partial sums (q_k is not stored: the next launch forms it again)
-        if (active && !(Q_ABL & 4)) {
+        if (active) {
             if (Q_P2 && interior) {
 #define Q_INT true
 #include "pcg_fused_q_phase2.inc"
@@ -446,9 +407,6 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
 #include "pcg_fused_q_phase2.inc"
 #undef Q_INT
             }
-        } else if (Q_TOUCH) {
-            // (a launch past the stop test skips phase 2: the loads phase 1 did not use -- the weights, when k = 0 -- count as used here)
-            Q_TOUCH_SLOT(0); Q_TOUCH_SLOT(1);
         }
     }
     if (!active) return;
@@ -456,33 +414,6 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     const double accs[kPartKinds] = {acc_rz, acc_rr, acc_pq, acc_qz, acc_qmq, acc_rq, acc_qq};
     double tot[kPartKinds];
     block_sum_multi_256<kPartKinds>(accs, s_red, tot);
-    if (Q_LASTFOLD && !BANDED) {
-        // every workgroup: partials write-through (sc1), drained, then one add to the arrival counter; whoever's add came last folds
-        __shared__ int s_last;
-        if (tid == 0) {
-#pragma unroll
-            for (int j = 0; j < kPartKinds; j++) __hip_atomic_store(&own_blk[j * kMaxParts + blockIdx.x], tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int old = __hip_atomic_fetch_add(&L.st[k & 1].pad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
-        }
-        __syncthreads();
-        if (s_last) {            // uniform
-            double v7[kPartKinds], out7[kPartKinds];
-#pragma unroll
-            for (int j = 0; j < kPartKinds; j++) v7[j] = 0.;
-            for (int i = tid; i < (int)gridDim.x; i += 256) {
-#pragma unroll
-                for (int j = 0; j < kPartKinds; j++) v7[j] += __hip_atomic_load(&own_blk[j * kMaxParts + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            block_sum_multi_256<kPartKinds>(v7, s_red, out7);
-            if (tid == 0) {
-#pragma unroll
-                for (int j = 0; j < kPartKinds; j++) own_blk[j * kMaxParts + (kMaxParts - 1)] = out7[j];
-            }
-        }
-        return;
-    }
     if (tid == 0) {
 #pragma unroll
         for (int j = 0; j < kPartKinds; j++) own_blk[j * kMaxParts + blockIdx.x] = tot[j];

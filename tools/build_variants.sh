@@ -2,7 +2,10 @@
 # Builds named variants of the LDS-DMA PCG kernel (octane_amd/csrc/pcg_fused_q_dma.hip) as whole libraries under octane_amd/variants/
 # (git-ignored; they travel to the GPU box), each with its register counts.  tools/time_variants.py times them on the GPU
 # (OCTANE_LIB=<variant>.so selects the library).  Run `make -C octane_amd/csrc` first.
-# usage: tools/build_variants.sh "name:flags" ...   e.g.  "t2n:-DQ_TOUCH=1" "abl1:-DQ_ABL=1 -mllvm -amdgpu-sched-strategy=max-ilp"
+# usage: tools/build_variants.sh "name:flags" ...   e.g.  "nop2:-DQ_P2=0" "norot:-DQ_ROT=0 -mllvm -amdgpu-sched-strategy=max-ilp"
+# (round 5: the default-off EXPERIMENT switches of rounds 2-4 -- Q_ABL ablations, Q_LASTFOLD, Q_TOUCH -- were removed from the kernel, the object
+# byte-identical before and after; their measurements are in EXPERIMENTS.md 5 / 8 and profiles/r3_ablation_q_dma.txt, r4_lastfold.txt.  The text
+# switches that DEFINE the shipped kernel -- Q_P1, Q_P2, Q_LB, Q_A2BR, Q_VMN, Q_ROT -- remain.)
 set -e
 cd "$(dirname "$0")/../octane_amd/csrc"
 mkdir -p ../variants /tmp/octane_vb
