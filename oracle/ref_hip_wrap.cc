@@ -1,7 +1,7 @@
 /* ref_hip_wrap.cc -- forwarding wrapper for the CROSS-CHECK build of the reference's two CUDA translation units (oracle/Makefile,
  * target `refhip`): src/oct_variational_optical_flow.cu and src/oct_pix2uv_cuda.cu are passed through the image's own hipify-perl WHERE
- * THEY LIE, the translated text goes to oracle/_ref/hipified/ (git-ignored, never committed), hipcc builds it for gfx950 together with
- * this file into oracle/_ref/liboct_ref_hip.so.  TEST INFRASTRUCTURE ONLY, and a TOOL STAND-IN (hipify + hipcc in place of nvcc, ocml in
+ * THEY LIE, the translated text goes to a scratch directory outside the repository (never committed, never shipped), hipcc builds it for
+ * gfx950 together with this file into oracle/_ref/liboct_ref_hip.so.  TEST INFRASTRUCTURE ONLY, and a TOOL STAND-IN (hipify + hipcc in place of nvcc, ocml in
  * place of libdevice, 64-wide wavefronts in place of 32-wide warps): by the rules of this build it pins nothing -- the oracle stays
  * "parity unpinned" -- but it is the one independent witness the restatement in vof_oracle.c / pix2uv_oracle.c can get: the reference's
  * OWN kernel text executing on the MI355X.  This file only forwards plain-C arguments into the reference's entry

@@ -1,7 +1,7 @@
 """Round 5 (VERDICT r4 "Next round" item 8, optional): a CROSS-CHECK of the restatement with the reference's own kernel text.
 
 oracle/Makefile `refhip` passes ref src/oct_variational_optical_flow.cu and src/oct_pix2uv_cuda.cu through the image's hipify-perl where
-they lie (translated text and binary under oracle/_ref/, git-ignored, never committed) and builds them with hipcc for gfx950; here that
+they lie (translated text in a scratch directory outside the repository, the binary under oracle/_ref/, git-ignored) and builds them with hipcc for gfx950; here that
 library -- the reference's cooperative kernel, its CSR matrix, its float atomics, its managed memory -- runs on the MI355X next to the HIP
 path and the CPU oracle on the same inputs.  It is a TOOL STAND-IN (hipify + hipcc for nvcc, ocml for libdevice, 64-wide wavefronts):
 by this build's rules it pins nothing and DESIGN.md keeps saying "parity unpinned"; it is the only independent witness the oracle has.
