@@ -240,3 +240,47 @@ def test_config3_quarter_scale_disc_scene_four_bands_and_plain_match_oracle(capi
     assert (a == 0).mean() > 0.2
     assert dp < INVESTIGATE and dt < INVESTIGATE
     assert rel_l2(ut, vt, up, vp) < INVESTIGATE
+
+
+def test_headline_r1_5000_disc_scene_matches_oracle(capi, oracle):
+    """Round 5: the headline configuration (5000 x 5000, kiters 8, liters 3, cgiters 30) on the DATA-SHAPED scene -- the Earth disc filling
+    the frame's width on exact zeros (22 % space pixels), limb taper, int16 counts, sensor noise, a saturated patch (synth.disc_scene;
+    ref src/oct_navcal_cuda.cu:81-93).  The finest levels run the LDS-DMA q-recomputing kernel with its border-free interior tiles
+    crossing the disc edge, the mid-size levels the persistent solves.  At this size the oracle's own variants agree to ~1e-5, so the
+    suite's 2e-5 is asserted against the primary oracle, with equal iteration counts."""
+    import torch
+    n = 5000
+    a, b = synth.disc_scene(n, n, seed=20240615, device="cuda")
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    torch.cuda.empty_cache()
+    prm = dict(kiters=8, liters=3, cgiters=30)
+    ug, vg, ig, tg = _plain(capi, a, b, prm)
+    assert np.isfinite(ug).all() and np.isfinite(vg).all()
+    uo, vo, io, to = _oracle(oracle, a, b, prm)
+    d = rel_l2(ug, vg, uo, vo)
+    m = synth.disc_mask(n, n) == 1
+    tu, tv = synth.true_lattice_flow(n, n)
+    eg = (np.abs(ug - tu)[m].mean(), np.abs(vg - tv)[m].mean())
+    _report("headline_R1_5000_disc", f"{n}x{n}", prm, d, io, ig, to, tg,
+            f"[{float((a == 0).mean()):.2f} of the pixels are exact zeros; inside the disc {rel_l2(ug[m], vg[m], uo[m], vo[m]):.2e}; "
+            f"mean |flow - truth| inside the disc {eg[0]:.3f}, {eg[1]:.3f} px]")
+    assert io == ig == 8 * 3 * 3 * 30
+    assert d < BAR
+    assert d < INVESTIGATE
+
+
+def test_config1_2000_three_channels_disc_scene_matches_oracle(capi, oracle):
+    """Round 5: BASELINE configs[1]'s size with THREE channels (the reference's loop handles 1 ... 3 alike, ref .cu:749-829; the file reader
+    resamples channels 2 and 3 onto channel 1's grid) on the data-shaped scene with the limb through a corner of the frame: the
+    three-channel template instances of k_assemble at a BASELINE size, all levels."""
+    n = 2000
+    kw = dict(centre=(0.15, 0.1), span=0.55)
+    a, b = synth.disc_scene(n, n, seed=7, nchan=3, **kw)
+    prm = dict(kiters=6, liters=3, cgiters=30)
+    uo, vo, io, to = _oracle(oracle, a, b, prm)
+    ug, vg, ig, tg = _plain(capi, a, b, prm)
+    d = rel_l2(ug, vg, uo, vo)
+    _report("config1_2000_nc3_disc", f"{n}x{n}x3", prm, d, io, ig, to, tg, f"[{float((a[0] == 0).mean()):.2f} of the pixels are exact zeros]")
+    assert np.isfinite(ug).all() and np.isfinite(vg).all()
+    assert io == ig == 6 * 3 * 3 * 30
+    assert d < INVESTIGATE
