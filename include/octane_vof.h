@@ -144,8 +144,10 @@ int octane_vof_plan_get_profile(octane_vof_plan *plan, octane_vof_profile *out);
  * launch, the first GNC step's weights are the constant -1 and are not read): bench.py prices each kind on its own bytes.  Returns
  * the number of launches recorded; writes min(that, cap) values. */
 int octane_vof_plan_get_launch_times(octane_vof_plan *plan, float *ms, int cap);
-/* Developer knob, per plan: key in {overlap, persist, persist_p, persist_step, persist_max_g, lane_mode, small, small_max, pass_a,
- * max_blocks, reverse_b, xcd, nt, defer_x, unit_w, fused, fused_q, fused_rows, q_dma, asm_fast, trace_levels}.  Results agree for every
+/* Developer knob, per plan: key in {overlap, persist, persist_p, persist_step, persist_max_g, persist_chain, lane_mode, small, small_max,
+ * pass_a, max_blocks, reverse_b, xcd, nt, defer_x, unit_w, fused, fused_q, fused_rows, q_dma, asm_fast, trace_levels}.  lane_mode: 0 the plan
+ * runs alone on its device; 2 beside ONE other plan (the two lanes of octane_vof_batch_run: persistent solves concurrent, each capped at half
+ * the compute units); 1 beside two or more (only the tiny levels keep the persistent solve).  Results agree for every
  * setting to the last bits of the PCG scalars (the grouping of the fp64 partial sums follows the grid); only speed changes.
  *
  * ENVIRONMENT.  The product library reads exactly these variables (none is needed):
