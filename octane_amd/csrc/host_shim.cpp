@@ -10,9 +10,20 @@
 // zero_guess: the caller KNOWS uarr / varr hold the zero first guess (oct_optical_flow below, without -firstguess): it is then not uploaded
 static void variational_flow(Image geo1i, Image geo2i, float *uarr, float *varr, int nx, int ny, OFFlags args, bool zero_guess);
 
+// OCTANE_HOST_TRACE=1: every entry point reports on stderr what arrived through the reference's by-value signature BEFORE anything touches
+// the GPU -- what tests/test_ref_caller_link.py reads when the reference's own caller object (src/oct_optical_flow.cc, compiled where it
+// lies with the reference's headers) is linked against this library on a machine without a GPU.
+static bool host_trace() { const char *e = getenv("OCTANE_HOST_TRACE"); return e && *e && *e != '0'; }
+
 void oct_variational_optical_flow(Image geo1i, Image geo2i, float *CTH, float *uarr, float *varr,
                                   int nx, int ny, int nc, OFFlags args)
 {
+    if (host_trace())
+        fprintf(stderr, "TRACE oct_variational_optical_flow nx=%d ny=%d nc=%d geo1i={%d,%d,%d,%g} geo2i={%d,%d,%d,%g} u0=%g v0=%g "
+                "args={alpha=%g lambda=%g lambdac=%g scaleF=%g scsig=%g kiters=%d liters=%d cgiters=%d dozim=%d setdevice=%d ftype=%s}\n",
+                nx, ny, nc, geo1i.nrow, geo1i.ncol, geo1i.nchannels, geo1i.data ? geo1i.data[0] : 0.f, geo2i.nrow, geo2i.ncol, geo2i.nchannels,
+                geo2i.data ? geo2i.data[0] : 0.f, uarr ? uarr[0] : 0.f, varr ? varr[0] : 0.f, args.alpha, args.lambda, args.lambdac, args.scaleF,
+                args.scsig, args.kiters, args.liters, args.cgiters, args.dozim, args.setdevice, args.ftype.c_str());
     (void)CTH; (void)nc;         // CTH is never dereferenced (dodiscrete is hard-wired false, ref .cu:1302); nc is ignored (ref .cu:1223)
     variational_flow(geo1i, geo2i, uarr, varr, nx, ny, args, false);
 }
@@ -76,6 +87,9 @@ void oct_pix2uv_cuda(GOESVar &g, double t2, float *uarr, float *varr, short *ur,
     nav.g2xOffset = g.nav.g2xOffset; nav.g2yOffset = g.nav.g2yOffset;
     nav.lat1 = g.nav.lat1; nav.lon1 = g.nav.lon1; nav.lon0 = g.nav.lon0; nav.R = g.nav.R;
     nav.minX = g.nav.minX; nav.minY = g.nav.minY; nav.nx = (int)g.nav.nx; nav.ny = (int)g.nav.ny;
+    if (host_trace())
+        fprintf(stderr, "TRACE oct_pix2uv_cuda t1=%g t2=%g nav={nx=%d ny=%d pph=%g xScale=%g yOffset=%g} pixuv=%d setdevice=%d\n", g.t, t2, nav.nx, nav.ny,
+                nav.pph, (double)nav.xScale, (double)nav.yOffset, args.pixuv, args.setdevice);
     int dev = args.setdevice;
     if (args.pixuv == 0) {                   // the GPU is only needed for the navigated branch
         const int ndev = octane_device_count();

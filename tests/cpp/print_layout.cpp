@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <string>
+#include <type_traits>
 #include "image.h"
 #include "goesread.h"
 #include "offlags.h"
@@ -13,6 +14,10 @@
 int main()
 {
     printf("sizeof Image %zu OFFlags %zu GOESNAVVar %zu GOESVar %zu\n", sizeof(Image), sizeof(OFFlags), sizeof(GOESNAVVar), sizeof(GOESVar));
+    // what decides HOW an aggregate travels by value (registers / stack copy against a hidden reference to a temporary)
+    printf("trivially_copyable Image %d OFFlags %d GOESNAVVar %d GOESVar %d  trivially_destructible Image %d OFFlags %d\n",
+           (int)std::is_trivially_copyable<Image>::value, (int)std::is_trivially_copyable<OFFlags>::value, (int)std::is_trivially_copyable<GOESNAVVar>::value,
+           (int)std::is_trivially_copyable<GOESVar>::value, (int)std::is_trivially_destructible<Image>::value, (int)std::is_trivially_destructible<OFFlags>::value);
     P(Image, data); P(Image, nrow); P(Image, ncol); P(Image, nchannels);
     P(OFFlags, farn); P(OFFlags, pixuv); P(OFFlags, dopolar); P(OFFlags, domerc); P(OFFlags, doahi); P(OFFlags, dosrsal);
     P(OFFlags, dososm); P(OFFlags, dofirstguess); P(OFFlags, ftype); P(OFFlags, dointerp); P(OFFlags, docorn);
