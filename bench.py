@@ -860,6 +860,9 @@ def main():
         except (OSError, ValueError):
             pass
 
+    # N > 1: what the collective library saw (world size after init_process_group, a sum all-reduce of ones, every rank's device uuid):
+    # "RCCL saw N ranks on N distinct GPUs" can be read off the line alone.  Collective, after the timed region.
+    census = shard.rank_census(backend, device=dev, local=local) if world > 1 else None
     out = None
     if rank == 0:
         dstate = device_state(torch, dev)
@@ -891,6 +894,8 @@ def main():
                "placement_trials": trials_ms,
                "device": dstate,
                "roofline": roof, "cpu_baseline": cpu}
+        if census is not None:
+            out["ranks"] = census
     # N > 1: after the timed pair headline rank 0 measures the two multi-GPU configurations of BASELINE.json -- configs[3] (one full-disk
     # frame, one row band per rank: the first time RCCL / IPC mappings see N real devices) and configs[4] (64 pairs sharded) -- as
     # bounded, NON-FATAL side legs in CHILD jobs of N fresh ranks each: whatever happens in them -- an error, a hang, a GPU fault that

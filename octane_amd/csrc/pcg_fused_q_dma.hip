@@ -32,16 +32,21 @@
 #define Q_VMCNT_U 10    // ... 5 per slot where the weights are the constant -1
 #endif
 #ifndef Q_REV
-#define Q_REV 0         // 1: launches with odd k walk the tiles backwards (the same tile -> workgroup map, mirrored), 2: the even ones do:
-                        // a launch then starts on the tiles whose r, p and operator lines the previous one touched last (Infinity Cache)
+#define Q_REV 1         // launches with odd k walk the tiles BACKWARDS (the same tile -> workgroup map, mirrored; 2: the even ones do; 0: none):
+                        // a launch starts on the tiles whose r, p and operator lines the previous launch touched last, so its first
+                        // fronts read them out of the 256 MB Infinity Cache instead of HBM.  Round 6, 5000^2 (profiles/r6_reverse_walk.txt):
+                        // 291.5 -> 287.0 us per launch; with Q_TAILC 285.3-286.1 (-2.0 %); nothing at 2500^2 / 2000^2 (not HBM-bound).
 #endif
 #ifndef Q_TAILC
-#define Q_TAILC 0       // r_k / p_k of a workgroup's last Q_TAILC tiles are stored WITHOUT the streaming hint (for the next launch's first tiles)
+#define Q_TAILC 6       // r_k / p_k of a workgroup's last Q_TAILC tiles are stored WITHOUT the streaming hint, so that they are still in the
+                        // cache when the next launch starts there (~4.9 Mpixel of a launch's tail fit beside what else the tail allocates);
+                        // only on walks of Q_TAILMIN rounds or more: on a level of 6 rounds (2500^2) it is +3 % (the whole level allocates)
 #endif
-#ifndef Q_TAILNT
-#define Q_TAILNT 0      // experiment: 1 = the p_{k-1} tile DMA of the tail tiles carries the streaming hint (dead lines, keep them out of the cache),
-                        // 2 = the own r_{k-1} loads too
+#ifndef Q_TAILMIN
+#define Q_TAILMIN 12
 #endif
+// Measured and not kept (round 6): the streaming hint on the tail tiles' p_{k-1} DMA (their lines are dead afterwards) gives the reverse
+// walk's gain back (291.6 us); on the own r loads as well it is the run-time-policy trap of EXPERIMENTS 8 (+8 %).
 #define Q_STR2(x) #x
 #define Q_STR(x) Q_STR2(x)
 #ifndef Q_ROT
@@ -144,7 +149,7 @@ __device__ __forceinline__ bool tile_is_interior(int tx0, int ty0, int w, int h,
 // contiguous bytes at column kQOff - 4 of the padded LDS row), rows dealt over the four waves.  The destination is M0 + lane * 16.
 // A row band takes the staged rows above its first / below its last row from the neighbouring band's planes (up_* / dn_*; the
 // band's own planes for a whole level).
-template <bool BANDED, bool NT = false>
+template <bool BANDED>
 __device__ __forceinline__ void dma_p_tile(const float *pin_u, const float *pin_v, const float *up_u, const float *up_v, const float *dn_u,
                                            const float *dn_v, int y0, int y1, float *s_ou, float *s_ov, int tx0, int ty0, int pitch, int lane, int wv)
 {
@@ -160,17 +165,10 @@ __device__ __forceinline__ void dma_p_tile(const float *pin_u, const float *pin_
             const unsigned du = __builtin_amdgcn_readfirstlane(base_u + (unsigned)(r * kQCols + kQOff - 4) * 4u);
             const unsigned dv = __builtin_amdgcn_readfirstlane(base_v + (unsigned)(r * kQCols + kQOff - 4) * 4u);
             unsigned keep;
-            if (NT) {
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(gu), "s"(du) : "memory");
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(gv), "s"(dv) : "memory");
-            } else {
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(gu), "s"(du) : "memory");
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(gv), "s"(dv) : "memory");
-            }
         }
     }
 }
@@ -328,7 +326,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     for (int t = tr.first; t < tr.end; t += tr.step, parity ^= 1, round++) {
         float *const s_nu = s_nu2 + parity * NSZ, *const s_nv = s_nv2 + parity * NSZ;
         const int tt = rev ? ntiles - 1 - t : t;
-        const bool tailc = Q_TAILC > 0 && t + Q_TAILC * tr.step >= tr.end;
+        const bool tailc = Q_TAILC > 0 && tr.end - tr.base >= Q_TAILMIN * tr.step && t + Q_TAILC * tr.step >= tr.end;
         const int tx0 = ((tt % tiles_x + (rotate ? round : 0)) % tiles_x) * TX, ty0 = y0 + (tt / tiles_x) * TY;
         // ---- loads of the thread's two tile groups first (r_{k-1} and the operator; addresses of groups beyond a ragged
         // edge are clamped into the frame, their values never used), so that they are in flight while phase 0 waits for p
@@ -341,8 +339,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
             const bool valid = y < y1 && x0 < w;
             const unsigned o = valid ? (unsigned)(y * pitch + x0) * 4u : 0u;
             QCoef &c = c3[slot];
-            if (Q_TAILNT == 2) { *(float4 *)r3u[slot] = ld4_if(at(rin_u, o), tailc); *(float4 *)r3v[slot] = ld4_if(at(rin_v, o), tailc); }
-            else { *(float4 *)r3u[slot] = ld4(at(rin_u, o)); *(float4 *)r3v[slot] = ld4(at(rin_v, o)); }
+            *(float4 *)r3u[slot] = ld4(at(rin_u, o)); *(float4 *)r3v[slot] = ld4(at(rin_v, o));
             *(float4 *)c.a1 = ld4(at(L.a1, o)); *(float4 *)c.a4 = ld4(at(L.a4, o));
             // no streaming hint by default (bit 256, not the stored-q kernels' bit 8): the neighbouring tiles' rings read these
             // lines too, -1.5 % without it.  The switch stays because the kernel is 3 % slower without the branch (sic).
@@ -414,9 +411,6 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
                 const int ntx0 = ((tnn % tiles_x + (rotate ? round + 1 : 0)) % tiles_x) * TX, nty0 = y0 + (tnn / tiles_x) * TY;
                 dma_next = tile_is_interior(ntx0, nty0, w, h, y1);
                 if (dma_next) {
-                    if (Q_TAILNT && Q_TAILC > 0 && tn + Q_TAILC * tr.step >= tr.end)
-                        dma_p_tile<BANDED, true>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);
-                    else
                     dma_p_tile<BANDED>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);
                     dma_ring<UNITW ? 5 : kRingOps, BANDED>(ring_plane, ring_shift, rb, s_ring, ntx0, nty0, pitch, lane, wv);
                 }

@@ -756,11 +756,32 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
                     if (k1 >= prm.cgiters) break;
                 }
             } else if (pl->use_fused) {
+                std::vector<double> sums;                   // debug tap only: what every launch summed and decided
                 for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182, one kernel per iteration
                     e = ev_begin(pl, s, EV_PASS_A, pf);
                     launch_pcg_fused(s, L, it, it == 0 ? g_asm : g_f, g_f, pl->tol);
                     ev_end(e, s);
+                    if (pl->trace && L.nbands == 1) {
+                        // Tag "pcg_sums": per launch ten doubles -- the launch's own DIRECT sums over the state it formed (r.z, r.r, p.q, q.z,
+                        // q.M^-1 q, r.q, q.q: the seven partial-sum kinds folded on the host in index order), then the PcgState it left
+                        // (rz = the r.z it USED: the assembly's direct sum at launch 0, the one-step recurrence afterwards; stopped; iters).
+                        // tests/test_gpu_parity.py forms the next launch's predicted r.z / r.r from row k and compares them with row k + 1's
+                        // direct sums (the second arithmetic freedom of DESIGN 4).  Delivered as nx = 20 floats per row = the doubles' bytes.
+                        HIP_TRY(hipStreamSynchronize(s));
+                        std::vector<double> blk((size_t)kPartBlock);
+                        HIP_TRY(hipMemcpy(blk.data(), L.part_own + (size_t)(it & 1) * kPartBlock, (size_t)kPartBlock * sizeof(double), hipMemcpyDeviceToHost));
+                        PcgState st;
+                        HIP_TRY(hipMemcpy(&st, &L.st[(it + 1) & 1], sizeof(st), hipMemcpyDeviceToHost));
+                        for (int j = 0; j < kPartKinds; j++) {
+                            double t = 0.;
+                            for (int i = 0; i < g_f; i++) t += blk[(size_t)j * kMaxParts + i];
+                            sums.push_back(t);
+                        }
+                        sums.push_back((double)st.rz); sums.push_back((double)st.stopped); sums.push_back((double)st.iters);
+                    }
                 }
+                if (pl->trace && !sums.empty() && !(pl->trace_levels > 0 && k >= pl->trace_levels))
+                    pl->trace(pl->trace_user, "pcg_sums", k, gnc, l, reinterpret_cast<const float *>(sums.data()), 20, (int)(sums.size() / 10), 1);
                 e = ev_begin(pl, s, EV_UPD, pf);
                 launch_flow_update_fused(s, L, prm.cgiters, g_f);   // ref .cu:1185-1195 (+ the last x update)
                 ev_end(e, s);

@@ -45,5 +45,35 @@ def gather_objects(obj, dst: int = 0):
     return out
 
 
+def rank_census(backend: str, device=None, local: int | None = None):
+    """What the collective library saw, for the record of an N-rank bench line: every rank reports who it is and which device it
+    drives, and a sum all-reduce of ones over the backend (RCCL on device tensors under "nccl") has to come back as the world size.
+    Collective: every rank calls it.  Rank 0 gets {"backend", "world_size", "allreduce_of_ones", "ranks": [{rank, local_rank, host,
+    pid, device, name, uuid, pci_bus_id}, ...]} -- distinct uuids = distinct GPUs --, the others None."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    me = {"rank": int(os.environ.get("RANK", "0")), "local_rank": local, "host": socket.gethostname(), "pid": os.getpid()}
+    if device is not None and getattr(device, "type", "cpu") == "cuda":
+        me["device"] = str(device)
+        try:                                            # a property this torch does not have must not cost an N-rank run its line
+            pr = torch.cuda.get_device_properties(device)
+            me.update(name=pr.name, uuid=str(getattr(pr, "uuid", "")) or None,
+                      pci_bus_id=(f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}" if hasattr(pr, "pci_bus_id") else None))
+        except Exception as e:                          # noqa: BLE001
+            me["device_info_error"] = repr(e)
+    if not dist.is_available() or not dist.is_initialized():
+        return {"backend": None, "world_size": 1, "allreduce_of_ones": 1, "ranks": [me]}
+    me["rank"] = dist.get_rank()
+    one = torch.ones(1, dtype=torch.int64, device=device if backend == "nccl" else None)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    ranks = gather_objects(me, dst=0)
+    if dist.get_rank() != 0:
+        return None
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": int(one.item()),
+            "ranks": sorted(ranks, key=lambda r: r["rank"]),
+            "distinct_devices": len({r.get("uuid") or r.get("pci_bus_id") or (r["host"], r.get("device")) for r in ranks})}
+
+
 def whole_job_mpix(world_pixels_per_step: int, steps: int, seconds_max: float) -> float:
     return world_pixels_per_step * steps / seconds_max / 1e6

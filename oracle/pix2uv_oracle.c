@@ -41,7 +41,7 @@
  * A build with -ffp-contract=fast (the "fma" flavour) additionally lets the compiler fuse what it likes: the site mask is for the
  * strict build. */
 #define P2U_NSITES 13
-static unsigned g_sites = 0u;
+static __thread unsigned g_sites = 0u;
 void oct_oracle_pix2uv_fma_sites(unsigned mask) { g_sites = mask; }
 int oct_oracle_pix2uv_nsites(void) { return P2U_NSITES; }
 #define SITE(k) (g_sites & (1u << (k)))

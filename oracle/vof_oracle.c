@@ -521,7 +521,7 @@ void oct_oracle_spmv(const float *val, const int *rowptr, const int *col, const 
  *                 atomicAdd (.cu:184) taken in block order.
  * Large-frame parity tests use the second: it is what a GPU run of the reference computes, up to
  * the order of its atomics. */
-static int g_dot_threads = 0;
+static __thread int g_dot_threads = 0;   /* per calling thread: two host threads may run the oracle side by side (tests/test_gpu_fullsize.py prefetches) */
 void oct_oracle_set_dot_schedule(int threads) { g_dot_threads = (threads > 0) ? (threads + 127) / 128 * 128 : 0; }
 
 static float dotf(const float *a, const float *b, int n)

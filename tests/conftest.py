@@ -14,6 +14,33 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The full-size oracle cases (tests/test_gpu_fullsize.py) run LAST: their CPU oracle legs are computed by a worker thread from
+    collection time on, under the GPU work of every other module (see that file's CASES)."""
+    last = [it for it in items if it.nodeid.split("::")[0].endswith("test_gpu_fullsize.py")]
+    if last:
+        items[:] = [it for it in items if it not in last] + last
+
+
+def pytest_collection_finish(session):
+    if session.config.option.collectonly or os.environ.get("OCT_NO_ORACLE_PREFETCH") == "1":
+        return
+    names = [getattr(getattr(it, "function", None), "_oracle_case", None) for it in session.items]
+    names = [n for n in names if n]
+    if not names:
+        return
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return                               # the tests will skip / fail by themselves; nothing to compute ahead
+        from oracle import oct_oracle
+        oct_oracle.build()
+        mod = next(it.module for it in session.items if getattr(getattr(it, "function", None), "_oracle_case", None))
+        mod.PREFETCH.start(oct_oracle, names)
+    except Exception as e:                       # noqa: BLE001 -- the cases are then computed in place
+        print(f"conftest: oracle prefetch not started ({e!r})", file=sys.stderr)
+
+
 def rel_l2(u, v, uo, vo):
     """Relative L2 distance of the flow field (u,v) from (uo,vo): the parity metric of
     BASELINE.json's north_star (bar: 1e-4)."""

@@ -165,6 +165,75 @@ def test_early_exit_of_the_pcg_loop(capi, oracle, golden_flow):
     assert ig == io
 
 
+def _recurrence_rows(store, tol):
+    """From the 'pcg_sums' rows of the debug tap (one per launch: the launch's own direct sums rz rr pq qz qmq rq qq over the
+    state it formed, then the PcgState it left: rz used, stopped, iterations): the NEXT launch's r.z / r.r by the kernels'
+    one-step recurrence (pcg_fused_q_dma.hip:253-262, pcg_kernels.hip:714-722, formed here exactly as there: alpha in float
+    from floats, the quadratic in double) next to the direct sums the next launch formed over the residual it wrote."""
+    out = []
+    for key in sorted(k for k in store if k[0] == "pcg_sums"):
+        rows = store[key].reshape(-1).view(np.float64).reshape(-1, 10)
+        for k in range(len(rows) - 1):
+            rz, rr, pq, qz, qmq, rq, qq, rz_used, stopped, _ = rows[k]
+            if stopped or rows[k + 1][8]:
+                break                                   # the launch after a stop writes nothing
+            alpha = np.float32(rz_used) / np.float32(pq)              # ref .cu:1169
+            a = float(alpha)
+            rz_pred = rz - 2. * a * qz + a * a * qmq
+            rr_pred = rr - 2. * a * rq + a * a * qq
+            assert np.float32(rz_pred) == np.float32(rows[k + 1][7])   # the next launch stored exactly this as the r.z it used
+            out.append((key[1:], k + 1, rr_pred, rows[k + 1][1], rz_pred, rows[k + 1][0]))
+    return out
+
+
+@pytest.mark.parametrize("case", ["early_exit_60x44", "q_dma_2304x1100"])
+def test_one_step_recurrence_of_rz_and_rr_agrees_with_the_direct_sums(capi, golden_flow, case):
+    """The SECOND arithmetic freedom the HIP path takes (the first is the summation order): r.z and r.r of the residual a
+    launch is about to form -- hence beta and the stop test `residc > tol` (ref .cu:1131) -- come from
+    (r.z)_k = (r.z)_{k-1} - 2 alpha (q.z)_{k-1} + alpha^2 (q.M^-1 q)_{k-1}, likewise r.r, where the reference sums over the
+    residual itself (ref .cu:1135-1178).  Base values are DIRECT sums of the previous launch, nothing is chained.  Logged per
+    iteration (pytest -rP) and asserted: predicted and direct agree to 1e-6 relative wherever r.r > 10 tol -- on the tolerance-exit
+    case of test_early_exit_of_the_pcg_loop (per-launch stored-q kernel: the persistent and single-workgroup solves switched
+    off) and on a level the LDS-DMA kernel runs (>= 2 Mi pixels)."""
+    tol = 1e-8                                           # ref .cu:1240
+    if case == "early_exit_60x44":
+        name = "lat_60x44_brox_hint"
+        a, b = golden_flow[name + "_img1"], golden_flow[name + "_img2"]
+        u0 = np.full(a.shape[1:], 2.0, np.float32); v0 = np.full(a.shape[1:], -1.0, np.float32)
+        prm = capi.FlowParams(kiters=2, dozim=0, lambdac=0.5, alpha=8.0, lambda_=0.5)
+        want_its = int(golden_flow[name + "_its"])
+    else:
+        a, b = synth.lattice_scene(2304, 1100, seed=5)
+        u0 = v0 = None
+        prm = capi.FlowParams(kiters=1, liters=1, cgiters=30)
+        want_its = 90
+    ny, nx = a.shape[-2:]
+    pl = capi.Plan(nx, ny, 1, prm)
+    try:
+        pl.tune("persist", 0); pl.tune("small", 0)       # one launch per iteration on every level
+        store = {}
+        pl.set_trace(store)
+        pl.run_host(a, b, u0, v0)
+        assert pl.last_iterations() == want_its           # the trace changes nothing: the same exits as the oracle's
+        pl.set_trace(None)
+    finally:
+        pl.close()
+    rows = _recurrence_rows(store, tol)
+    assert len(rows) >= want_its // 2
+    worst = 0.0
+    for key, k, rr_p, rr_d, rz_p, rz_d in rows:
+        e_rr = abs(rr_p - rr_d) / abs(rr_d) if rr_d else 0.0
+        e_rz = abs(rz_p - rz_d) / abs(rz_d) if rz_d else 0.0
+        print(f"RECURRENCE {case} level/gnc/l={key} launch {k:2d}: r.r predicted {rr_p:.9e} direct {rr_d:.9e} (rel {e_rr:.1e})   "
+              f"r.z predicted {rz_p:.9e} direct {rz_d:.9e} (rel {e_rz:.1e})")
+        if rr_d > 10 * tol:
+            worst = max(worst, e_rr, e_rz)
+            assert e_rr <= 1e-6 and e_rz <= 1e-6, (key, k, rr_p, rr_d, rz_p, rz_d)
+        # the stop decision itself: the two values are on the same side of tol except within rounding of it
+        assert (rr_p > tol) == (rr_d > tol) or abs(rr_p - rr_d) <= 1e-6 * tol + 1e-6 * abs(rr_d)
+    print(f"RECURRENCE {case}: {len(rows)} launches compared, worst relative difference above 10 tol: {worst:.2e}")
+
+
 def test_identical_images_give_zero_flow_without_nans(capi, oracle):
     """b == 0 -> residual 0 -> the loop never runs (ref .cu:1131); 0/0 must not appear."""
     a, _ = synth.lattice_scene(80, 64, seed=3)

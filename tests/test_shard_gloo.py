@@ -47,8 +47,9 @@ def _worker(rank, world, port, npairs, q):
     local = time.perf_counter() - t0 if r == 1 else 0.01
     tmax = shard.max_over_ranks(local)
     gathered = shard.gather_objects(res, dst=0)
+    census = shard.rank_census("gloo")                  # what bench.py --gpus N adds to its line as "ranks"
     if r == 0:
-        q.put((gathered, tmax))
+        q.put((gathered, tmax, census))
     dist.destroy_process_group()
 
 
@@ -61,10 +62,12 @@ def test_two_ranks_shard_a_batch_and_rank0_gathers():
     procs = [ctx.Process(target=_worker, args=(r, world, port, npairs, q)) for r in range(world)]
     for p in procs:
         p.start()
-    gathered, tmax = q.get(timeout=120)
+    gathered, tmax, census = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert census["backend"] == "gloo" and census["world_size"] == world and census["allreduce_of_ones"] == world
+    assert [r["rank"] for r in census["ranks"]] == [0, 1] and len({r["pid"] for r in census["ranks"]}) == world
     assert sorted(gathered[0]) == [0, 2, 4] and sorted(gathered[1]) == [1, 3]
     merged = {**gathered[0], **gathered[1]}
     assert merged == {b: _solve_pair(b) for b in range(npairs)}
