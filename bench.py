@@ -116,9 +116,9 @@ def pair_lanes(args, capi, shard, synth, torch, dist, world, rank, dev, n, prm):
     plans = [capi.Plan(n, n, 1, prm) for _ in range(lanes)]
     for pl in plans:
         if lanes > 2:
-            pl.tune("lane_mode", 1)      # beside more than one other lane only the tiny levels keep the persistent solve (octane_vof_batch_run does the same)
+            pl.set_lane_mode(1)      # beside more than one other lane only the tiny levels keep the persistent solve (octane_vof_batch_run does the same)
         elif lanes == 2:
-            pl.tune("lane_mode", 2)      # two lanes: persistent solves concurrent, each on half the CUs (octane_vof_batch_run does the same)
+            pl.set_lane_mode(2)      # two lanes: persistent solves concurrent, each on half the CUs (octane_vof_batch_run does the same)
     outs = [(torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)) for _ in range(lanes)]
 
     def lane_work(ln, count):
@@ -179,9 +179,9 @@ def batch64_leg(args, capi, shard, synth, torch, dist, world, rank, local, dev):
     for pl in plans:
         if os.environ.get("OCTANE_BENCH_LANE_MODE", "1") != "0":
             if lanes > 2:
-                pl.tune("lane_mode", 1)      # as octane_vof_batch_run does for more than two lanes
+                pl.set_lane_mode(1)      # as octane_vof_batch_run does for more than two lanes
             elif lanes == 2:
-                pl.tune("lane_mode", 2)      # ... and for two: persistent solves concurrent, each capped at half the CUs (round 5: +9 %)
+                pl.set_lane_mode(2)      # ... and for two: persistent solves concurrent, each capped at half the CUs (round 5: +9 %)
     outs = [(torch.zeros(n, n, device=dev), torch.zeros(n, n, device=dev)) for _ in range(lanes)]
 
     # Each lane runs on its plan's private stream: those sit on different hardware queues, so one pair's latency-bound

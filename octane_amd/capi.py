@@ -21,16 +21,21 @@ NAV_GEOS, NAV_POLAR, NAV_MERC = 0, 1, 2
 NAV_FMAD = 0x100      # or into mode: the navigation kernel built with fused multiply-adds (include/octane_vof.h)
 NAV_FMAD_FLOAT = 0x200   # or into mode: the strict build with exactly the two float sites of the base position fused (the C++ shim's default)
 
-# the diagnostic library (make -C octane_amd/csrc DIAG=1: stamped copies of two kernels for tools/probe_stamps.py / probe_mid_stamps.py and
-# one GPU test; never the product) and what it exports on top of EXPORTS
+# The DIAGNOSTIC library (make -C octane_amd/csrc DIAG=1: the same sources + -DOCTANE_DIAG=1).  It exports, on top of EXPORTS, what
+# include/octane_vof_dev.h declares under OCTANE_DIAG: the tuning knob octane_vof_tune, probes, self-tests, the stamped kernel copies --
+# and only it contains the two-pass form of the PCG iteration.  tools/ and the form-against-form tests bind it with diag(); the product
+# path (flow(), bench.py, smoke()) never does.
 DIAG_LIB_PATH = os.path.join(_HERE, "liboctane_vof_diag.so")
-DIAG_EXPORTS = ("octane_vof_plan_probe_stamps", "octane_vof_mid_stamps")
+DIAG_EXPORTS = ("octane_vof_tune", "octane_vof_mid_geometry", "octane_selftest_rcp", "octane_selftest_assembly_math", "octane_selftest_assembly_math_bits",
+                "octane_vof_plan_probe", "octane_vof_plan_probe_stamps", "octane_vof_mid_stamps")
 
-# every symbol include/octane_vof.h declares (outside its OCTANE_DIAG section)
+# every symbol include/octane_vof.h, include/octane_extras.h and the product section of include/octane_vof_dev.h declare: exactly what
+# liboctane_vof.so exports (tests/test_capi_cpu.py compares the three lists: headers, this tuple, `nm -D`)
 EXPORTS = (
     "octane_vof_default_params", "octane_vof_run", "octane_vof_solve", "octane_vof_release_cache", "octane_vof_plan_create", "octane_vof_plan_destroy",
-    "octane_vof_plan_device_bytes", "octane_vof_plan_placement_trials", "octane_vof_plan_run", "octane_vof_plan_solve", "octane_vof_plan_wait", "octane_vof_plan_last_iterations",
-    "octane_vof_plan_persist_state", "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_get_launch_times", "octane_vof_plan_probe", "octane_vof_tune", "octane_vof_mid_geometry", "octane_selftest_rcp", "octane_selftest_assembly_math", "octane_selftest_assembly_math_bits",
+    "octane_vof_plan_device_bytes", "octane_vof_plan_run", "octane_vof_plan_solve", "octane_vof_plan_wait", "octane_vof_plan_last_iterations",
+    "octane_vof_plan_persist_state", "octane_vof_plan_set_lane_mode",
+    "octane_vof_plan_placement_trials", "octane_vof_plan_set_trace", "octane_vof_plan_set_profiling", "octane_vof_plan_get_profile", "octane_vof_plan_get_launch_times",
     "octane_vof_batch_run",
     "octane_vof_tiled_create", "octane_vof_tiled_destroy", "octane_vof_tiled_load", "octane_vof_tiled_solve",
     "octane_vof_tiled_wait", "octane_vof_tiled_fetch", "octane_vof_tiled_run", "octane_vof_tiled_banded_levels",
@@ -44,6 +49,43 @@ EXPORTS = (
     "octane_proj_navcal_run", "octane_uv2pix_run", "octane_srsal_run", "octane_sosm_run",
     "octane_last_error", "octane_device_count",
 )
+
+
+def diag():
+    """A second, independent binding of this module onto the DIAGNOSTIC library (its own module object, its own loaded library): what
+    exposes Plan.tune / Plan.probe / the self-tests.  Raises ImportError when `make -C octane_amd/csrc DIAG=1` has not been run."""
+    return variant(DIAG_LIB_PATH)
+
+
+def dev():
+    """The binding developer tools use: this module when its library already has the developer exports (OCTANE_LIB names a diagnostic or
+    variant build), the diagnostic library's binding otherwise."""
+    import sys
+    return sys.modules[__name__] if hasattr(lib(), "octane_vof_tune") else diag()
+
+
+_variants: dict = {}
+
+
+def variant(lib_path: str):
+    """This module bound to another build of the library (the diagnostic library, a kernel variant of tools/build_variants.sh)."""
+    import importlib.util
+    import sys
+    lib_path = os.path.abspath(lib_path)
+    if lib_path == os.path.abspath(LIB_PATH):
+        return sys.modules[__name__]
+    if lib_path in _variants:
+        return _variants[lib_path]
+    if not os.path.exists(lib_path):
+        raise ImportError(f"{lib_path} is missing (the diagnostic library is built by `make -C octane_amd/csrc DIAG=1`)")
+    name = f"{__name__}__{len(_variants)}_{os.path.basename(lib_path).replace('.', '_')}"
+    spec = importlib.util.spec_from_file_location(name, os.path.abspath(__file__))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    mod.LIB_PATH = lib_path
+    _variants[lib_path] = mod
+    return mod
 
 
 class VofParams(C.Structure):
@@ -178,10 +220,14 @@ def lib() -> C.CDLL:
     L.octane_vof_plan_set_profiling.argtypes = [vp, C.c_int]
     L.octane_vof_plan_get_profile.argtypes = [vp, C.POINTER(VofProfile)]
     L.octane_vof_plan_get_launch_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
-    L.octane_vof_tune.argtypes = [vp, C.c_char_p, C.c_int]
-    L.octane_vof_plan_probe.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    L.octane_selftest_assembly_math.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_ulonglong)]
-    L.octane_selftest_assembly_math_bits.argtypes = [C.c_int, C.c_double]
+    L.octane_vof_plan_set_lane_mode.argtypes = [vp, C.c_int]
+    if hasattr(L, "octane_vof_tune"):          # the diagnostic library (include/octane_vof_dev.h, OCTANE_DIAG section)
+        L.octane_vof_tune.argtypes = [vp, C.c_char_p, C.c_int]
+        L.octane_vof_plan_probe.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.octane_selftest_assembly_math.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_ulonglong)]
+        L.octane_selftest_assembly_math_bits.argtypes = [C.c_int, C.c_double]
+        L.octane_selftest_rcp.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+        L.octane_vof_mid_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.octane_vof_batch_run.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int,
                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(VofParams), C.c_int,
                                        C.POINTER(C.c_int)]
@@ -348,14 +394,26 @@ class Plan:
     def set_profiling(self, on: bool):
         lib().octane_vof_plan_set_profiling(self._h, 1 if on else 0)
 
+    def set_lane_mode(self, mode: int):
+        """How many other plans share the device: 0 none, 2 one (the two lanes of a batch), 1 two or more (include/octane_vof.h)."""
+        rc = lib().octane_vof_plan_set_lane_mode(self._h, mode)
+        if rc != OK:
+            raise OctaneError(rc, "octane_vof_plan_set_lane_mode")
+
     def tune(self, key: str, value: int):
-        rc = lib().octane_vof_tune(self._h, key.encode(), value)
+        """Developer knob: DIAGNOSTIC library only (capi.diag().Plan(...).tune(...)); the product library does not export it."""
+        L = lib()
+        if not hasattr(L, "octane_vof_tune"):
+            raise AttributeError("octane_vof_tune is exported by the diagnostic library only: bind it with octane_amd.capi.diag()")
+        rc = L.octane_vof_tune(self._h, key.encode(), value)
         if rc != OK:
             raise OctaneError(rc, "octane_vof_tune")
 
     def probe(self, level: int, iterations: int = 20):
-        """(pass A ms, pass B ms) of one pyramid level timed in isolation (diagnostic; clobbers the planes)."""
+        """(pass A ms, pass B ms) of one pyramid level timed in isolation (diagnostic library only; clobbers the planes)."""
         a, b = C.c_double(), C.c_double()
+        if not hasattr(lib(), "octane_vof_plan_probe"):
+            raise AttributeError("octane_vof_plan_probe is exported by the diagnostic library only: bind it with octane_amd.capi.diag()")
         rc = lib().octane_vof_plan_probe(self._h, level, iterations, C.byref(a), C.byref(b))
         if rc != OK:
             raise OctaneError(rc, "octane_vof_plan_probe")

@@ -6,6 +6,7 @@
 
 #include "../../include/octane_host.hpp"
 #include "../../include/octane_vof.h"
+#include "../../include/octane_extras.h"
 
 // zero_guess: the caller KNOWS uarr / varr hold the zero first guess (oct_optical_flow below, without -firstguess): it is then not uploaded
 static void variational_flow(Image geo1i, Image geo2i, float *uarr, float *varr, int nx, int ny, OFFlags args, bool zero_guess);

@@ -1364,6 +1364,7 @@ __device__ __forceinline__ void pass_b_issue(const LevelPtrs &L, int k, int xmod
     else { b.ou = make_float4(0, 0, 0, 0); b.ov = make_float4(0, 0, 0, 0); }
 }
 
+#ifdef OCTANE_DIAG      // the two-pass form (pass A + pass B per iteration) exists in the diagnostic library only: the product always runs one kernel per iteration
 __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int nparts_a)
 {
     __shared__ double s_red[8];
@@ -1424,9 +1425,11 @@ __global__ __launch_bounds__(256) void k_pcg_pass_b(LevelPtrs L, int k, int npar
     const double trr = block_sum_256(acc_rr, s_red);
     if (threadIdx.x == 0) { L.part_rz[blockIdx.x] = trz; L.part_rr[blockIdx.x] = trr; }
 }
+#endif
 
 // u += dx, v += dy after a solve (ref .cu:1185-1195).  x is only meaningful if at least one
 // iteration ran; the reference's x0 stays zero otherwise.
+#ifdef OCTANE_DIAG
 __global__ __launch_bounds__(256) void k_flow_update(LevelPtrs L, int nlaunched)
 {
     const PcgState st = L.st[nlaunched & 1];
@@ -1458,6 +1461,7 @@ __global__ __launch_bounds__(256) void k_flow_update(LevelPtrs L, int nlaunched)
         st4(L.u + o, u); st4(L.v + o, v);
     }
 }
+#endif
 
 static int stream_grid_size(int w, int h)
 {
@@ -1548,6 +1552,7 @@ int pcg_band_grid_size(int w, int rows)
     return (int)((items + rounds - 1) / rounds);
 }
 
+#ifdef OCTANE_DIAG
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol)
 {
     if (L.nbands > 1 || L.y0 != 0 || L.y1 != L.h) {   // a row band: only the tiled form knows about bands
@@ -1574,6 +1579,7 @@ void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, i
 {
     hipLaunchKernelGGL(k_pcg_pass_b, dim3(grid), dim3(256), 0, s, L, k, nparts_a);
 }
+#endif  // OCTANE_DIAG
 
 // Fused PCG: grid (shared by every launch of a solve, it is also the number of partials), launch, flow update.
 static int g_fused_q = 1;            // large levels of a plain plan recompute q instead of storing it (k_pcg_fused_q); 0 = always store q
@@ -1647,10 +1653,12 @@ void launch_flow_update_fused(hipStream_t s, const LevelPtrs &L, int nlaunched, 
     hipLaunchKernelGGL(k_flow_update_fused, dim3(stream_grid_size(L.w, L.y1 - L.y0)), dim3(256), 0, s, L, nlaunched, nparts);
 }
 
+#ifdef OCTANE_DIAG
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int nlaunched)
 {
     hipLaunchKernelGGL(k_flow_update, dim3(stream_grid_size(L.w, L.y1 - L.y0)), dim3(256), 0, s, L, nlaunched);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Whole PCG solve in one workgroup, for the coarsest pyramid levels (<= kSmallMaxPix pixels).

@@ -157,9 +157,11 @@ int  pcg_b_grid_size(int w, int h);
 void set_pass_a_variant(int v);       // tuning knob: tile rows per thread 1 | 2 (default) | 4; 3 = LDS-ring marching experiment
 int  assemble_grid_size(int w, int h);
 void launch_assemble(hipStream_t s, const LevelPtrs &L, const AssembleParams &P, int grid);
+#ifdef OCTANE_DIAG      // the two-pass form of a PCG iteration: diagnostic library only (the product runs one kernel per iteration)
 void launch_pcg_pass_a(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 void launch_pcg_pass_b(hipStream_t s, const LevelPtrs &L, int k, int nparts_a, int grid);
 void launch_flow_update(hipStream_t s, const LevelPtrs &L, int niter_launched);
+#endif
 void set_fused_q_min(long px);               // tuning: level size from which q is recomputed (default 3 * 2^20 pixels)
 void set_fused_q(int v);                     // tuning: the q-recomputing form of the fused kernel on large levels
 void set_fused_rows(int r);                  // tuning: tile rows of the fused kernel (0 = by level size)

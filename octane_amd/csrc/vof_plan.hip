@@ -17,7 +17,8 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/octane_vof.h"
+#include "../../include/octane_vof_dev.h"
+#include "../../include/octane_extras.h"
 #include "vof_kernels.hpp"
 #include "vof_plan.hpp"
 
@@ -193,11 +194,15 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
             ok = ok && hipEventRecord(fev[2 * (it - 1) + 1], s) == hipSuccess;
             continue;
         }
+#ifdef OCTANE_DIAG
         if (split) ok = ok && hipEventRecord(ev[3 * (it - 1)], s) == hipSuccess;
         launch_pcg_pass_a(s, L, it, g_b, g_a, 0.f);
         if (split) ok = ok && hipEventRecord(ev[3 * (it - 1) + 1], s) == hipSuccess;
         launch_pcg_pass_b(s, L, it, g_a, g_b);
         if (split) ok = ok && hipEventRecord(ev[3 * (it - 1) + 2], s) == hipSuccess;
+#else
+        (void)g_a; (void)g_b; ok = false;        // the two-pass form is not in the product library
+#endif
     }
     ok = ok && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess;
     if (ok) {
@@ -786,6 +791,7 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
                 launch_flow_update_fused(s, L, prm.cgiters, g_f);   // ref .cu:1185-1195 (+ the last x update)
                 ev_end(e, s);
             } else {
+#ifdef OCTANE_DIAG      // pass A + pass B per iteration: what the fused kernels are compared with (tune "fused" 0); diagnostic library only
                 for (int it = 0; it < prm.cgiters; it++) {  // ref .cu:1131-1182
                     e = ev_begin(pl, s, EV_PASS_A, pf);
                     launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
@@ -797,6 +803,11 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
                 e = ev_begin(pl, s, EV_UPD, pf);
                 launch_flow_update(s, L, prm.cgiters);      // ref .cu:1185-1195
                 ev_end(e, s);
+#else
+                (void)g_a; (void)g_b;
+                g_last_error = "the two-pass form of the PCG iteration is built into the diagnostic library only";
+                return OCTANE_E_INVALID;
+#endif
             }
             if (pl->trace) {
                 int rc;
@@ -1647,6 +1658,8 @@ extern "C" int octane_srsal_run(float *u, float *v, const float *cth, int nx, in
     return rc;
 }
 
+#ifdef OCTANE_DIAG
+// ---- from here to the end of octane_vof_tune: exported by the DIAGNOSTIC library only (include/octane_vof_dev.h, OCTANE_DIAG section) ----
 // Diagnostic: time the two PCG passes of one pyramid level in isolation (values in the planes are irrelevant).
 extern "C" int octane_vof_plan_probe(octane_vof_plan *pl, int level, int iterations, double *pass_a_ms, double *pass_b_ms)
 {
@@ -1665,7 +1678,6 @@ extern "C" int octane_vof_plan_probe(octane_vof_plan *pl, int level, int iterati
     return OCTANE_OK;
 }
 
-#ifdef OCTANE_DIAG
 // Diagnostic: where the waves of one launch of the q-recomputing PCG kernel spend their time at pyramid level `level` (shader
 // clock cycles summed over all waves, per seam of a tile: pcg_kernels.hip, g_q_stamps).  even != 0 times a launch that also
 // updates x.  The planes are clobbered, values are irrelevant (stop test held open).
@@ -1714,8 +1726,6 @@ extern "C" int octane_vof_mid_stamps(int device, unsigned long long *out16)
     if (hipDeviceSynchronize() != hipSuccess) return OCTANE_E_HIP;
     return pcg_mid_stamps(nullptr, out16) == 0 ? OCTANE_OK : OCTANE_E_HIP;
 }
-
-#endif  // OCTANE_DIAG
 
 // Self-test of the assembly's fast exact forms for `alpha` (vof_kernels.hip, assemble_math_selftest): out8 = {patterns, mismatches} of
 // x / alpha on every finite float x, of 1 / (s + 1) on every float s >= 0, of 1 / sqrt(x + 1e-6) on every float x >= 0 -- each against the
@@ -1781,13 +1791,22 @@ extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
 #endif
     else if (k == "persist_max_g") pl->persist_max_g = value;
     else if (k == "persist_chain") pl->persist_chain = value != 0;   // 0: persistent launches of this plan are not serialised with other plans' (experiment)
-    else if (k == "lane_mode") {      // 1: beside two or more other plans; 2: beside ONE other plan (the two lanes of a batch); 0: alone
-        if (value == 2) plan_lane_pair_mode(pl);
-        else if (value) plan_lane_mode(pl);
-        else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 1536; pl->persist_chain = 1; }
-    }
+    else if (k == "lane_mode") return octane_vof_plan_set_lane_mode(pl, value == 2 ? 2 : (value ? 1 : 0));
     else if (k == "fused_rows") set_fused_rows(value);
     else if (k == "asm_fast") pl->asm_fast = value ? assemble_fast_math_bits(pl->prm.alpha) : 0;    // 0: IEEE divisions throughout (same bits)
     else return OCTANE_E_INVALID;
+    return OCTANE_OK;
+}
+#endif  // OCTANE_DIAG
+
+// How many other plans work on this plan's device at the same time (include/octane_vof.h): 0 alone, 2 beside ONE other plan (the two lanes
+// of octane_vof_batch_run: persistent solves concurrent, each capped at half the compute units), 1 beside two or more (only the tiny levels
+// keep the persistent solve).
+extern "C" int octane_vof_plan_set_lane_mode(octane_vof_plan *pl, int mode)
+{
+    if (!pl || mode < 0 || mode > 2) { g_last_error = "octane_vof_plan_set_lane_mode: invalid argument"; return OCTANE_E_INVALID; }
+    if (mode == 2) plan_lane_pair_mode(pl);
+    else if (mode == 1) plan_lane_mode(pl);
+    else { pl->persist_max_g = kMidMaxG; pl->small_max_pixels = 1536; pl->persist_chain = 1; }
     return OCTANE_OK;
 }

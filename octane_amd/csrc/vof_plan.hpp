@@ -6,7 +6,8 @@
 #include <string>
 #include <vector>
 
-#include "../../include/octane_vof.h"
+#include "../../include/octane_vof_dev.h"
+#include "../../include/octane_extras.h"
 #include "vof_kernels.hpp"
 
 struct LevelInfo {

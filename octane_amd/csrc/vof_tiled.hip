@@ -52,7 +52,8 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/octane_vof.h"
+#include "../../include/octane_vof_dev.h"
+#include "../../include/octane_extras.h"
 #include "vof_kernels.hpp"
 #include "vof_plan.hpp"
 
@@ -746,6 +747,7 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
                 }
                 if (!N.failed()) launch_flow_update_fused(s, L, prm.cgiters, g_f);     // ref .cu:1185-1195
             } else {
+#ifdef OCTANE_DIAG      // the two-pass form: diagnostic library only
                 for (int it = 0; it < prm.cgiters; it++) {
                     if (!N.failed()) launch_pcg_pass_a(s, L, it, it == 0 ? g_asm : g_b, g_a, pl->tol);
                     N.sync(b);
@@ -753,6 +755,10 @@ static void solve_level_banded(BandNet &N, int b, int k, int cur, const LevelCtx
                     N.sync(b);
                 }
                 if (!N.failed()) launch_flow_update(s, L, prm.cgiters);
+#else
+                (void)g_a; (void)g_b;
+                N.fail(b, OCTANE_E_INVALID, "the two-pass form of the PCG iteration is built into the diagnostic library only");
+#endif
             }
             // the next assembly reads u, v two rows beyond the band (one for the halo row it fills, one for that
             // row's own 3 x 3 neighbourhood)

@@ -88,3 +88,14 @@ def capi():
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "octane_amd", "csrc"), "-s"])
     return _capi
+
+
+@pytest.fixture(scope="session")
+def capi_diag(capi):
+    """The same binding on the DIAGNOSTIC library (liboctane_vof_diag.so: the product's sources + -DOCTANE_DIAG=1): the only build that
+    exports octane_vof_tune, the probes and the self-tests and contains the two-pass form of the PCG iteration.  Tests that compare
+    kernel FORMS with each other run on it; every parity test against the oracle runs on the product library (`capi`)."""
+    try:
+        return capi.diag()
+    except ImportError as e:
+        pytest.skip(str(e))

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("alpha", [5.0, 12.0, 8.0, 3.0, 0.7])
-def test_fast_forms_are_used_only_where_they_are_exact_on_every_float(capi, alpha):
+def test_fast_forms_are_used_only_where_they_are_exact_on_every_float(capi_diag, alpha):
+    capi = capi_diag      # the self-tests' exports live in the diagnostic library (include/octane_vof_dev.h); plan creation runs the same check in the product
     L = capi.lib()
     out = (C.c_ulonglong * 8)()
     assert L.octane_selftest_assembly_math(0, alpha, out) == 0
@@ -32,10 +33,11 @@ def test_fast_forms_are_used_only_where_they_are_exact_on_every_float(capi, alph
         assert bits & 1, "the three-instruction division by the default alpha must be exact"
 
 
-def test_fast_forms_do_not_change_a_bit_of_the_flow(capi):
+def test_fast_forms_do_not_change_a_bit_of_the_flow(capi_diag):
     """Same pair, the assembly with and without the fast forms (tune("asm_fast", 0): IEEE divisions throughout), all three GNC steps,
     Zimmer and Brox data terms: the flows have to be the same bits (the coefficient planes are compared with the oracle bit for bit in
     test_gpu_parity.py, which runs with the fast forms on)."""
+    capi = capi_diag      # tune("asm_fast") exists in the diagnostic library only
     nx, ny = 333, 217
     a, b = synth.lattice_scene(nx, ny, seed=44)
     for prm in (dict(kiters=3, liters=2, cgiters=10), dict(kiters=2, liters=1, cgiters=8, dozim=0, alpha=12.0, lambda_=0.25)):

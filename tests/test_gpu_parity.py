@@ -168,7 +168,7 @@ def test_early_exit_of_the_pcg_loop(capi, oracle, golden_flow):
 def _recurrence_rows(store, tol):
     """From the 'pcg_sums' rows of the debug tap (one per launch: the launch's own direct sums rz rr pq qz qmq rq qq over the
     state it formed, then the PcgState it left: rz used, stopped, iterations): the NEXT launch's r.z / r.r by the kernels'
-    one-step recurrence (pcg_fused_q_dma.hip:253-262, pcg_kernels.hip:714-722, formed here exactly as there: alpha in float
+    one-step recurrence (pcg_fused_q_dma.hip:254-261, pcg_kernels.hip:715-722, formed here exactly as there: alpha in float
     from floats, the quadratic in double) next to the direct sums the next launch formed over the residual it wrote."""
     out = []
     for key in sorted(k for k in store if k[0] == "pcg_sums"):
@@ -187,7 +187,7 @@ def _recurrence_rows(store, tol):
 
 
 @pytest.mark.parametrize("case", ["early_exit_60x44", "q_dma_2304x1100"])
-def test_one_step_recurrence_of_rz_and_rr_agrees_with_the_direct_sums(capi, golden_flow, case):
+def test_one_step_recurrence_of_rz_and_rr_agrees_with_the_direct_sums(capi_diag, golden_flow, case):
     """The SECOND arithmetic freedom the HIP path takes (the first is the summation order): r.z and r.r of the residual a
     launch is about to form -- hence beta and the stop test `residc > tol` (ref .cu:1131) -- come from
     (r.z)_k = (r.z)_{k-1} - 2 alpha (q.z)_{k-1} + alpha^2 (q.M^-1 q)_{k-1}, likewise r.r, where the reference sums over the
@@ -195,6 +195,7 @@ def test_one_step_recurrence_of_rz_and_rr_agrees_with_the_direct_sums(capi, gold
     iteration (pytest -rP) and asserted: predicted and direct agree to 1e-6 relative wherever r.r > 10 tol -- on the tolerance-exit
     case of test_early_exit_of_the_pcg_loop (per-launch stored-q kernel: the persistent and single-workgroup solves switched
     off) and on a level the LDS-DMA kernel runs (>= 2 Mi pixels)."""
+    capi = capi_diag      # tuning knobs (and the two-pass form) exist in the diagnostic library only: both legs run on it
     tol = 1e-8                                           # ref .cu:1240
     if case == "early_exit_60x44":
         name = "lat_60x44_brox_hint"
@@ -352,10 +353,11 @@ def test_runs_are_bitwise_reproducible(capi):
     (300, 260, 3, dict(kiters=3, lambdac=0.5), True),      # the hint term: every level has its own decimated first guess
     (2200, 1100, 1, dict(kiters=3, liters=1, cgiters=5), False),
 ])
-def test_level_setup_on_the_side_stream_changes_no_bit(capi, nx, ny, nc, prm, guess):
+def test_level_setup_on_the_side_stream_changes_no_bit(capi_diag, nx, ny, nc, prm, guess):
     """Round 3: the pyramid images, the first-guess hint and the gradient fields of level k + 1 are prepared on the plan's side stream,
     in a second set of planes, while level k is solved.  Placement in time only: the flow must have the bits of the one-stream run,
     also when the same plan runs repeatedly (the sets alternate by level parity; a run reuses what the previous one left)."""
+    capi = capi_diag      # tuning knobs (and the two-pass form) exist in the diagnostic library only: both legs run on it
     a, b = synth.lattice_scene(nx, ny, seed=nx + 7 * ny, nchan=nc)
     rng = np.random.RandomState(3)
     u0 = (1.5 * rng.randn(ny, nx)).astype(np.float32) if guess else None
@@ -376,10 +378,11 @@ def test_level_setup_on_the_side_stream_changes_no_bit(capi, nx, ny, nc, prm, gu
 
 
 @pytest.mark.parametrize("cgiters", [1, 2, 7, 30])
-def test_deferred_x_update_is_bitwise_identical(capi, cgiters):
+def test_deferred_x_update_is_bitwise_identical(capi_diag, cgiters):
     """Pass B applies x += alpha p for two iterations at once (every second launch) in the reference's order of
     operations; the result must equal the every-iteration form bit for bit, for even and odd iteration counts
     (an odd count leaves one update pending for the flow-update kernel)."""
+    capi = capi_diag      # tuning knobs (and the two-pass form) exist in the diagnostic library only: both legs run on it
     nx, ny = 310, 240           # finest level above the single-workgroup solver's size
     a, b = synth.lattice_scene(nx, ny, seed=17)
     prm = capi.FlowParams(kiters=2, liters=1, cgiters=cgiters)
@@ -395,9 +398,10 @@ def test_deferred_x_update_is_bitwise_identical(capi, cgiters):
 
 
 @pytest.mark.parametrize("variant", [2, 3])
-def test_unit_weight_pass_a_is_bitwise_identical(capi, variant):
+def test_unit_weight_pass_a_is_bitwise_identical(capi_diag, variant):
     """In the first GNC step every neighbour weight is exactly -1 and pass A does not read the wx / wy planes;
     the result must equal the plane-reading form bit for bit (tiled and marching forms of pass A forced)."""
+    capi = capi_diag      # tuning knobs (and the two-pass form) exist in the diagnostic library only: both legs run on it
     nx, ny = 1150, 700
     a, b = synth.lattice_scene(nx, ny, seed=23)
     prm = capi.FlowParams(kiters=2, liters=1, cgiters=9)
@@ -450,7 +454,7 @@ def test_config4_batch_of_64_pairs_2000(capi):
     # partial sums, so a lane's flow equals the DEFAULT plan's to the last bits of the PCG scalars (asserted below the suite's 2e-5),
     # and equals bit for bit a single plan configured the way the lanes are -- lanes share a GPU, never a result.
     pl = capi.Plan(n, n, 1, prm)
-    pl.tune("lane_mode", 2)
+    pl.set_lane_mode(2)
     pd = capi.Plan(n, n, 1, prm)
     ud, vd = pd.run_host(*pairs[0])
     pd.close()
@@ -518,12 +522,13 @@ def test_full_size_properties_2000(capi):
     assert torch.equal(u, u1) and torch.equal(v, v1)
 
 
-def test_headline_config_5000_three_forms_of_the_pcg_agree(capi):
+def test_headline_config_5000_three_forms_of_the_pcg_agree(capi_diag):
     """BASELINE.json's headline run: 5000 x 5000, 8 levels, 2160 PCG iterations.  No oracle at this size
     in test time; instead the three independent forms of the PCG iteration this library has -- one kernel recomputing q
     (the default on the two finest levels), one kernel storing q, and the two-pass form with its own kernels -- are run
     on the same pair and have to agree, the recovered flow has to follow the analytic displacement field, and the
     iteration count is the fixed kiters * 3 * liters * cgiters."""
+    capi = capi_diag      # tuning knobs (and the two-pass form) exist in the diagnostic library only: both legs run on it
     import torch
     n = 5000
     a, b = synth.lattice_scene(n, n, seed=20240615, device="cuda")
@@ -584,10 +589,11 @@ def test_full_disk_frame_runs_on_one_gpu(capi):
 @pytest.mark.parametrize("nx,ny,prm", [(700, 520, dict(kiters=3, liters=2, cgiters=17)),      # 128 x 8 tiles, odd iteration count
                                         (1500, 1100, dict(kiters=2, liters=1, cgiters=12)),     # 128 x 16 tiles, more workgroups than are resident
                                         (300, 260, dict(kiters=4, liters=1, cgiters=1))])       # a single iteration: only the pending update
-def test_fused_iteration_equals_two_pass_form(capi, nx, ny, prm):
+def test_fused_iteration_equals_two_pass_form(capi_diag, nx, ny, prm):
     """One fused kernel per PCG iteration (r.z, r.r of the next residual by recurrence) against pass A + pass B (direct
     sums): same iterates up to the rounding of those scalars, same iteration counts, and bit-identical from run to run
     (the partial sums are double-buffered: workgroups of one launch do not all run at the same time)."""
+    capi = capi_diag      # tuning knobs (and the two-pass form) exist in the diagnostic library only: both legs run on it
     a, b = synth.lattice_scene(nx, ny, seed=nx + 3 * ny)
     outs, its = {}, {}
     for fused in (0, 1):
@@ -604,11 +610,12 @@ def test_fused_iteration_equals_two_pass_form(capi, nx, ny, prm):
 
 
 @pytest.mark.parametrize("nx,ny", [(2500, 1750), (2503, 1699)])
-def test_q_recomputing_form_equals_stored_q_form(capi, nx, ny):
+def test_q_recomputing_form_equals_stored_q_form(capi_diag, nx, ny):
     """k_pcg_fused_q (levels of at least 2 * 2^20 pixels; OCTANE_TUNE_FUSED_Q=0 / tune("fused_q", 0) turns it off) does not
     store q = A p but forms it again in the next launch from the stored p, on the tile and its one-pixel ring: same
     inputs, same operations as the form that stores q.  Frame with ragged right / bottom tiles and more tiles than
     workgroups; the second size has a width that is no multiple of 4 (a float4 group straddles the frame's edge)."""
+    capi = capi_diag      # tuning knobs (and the two-pass form) exist in the diagnostic library only: both legs run on it
     a, b = synth.lattice_scene(nx, ny, seed=91)
     prm = capi.FlowParams(kiters=2, liters=1, cgiters=11)
     outs = []
@@ -633,13 +640,14 @@ def test_q_recomputing_form_equals_stored_q_form(capi, nx, ny):
     (2503, 1699, dict(kiters=2, liters=1, cgiters=11)),     # a width that is no multiple of 4
     (2560, 2048, dict(kiters=1, liters=2, cgiters=6)),      # whole tiles only
 ])
-def test_lds_dma_form_of_the_q_recomputing_kernel_is_bit_identical(capi, nx, ny, prm):
+def test_lds_dma_form_of_the_q_recomputing_kernel_is_bit_identical(capi_diag, nx, ny, prm):
     """Whole levels run the q-recomputing kernel with the next tile's p and ring operands fetched by LDS-DMA during phase 2, the
     border-free form of the operator on tiles strictly inside the frame and the reciprocal of the diagonal by rcp_exact
     (pcg_fused_q_dma.hip; the default).  Same arithmetic, same tile walk, same partial sums as the register-staged kernel
     (tune("q_dma", 0)): the flow has to be the same bits, in all three GNC steps (unit and varying weights).  (Widths whose
     tile-column count divides the 512-workgroup grid -- 2000, 2048 -- walk the tiles in another order in the DMA kernel, hence
     group the fp64 partial sums differently: the next test.)"""
+    capi = capi_diag      # tuning knobs (and the two-pass form) exist in the diagnostic library only: both legs run on it
     a, b = synth.lattice_scene(nx, ny, seed=nx - ny)
     outs = {}
     for dma in (0, 1):
@@ -656,10 +664,11 @@ def test_lds_dma_form_of_the_q_recomputing_kernel_is_bit_identical(capi, nx, ny,
     assert np.isfinite(outs[1][0]).all() and ndiff == 0
 
 
-def test_lds_dma_kernel_with_rotated_tile_columns_agrees_with_the_register_staged_kernel(capi):
+def test_lds_dma_kernel_with_rotated_tile_columns_agrees_with_the_register_staged_kernel(capi_diag):
     """2048 pixels = 16 tile columns, which divides the grid of 512 workgroups: the DMA kernel rotates the columns of a tile row by the
     round number so that no workgroup owns the frame's border column in every round.  Another tile order = another grouping of
     the fp64 partial sums: not the same bits as the register-staged kernel, the same flow within 1e-5 and the same iteration count."""
+    capi = capi_diag      # tuning knobs (and the two-pass form) exist in the diagnostic library only: both legs run on it
     nx, ny, prm = 2048, 1800, dict(kiters=1, liters=2, cgiters=8)
     a, b = synth.lattice_scene(nx, ny, seed=77)
     outs, its = {}, {}

@@ -19,6 +19,11 @@ pytestmark = pytest.mark.gpu
 
 def _run(capi, a, b, prm, u0=None, v0=None, **knobs):
     nc, ny, nx = (1,) + a.shape if a.ndim == 2 else a.shape
+    if knobs:            # tuning knobs exist in the diagnostic library only (the product's sources + -DOCTANE_DIAG=1); plain runs stay on the product
+        try:
+            capi = capi.diag()
+        except ImportError as e:
+            pytest.skip(str(e))
     pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm))
     try:
         for k, v in knobs.items():
@@ -107,8 +112,10 @@ def test_three_instruction_reciprocal_equals_the_division_everywhere(capi):
     what `1.0f / x` gives -- for every x it can meet: checked on ALL positive normal floats whose reciprocal is normal."""
     import ctypes as C
     out = (C.c_ulonglong * 3)()
-    L = capi.lib()
-    L.octane_selftest_rcp.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+    try:
+        L = capi.diag().lib()       # the self-test's export lives in the diagnostic library (include/octane_vof_dev.h); same device code
+    except ImportError as e:
+        pytest.skip(str(e))
     assert L.octane_selftest_rcp(0, out) == 0
     print(f"PERSIST reciprocal self-test: {out[0]} patterns, {out[1]} mismatches" + (f" (e.g. 0x{out[2]:08x})" if out[1] else ""))
     assert out[0] == 0x7E000000 - 0x01000000
@@ -156,10 +163,11 @@ def test_an_abandoned_solve_fails_the_row_band_solve_too(capi):
 
 
 def test_the_product_library_has_no_fault_hook(capi):
-    """the tune key of the drill is rejected by the product library."""
+    """the product library has no tuning knob at all (octane_vof_tune is not exported), let alone the drill's."""
+    assert not hasattr(capi.lib(), "octane_vof_tune")
     pl = capi.Plan(64, 64, 1, capi.FlowParams(kiters=1))
     try:
-        with pytest.raises(capi.OctaneError):
+        with pytest.raises(AttributeError):
             pl.tune("persist_fault", 1)
     finally:
         pl.close()

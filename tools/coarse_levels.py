@@ -44,6 +44,7 @@ def main():
 
     if gpu:
         from octane_amd import capi
+        capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
         pl = capi.Plan(n, n, 1, capi.FlowParams(kiters=kit, liters=lit, cgiters=cg))
         pl.tune("trace_levels", K)
         store = {}

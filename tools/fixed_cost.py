@@ -4,6 +4,7 @@ usage: [OCTANE_LIB=octane_amd/variants/x.so] python tools/fixed_cost.py [WxH ...
 import sys, os
 sys.path.insert(0, os.getcwd())
 from octane_amd import capi
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 sizes = [tuple(int(t) for t in a.split("x")) for a in sys.argv[1:]] or [(128, 16), (1024, 64), (2048, 256), (2048, 512), (2048, 1024), (2048, 2048), (4096, 2048), (4096, 4096)]
 tag = os.path.basename(os.environ.get("OCTANE_LIB", "product"))
 for nx, ny in sizes:

@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 from octane_amd import capi, synth  # noqa: E402
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 kit = int(sys.argv[2]) if len(sys.argv) > 2 else 6

@@ -4,6 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from octane_amd import capi, synth
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 
 specs = [(int(a), int(b)) for a, b in zip(sys.argv[1::2], sys.argv[2::2])] or [(1250, 4), (2000, 6)]
 for n, kit in specs:

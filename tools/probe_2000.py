@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from octane_amd import capi
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 kit = 6
 pl = capi.Plan(n, n, 1, capi.FlowParams(kiters=kit))

@@ -4,6 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from octane_amd import capi, synth
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 n, kit = (int(sys.argv[1]) if len(sys.argv) > 1 else 2000), 6
 a, b = synth.lattice_scene(n, n, seed=5, device="cuda")
 u = torch.zeros(n, n, device="cuda"); v = torch.zeros(n, n, device="cuda")

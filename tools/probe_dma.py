@@ -4,6 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from octane_amd import capi, synth
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 
 def run(nx, ny, prm, dma):
     a, b = synth.lattice_scene(nx, ny, seed=nx + ny)

@@ -4,6 +4,7 @@ import sys
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from octane_amd import capi  # noqa: E402
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 
 sizes = [int(a) for a in sys.argv[1:]] or [625, 1250, 2500, 5000]
 for n in sizes:

@@ -7,6 +7,7 @@ import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from octane_amd import capi, synth
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 sizes = [int(a) for a in sys.argv[1:]] or [157, 313, 625, 1000, 1250]
 L = capi.lib()
 L.octane_vof_mid_stamps.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]

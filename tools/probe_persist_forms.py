@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from octane_amd import capi, synth
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 nx, ny, cg = (int(x) for x in (sys.argv[1:4] if len(sys.argv) >= 4 else (640, 500, 9)))
 a, b = synth.lattice_scene(nx, ny, seed=nx + ny)
 prm = dict(kiters=1, liters=1, cgiters=cg)

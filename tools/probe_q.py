@@ -5,6 +5,7 @@ _os.environ.setdefault('OCTANE_LIB', _os.path.join(_os.path.dirname(_os.path.dir
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from octane_amd import capi
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 combos = [tuple(int(y) for y in x.split(":")) for x in (sys.argv[2] if len(sys.argv) > 2 else "4:15,8:15").split(",")]
 os.environ.setdefault('OCTANE_TUNE_PLACEMENT_TRIALS', '8')

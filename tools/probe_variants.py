@@ -2,6 +2,7 @@ import os; os.environ.setdefault("OCTANE_LIB", os.path.join(os.path.dirname(os.p
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from octane_amd import capi
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 n = 5000
 os.environ['OCTANE_TUNE_PLACEMENT_TRIALS'] = '1'
 for plan_i in range(3):

@@ -3,6 +3,7 @@ is an exact multiple of the 512-workgroup grid, just above one, and in between. 
 import sys, os
 sys.path.insert(0, os.getcwd())
 from octane_amd import capi
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 for nx, ny in ((5120, 4096), (5120, 4112), (5120, 4200), (5120, 4300), (5120, 4500), (5000, 5000), (2560, 2560), (2500, 2500), (2560, 2048)):
     pl = capi.Plan(nx, ny, 1, capi.FlowParams(kiters=1, liters=1, cgiters=4))
     us = min(pl.probe(0, 41)[0] * 1e3 for _ in range(3))

@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from octane_amd import capi, synth
+capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
 from oracle import oct_oracle as oo          # a tool, not the product: the oracle is the checker here
 
 

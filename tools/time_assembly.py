@@ -17,6 +17,7 @@ def child(n, nc=1):
     sys.path.insert(0, ROOT)
     import torch
     from octane_amd import capi, synth
+    capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
     a, b = synth.lattice_scene(n, n, seed=20240615, nchan=nc, device="cuda")
     u = torch.zeros(n, n, device="cuda"); v = torch.zeros(n, n, device="cuda")
     pl = capi.Plan(n, n, nc, capi.FlowParams(kiters=1, liters=3, cgiters=2))

@@ -25,6 +25,7 @@ def child(size, solve):
     import numpy as np
     import torch
     from octane_amd import capi, synth
+    capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
     n = size
     pl = capi.Plan(n, n, 1, capi.FlowParams(kiters=1, liters=3, cgiters=30))
     out = {"trials_ms": [round(t, 4) for t in pl.placement_trials() if t > 0]}
