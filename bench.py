@@ -766,6 +766,10 @@ def main():
         survey_bpp = 116 if fused else (60 if dom == "k_pcg_pass_a" else 56)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                # `traffic` sits on the L2's fabric side and counts Infinity-Cache hits; the DRAM-side split the round-5 review asked for does
+                # not exist on gfx950: TCC_EA0_RDREQ_DRAM / _WRREQ_DRAM equal TCC_EA0_RDREQ / _WRREQ to the last request ("DRAM" = the request's
+                # destination class, not a miss of the memory-side cache), profiles/r6_dram_counters.txt
+                "traffic_dram": None,
                 "avg_launch_ms": round(dms, 4), "bytes_per_launch": int(round(bpp * n * n)), "by_kind_of_launch": by_kind,
                 "pcg_iteration_ms": round(iter_ms, 4),
                 # one whole PCG iteration on SURVEY 8(d)'s accounting (116 B/px: pass A with seven coefficient planes + pass B).
