@@ -15,8 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from octane_amd import capi, synth  # noqa: E402
-capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
+from octane_amd import capi, synth  # noqa: E402   (the sweep runs on the PRODUCT library; only the form comparison binds the diagnostic one)
 from oracle import oct_oracle as oo  # noqa: E402  (the checker)
 
 
@@ -67,7 +66,8 @@ def main():
             a, b = synth.lattice_scene(nx, ny, seed=scene_seed, nchan=nc)
         if forms:
             res = {}
-            pl = capi.Plan(nx, ny, nc, capi.FlowParams(**prm))
+            dcapi = capi.dev()      # the tuning knob and the two-pass form exist in the diagnostic library only
+            pl = dcapi.Plan(nx, ny, nc, dcapi.FlowParams(**prm))
             for name, knobs in (("q", dict(fused=1, fused_q=1)), ("stored", dict(fused=1, fused_q=0)), ("two_pass", dict(fused=0, fused_q=1))):
                 for key, val in knobs.items():
                     pl.tune(key, val)
