@@ -65,14 +65,32 @@ def rank_census(backend: str, device=None, local: int | None = None):
     if not dist.is_available() or not dist.is_initialized():
         return {"backend": None, "world_size": 1, "allreduce_of_ones": 1, "ranks": [me]}
     me["rank"] = dist.get_rank()
-    one = torch.ones(1, dtype=torch.int64, device=device if backend == "nccl" else None)
-    dist.all_reduce(one, op=dist.ReduceOp.SUM)
-    ranks = gather_objects(me, dst=0)
-    if dist.get_rank() != 0:
-        return None
-    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": int(one.item()),
-            "ranks": sorted(ranks, key=lambda r: r["rank"]),
-            "distinct_devices": len({r.get("uuid") or r.get("pci_bus_id") or (r["host"], r.get("device")) for r in ranks})}
+    # plain tensor collectives only (the same kind as the timing's all-reduce): a sum of ones, and an all-gather of every rank's report as
+    # 1 KiB of bytes -- no pickled-object collective in an N-rank run whose one purpose is its headline line
+    import json
+    dev = device if backend == "nccl" else None
+    try:
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        blob = json.dumps(me).encode()[:1024]
+        mine = torch.zeros(1024, dtype=torch.uint8, device=dev)
+        mine[:len(blob)] = torch.tensor(list(blob), dtype=torch.uint8, device=dev)
+        allb = [torch.zeros(1024, dtype=torch.uint8, device=dev) for _ in range(dist.get_world_size())]
+        dist.all_gather(allb, mine)
+        if dist.get_rank() != 0:
+            return None
+        ranks = []
+        for t in allb:
+            raw = bytes(t.cpu().tolist()).rstrip(b"\0")
+            try:
+                ranks.append(json.loads(raw.decode()))
+            except ValueError:
+                ranks.append({"unparsed": raw[:80].decode(errors="replace")})
+        return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": int(one.item()),
+                "ranks": sorted(ranks, key=lambda r: r.get("rank", -1)),
+                "distinct_devices": len({r.get("uuid") or r.get("pci_bus_id") or (r.get("host"), r.get("device")) for r in ranks})}
+    except Exception as e:                              # noqa: BLE001 -- the census must never cost the line it decorates
+        return {"error": repr(e), "world_size": dist.get_world_size()} if dist.get_rank() == 0 else None
 
 
 def whole_job_mpix(world_pixels_per_step: int, steps: int, seconds_max: float) -> float:
