@@ -47,6 +47,9 @@
 #endif
 // Measured and not kept (round 6): the streaming hint on the tail tiles' p_{k-1} DMA (their lines are dead afterwards) gives the reverse
 // walk's gain back (291.6 us); on the own r loads as well it is the run-time-policy trap of EXPERIMENTS 8 (+8 %).
+#ifndef Q_RROT
+#define Q_RROT 1         // rotate the tile columns by the tile row where the host asks for it (L.row_rot); 0: never (A/B builds)
+#endif
 #define Q_STR2(x) #x
 #define Q_STR(x) Q_STR2(x)
 #ifndef Q_ROT
@@ -301,6 +304,10 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     // tile row are then rotated by the round number (a permutation within the row, so every tile is still done exactly once).
     const bool rotate = Q_ROT && tr.step == (int)gridDim.x && tr.step % tiles_x == 0 && tiles_x > 1;
     const bool rev = Q_REV != 0 && ((k & 1) != 0) == (Q_REV == 1);
+    // Otherwise the columns of tile row r may be rotated by r -- where the host found that this spreads the border-column tiles (register-
+    // staged, bordered operator) more evenly over the workgroups (pcg_row_rotation, pcg_kernels.hip): at 5000^2 64 of the 512 workgroups
+    // own ALL left-border tiles and finish last in every launch; rotated, no workgroup has more than two (-1.1 % per launch).
+    const bool rowrot = Q_RROT && !rotate && L.row_rot != 0;
     int parity = 0, round = 0;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // p_{k-1} of an interior tile (every staged float4 group inside the level) comes by LDS-DMA, issued one phase ahead: for the
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
     bool dma_cur = false;
     if (!first && tr.first < tr.end) {
         const int ft = rev ? ntiles - 1 - tr.first : tr.first;
-        const int ftx0 = (ft % tiles_x) * TX, fty0 = y0 + (ft / tiles_x) * TY;      // round 0: no rotation
+        const int ftx0 = ((ft % tiles_x + (rowrot ? ft / tiles_x : 0)) % tiles_x) * TX, fty0 = y0 + (ft / tiles_x) * TY;      // round 0: no rotation
         dma_cur = tile_is_interior(ftx0, fty0, w, h, y1);
         if (dma_cur) {
             dma_p_tile<BANDED>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ftx0, fty0, pitch, lane, wv);
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
         float *const s_nu = s_nu2 + parity * NSZ, *const s_nv = s_nv2 + parity * NSZ;
         const int tt = rev ? ntiles - 1 - t : t;
         const bool tailc = Q_TAILC > 0 && tr.end - tr.base >= Q_TAILMIN * tr.step && t + Q_TAILC * tr.step >= tr.end;
-        const int tx0 = ((tt % tiles_x + (rotate ? round : 0)) % tiles_x) * TX, ty0 = y0 + (tt / tiles_x) * TY;
+        const int tx0 = ((tt % tiles_x + (rotate ? round : (rowrot ? tt / tiles_x : 0))) % tiles_x) * TX, ty0 = y0 + (tt / tiles_x) * TY;
         // ---- loads of the thread's two tile groups first (r_{k-1} and the operator; addresses of groups beyond a ragged
         // edge are clamped into the frame, their values never used), so that they are in flight while phase 0 waits for p
         QCoef c3[2];
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(256, Q_LB) void k_pcg_fused_q_dma(LevelPtrs L, int 
             bool dma_next = false;
             if (!first && tn < tr.end) {
                 const int tnn = rev ? ntiles - 1 - tn : tn;
-                const int ntx0 = ((tnn % tiles_x + (rotate ? round + 1 : 0)) % tiles_x) * TX, nty0 = y0 + (tnn / tiles_x) * TY;
+                const int ntx0 = ((tnn % tiles_x + (rotate ? round + 1 : (rowrot ? tnn / tiles_x : 0))) % tiles_x) * TX, nty0 = y0 + (tnn / tiles_x) * TY;
                 dma_next = tile_is_interior(ntx0, nty0, w, h, y1);
                 if (dma_next) {
                     dma_p_tile<BANDED>(pin_u, pin_v, up_u, up_v, dn_u, dn_v, y0, y1, s_ou, s_ov, ntx0, nty0, pitch, lane, wv);

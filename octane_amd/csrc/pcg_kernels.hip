@@ -26,6 +26,8 @@
 // (EXPERIMENTS.md 8).  The tiled and marching forms skip the wx / wy planes in the first GNC step, where every weight is -1,
 // and the tiled form can work on a row band of the level (vof_tiled.hip).
 // Also here: k_pcg_solve_small (a whole solve in one workgroup for the coarsest levels) and k_flow_update.
+#include <vector>
+
 #include "vof_kernels.hpp"
 #include "device_util.hpp"
 
@@ -1615,6 +1617,34 @@ int pcg_fused_grid_size(int w, int rows, int unit_w, int q_form)
     int g = qform ? (int)cap : (int)((items + rounds - 1) / rounds);
     if (grid_multiple() > 1 && g >= 8 * grid_multiple()) g = g / grid_multiple() * grid_multiple();   // XCD bands want a multiple of 8
     return g;
+}
+
+// Which workgroups walk the border-column tiles.  The tiles of the frame's first and last tile column are the expensive ones of the LDS-DMA
+// kernel (no DMA staging, the bordered operator: ~1 us more than an interior tile), and the walk "tile t -> workgroup" is periodic in the
+// tile-column count: at 5000 pixels (40 columns, 512 workgroups) 64 workgroups own ALL left-border tiles, five of their 24-25, and finish
+// last in every launch.  Rotating the columns of tile row r by r (a permutation within the row, so every tile is still done exactly once)
+// spreads them: at most two per workgroup at 5000^2 (-1.1 % per launch, profiles/r6_row_rotation.txt) -- but at 10848 pixels (85 columns)
+// the plain walk is the more even one, so the host counts both and the kernel rotates only where that lowers the maximum.
+int pcg_row_rotation(int w, int rows, int grid, int walk_mode)
+{
+    const int tiles_x = (w + kTileX - 1) / kTileX, tiles_y = (rows + 2 * kTileY - 1) / (2 * kTileY);
+    const long nt = (long)tiles_x * tiles_y;
+    if (tiles_x < 3 || grid < 1 || grid > kMaxParts || (grid % tiles_x == 0 && tiles_x > 1)) return 0;      // (columns dividing the grid: the kernel rotates by round)
+    if (!(walk_mode == 0 || ((walk_mode == 3 || walk_mode == 4) && (grid & 63) == 0))) return 0;           // walks this count does not model
+    std::vector<int> plain((size_t)grid, 0), rot((size_t)grid, 0);
+    const int run = walk_mode == 3 ? 4 : 8;
+    for (int b = 0; b < grid; b++) {
+        long first = b;
+        if (walk_mode == 3 || walk_mode == 4) { const int x = b & 7, j = b >> 3; first = ((long)(j / run) * 8 + x) * run + (j % run); }
+        for (long t = first; t < nt; t += grid) {
+            const int row = (int)(t / tiles_x), col = (int)(t % tiles_x), colr = (col + row) % tiles_x;
+            plain[b] += (col == 0 || col == tiles_x - 1);
+            rot[b] += (colr == 0 || colr == tiles_x - 1);
+        }
+    }
+    int mp = 0, mr = 0;
+    for (int b = 0; b < grid; b++) { mp = plain[b] > mp ? plain[b] : mp; mr = rot[b] > mr ? rot[b] : mr; }
+    return mr < mp ? 1 : 0;
 }
 
 #ifdef OCTANE_DIAG

@@ -109,6 +109,8 @@ struct LevelPtrs {       // everything one pyramid level's solve touches
     int unit_w;                     // this linearisation has al1 == 1: wx == wy == -1 everywhere, pass A need not read them
     int lean;                       // the fused kernels are the only readers: the assembly skips the planes they never read
                                     // (mu, mv; wx, wy while unit_w) and the flow update does not write x back
+    int row_rot;                    // LDS-DMA PCG kernel: the tile columns of tile row r are rotated by r (a permutation within the row) -- set by
+                                    // the host where it spreads the border-column tiles more evenly over the workgroups (pcg_row_rotation)
     int no_dma;                     // row bands whose first-contact self-check (vof_tiled.hip) found LDS-DMA from the neighbouring band's
                                     // memory wanting: q-form launches take the register-staged kernel (host-side dispatch only)
 };
@@ -142,6 +144,9 @@ void launch_upsample(hipStream_t s, const float *coarse, int cw, int ch, int cpi
 void set_max_blocks(int n);
 void set_q_dma(int v);                   // the q-form kernel with LDS-DMA staging of p (pcg_fused_q_dma.hip)
 void launch_pcg_fused_q_dma(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
+// 1 where rotating the tile columns of tile row r by r lowers the largest number of border-column tiles (frame's first / last tile column:
+// register-staged, bordered operator, ~1 us more than an interior tile) any ONE workgroup of a `grid`-workgroup launch walks; host arithmetic
+int  pcg_row_rotation(int w, int rows, int grid, int walk_mode);
 void set_q_diag(int v);                  // diagnostics: the q-form kernel's copy in pcg_fused_q_diag.hip instead of the production one
 void launch_pcg_fused_q_diag(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 int  pcg_fused_q_stamps(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol, unsigned long long *out16);   // diagnostic

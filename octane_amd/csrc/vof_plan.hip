@@ -129,6 +129,7 @@ static void fill_level_ptrs(octane_vof_plan *pl, const LevelInfo &li, int cur, c
     L.nt_hints = pl->nt_hints;
     L.unit_w = 0;
     L.lean = 0;
+    L.row_rot = 0;
     L.no_dma = 0;
 }
 
@@ -158,6 +159,7 @@ static double probe_level(octane_vof_plan *pl, int level, int reps, double *a_ms
     const int g_a = pcg_grid_size(li.w, li.h), g_b = pcg_b_grid_size(li.w, li.h);
     L.q_form = pcg_fused_q_form(li.w, li.h, li.h);
     const int g_f = pcg_fused_grid_size(li.w, li.h, 0, L.q_form);
+    L.row_rot = L.q_form ? pcg_row_rotation(li.w, li.h, g_f, pl->xcd_bands) : 0;
     const bool fused = pl->use_fused && !(a_ms && b_ms);      // the split timing is defined for the two-pass form only
     // sums that keep the stop test open and every scalar finite whatever the planes hold: with all seven sums equal
     // to 1 the fused kernel's recurrences give alpha = 1, r.z = 0, r.r = 0 + ... -> use values that stay positive
@@ -706,6 +708,7 @@ int octane::plan_level_solve(octane_vof_plan *pl, hipStream_t s, int k, int cur,
     const int g_asm = assemble_grid_size(li.w, li.h);
     L.q_form = pcg_fused_q_form(li.w, li.h, li.h);
     const int g_f_plain = pcg_fused_grid_size(li.w, li.h, 0, L.q_form), g_f_unit = pcg_fused_grid_size(li.w, li.h, 1, L.q_form);
+    L.row_rot = L.q_form ? pcg_row_rotation(li.w, li.h, g_f_plain, pl->xcd_bands) : 0;     // (the q-form's grid is the same with and without unit weights)
     const int g_a_plain = pcg_grid_size(li.w, li.h);
     const int g_a_unit = pcg_grid_size_unit_w(li.w, li.h);
     const int g_b = pcg_b_grid_size(li.w, li.h);
