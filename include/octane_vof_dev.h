@@ -57,6 +57,10 @@ int octane_vof_tune(octane_vof_plan *plan, const char *key, int value);
  * compute units: out5 = {columns, rows of sub-domains, rows per sub-domain, slots of 8 rows per thread, workgroups}.  Returns 1, or 0
  * when the level does not fit the device.  Host arithmetic only. */
 int octane_vof_mid_geometry(int w, int h, int ncu, int *out5);
+/* Does the LDS-DMA PCG kernel rotate the tile columns by the tile row on a level of w x rows pixels walked by `grid` workgroups (walk_mode:
+ * the plan's tile walk, 4 by default)?  It does where that lowers the largest number of border-column tiles any one workgroup walks;
+ * out3 = {tile columns, that maximum without / with the rotation} (-1: not counted).  Host arithmetic only. */
+int octane_vof_row_rotation(int w, int rows, int grid, int walk_mode, int *out3);
 /* Self-test of the three-instruction reciprocal (hardware estimate + one fused Newton step) against the IEEE division on every
  * positive normal float whose reciprocal is normal: out3 = {patterns compared, mismatches, one mismatching bit pattern}. */
 int octane_selftest_rcp(int device, unsigned long long *out3);

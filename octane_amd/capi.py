@@ -26,7 +26,7 @@ NAV_FMAD_FLOAT = 0x200   # or into mode: the strict build with exactly the two f
 # and only it contains the two-pass form of the PCG iteration.  tools/ and the form-against-form tests bind it with diag(); the product
 # path (flow(), bench.py, smoke()) never does.
 DIAG_LIB_PATH = os.path.join(_HERE, "liboctane_vof_diag.so")
-DIAG_EXPORTS = ("octane_vof_tune", "octane_vof_mid_geometry", "octane_selftest_rcp", "octane_selftest_assembly_math", "octane_selftest_assembly_math_bits",
+DIAG_EXPORTS = ("octane_vof_tune", "octane_vof_mid_geometry", "octane_vof_row_rotation", "octane_selftest_rcp", "octane_selftest_assembly_math", "octane_selftest_assembly_math_bits",
                 "octane_vof_plan_probe", "octane_vof_plan_probe_stamps", "octane_vof_mid_stamps")
 
 # every symbol include/octane_vof.h, include/octane_extras.h and the product section of include/octane_vof_dev.h declare: exactly what
@@ -228,6 +228,7 @@ def lib() -> C.CDLL:
         L.octane_selftest_assembly_math_bits.argtypes = [C.c_int, C.c_double]
         L.octane_selftest_rcp.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
         L.octane_vof_mid_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.octane_vof_row_rotation.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.octane_vof_batch_run.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int,
                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(VofParams), C.c_int,
                                        C.POINTER(C.c_int)]

@@ -1625,10 +1625,12 @@ int pcg_fused_grid_size(int w, int rows, int unit_w, int q_form)
 // last in every launch.  Rotating the columns of tile row r by r (a permutation within the row, so every tile is still done exactly once)
 // spreads them: at most two per workgroup at 5000^2 (-1.1 % per launch, profiles/r6_row_rotation.txt) -- but at 10848 pixels (85 columns)
 // the plain walk is the more even one, so the host counts both and the kernel rotates only where that lowers the maximum.
-int pcg_row_rotation(int w, int rows, int grid, int walk_mode)
+int pcg_row_rotation(int w, int rows, int grid, int walk_mode) { return pcg_row_rotation_count(w, rows, grid, walk_mode, nullptr); }
+int pcg_row_rotation_count(int w, int rows, int grid, int walk_mode, int *out3)
 {
     const int tiles_x = (w + kTileX - 1) / kTileX, tiles_y = (rows + 2 * kTileY - 1) / (2 * kTileY);
     const long nt = (long)tiles_x * tiles_y;
+    if (out3) { out3[0] = tiles_x; out3[1] = out3[2] = -1; }
     if (tiles_x < 3 || grid < 1 || grid > kMaxParts || (grid % tiles_x == 0 && tiles_x > 1)) return 0;      // (columns dividing the grid: the kernel rotates by round)
     if (!(walk_mode == 0 || ((walk_mode == 3 || walk_mode == 4) && (grid & 63) == 0))) return 0;           // walks this count does not model
     std::vector<int> plain((size_t)grid, 0), rot((size_t)grid, 0);
@@ -1644,6 +1646,7 @@ int pcg_row_rotation(int w, int rows, int grid, int walk_mode)
     }
     int mp = 0, mr = 0;
     for (int b = 0; b < grid; b++) { mp = plain[b] > mp ? plain[b] : mp; mr = rot[b] > mr ? rot[b] : mr; }
+    if (out3) { out3[1] = mp; out3[2] = mr; }
     return mr < mp ? 1 : 0;
 }
 

@@ -147,6 +147,7 @@ void launch_pcg_fused_q_dma(hipStream_t s, const LevelPtrs &L, int k, int nparts
 // 1 where rotating the tile columns of tile row r by r lowers the largest number of border-column tiles (frame's first / last tile column:
 // register-staged, bordered operator, ~1 us more than an interior tile) any ONE workgroup of a `grid`-workgroup launch walks; host arithmetic
 int  pcg_row_rotation(int w, int rows, int grid, int walk_mode);
+int  pcg_row_rotation_count(int w, int rows, int grid, int walk_mode, int *out3);   // the same + {tile columns, max border tiles per workgroup plain, rotated}
 void set_q_diag(int v);                  // diagnostics: the q-form kernel's copy in pcg_fused_q_diag.hip instead of the production one
 void launch_pcg_fused_q_diag(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol);
 int  pcg_fused_q_stamps(hipStream_t s, const LevelPtrs &L, int k, int nparts_prev, int grid, float tol, unsigned long long *out16);   // diagnostic

@@ -1763,6 +1763,15 @@ extern "C" int octane_vof_mid_geometry(int w, int h, int ncu, int *out5)
     return 1;
 }
 
+// Host arithmetic only: does the LDS-DMA PCG kernel rotate the tile columns by the tile row on a level of w x rows pixels walked by `grid`
+// workgroups (pcg_row_rotation, pcg_kernels.hip)?  out3 = {tile columns, largest number of border-column tiles one workgroup walks without
+// / with the rotation}.
+extern "C" int octane_vof_row_rotation(int w, int rows, int grid, int walk_mode, int *out3)
+{
+    if (w < 1 || rows < 1 || grid < 1) { g_last_error = "octane_vof_row_rotation: invalid argument"; return OCTANE_E_INVALID; }
+    return pcg_row_rotation_count(w, rows, grid, walk_mode, out3);
+}
+
 extern "C" int octane_vof_tune(octane_vof_plan *pl, const char *key, int value)
 {
     if (!key) return OCTANE_E_INVALID;

@@ -79,7 +79,7 @@ def test_product_library_carries_no_diagnostics(capi):
     import subprocess
     L = capi.lib()
     diag = _declared_symbols(diag=True)
-    assert sorted(capi.DIAG_EXPORTS) == diag and len(diag) == 8
+    assert sorted(capi.DIAG_EXPORTS) == diag and len(diag) == 9
     for name in diag:
         assert not hasattr(L, name), f"{name} is a diagnostic export and must not be in the product library"
     syms = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
@@ -125,6 +125,42 @@ def test_sub_domain_grid_of_the_persistent_solve(capi):
     assert geo(2000, 2000)[0] == 0 and geo(20000, 50)[0] == 0   # do not fit 256 CUs at 16 slots / 256 columns of sub-domains
     assert geo(250, 250, 16)[:1] + geo(250, 250, 16)[4:] == (1, 8, 16)   # a lane of a batch (16 CUs): 4 x 4 sub-domains of 8 slots
     assert L.octane_vof_mid_geometry(0, 5, 256, (C.c_int * 5)()) < 0
+
+
+def test_row_rotation_of_the_tile_columns_is_chosen_where_it_spreads_the_border_tiles(capi):
+    """Host arithmetic only (no GPU): the LDS-DMA PCG kernel rotates the tile columns of tile row r by r where that lowers the largest number
+    of border-column tiles (the frame's first / last tile column: register-staged, bordered operator) any ONE workgroup walks.  The count
+    is redone here in Python for the default walk (runs of 8 adjacent tiles per XCD) and has to agree with the library's; a per-row
+    rotation is a permutation of the row, so every tile is still visited exactly once (asserted on the replica)."""
+    if not os.path.exists(capi.DIAG_LIB_PATH):
+        pytest.skip("the diagnostic library has not been built")
+    L = capi.diag().lib()
+
+    def replica(w, rows, grid):
+        tx, ty = (w + 127) // 128, (rows + 15) // 16
+        nt = tx * ty
+        plain, rot, seen = [0] * grid, [0] * grid, set()
+        for b in range(grid):
+            x, j = b & 7, b >> 3
+            first = ((j // 8) * 8 + x) * 8 + (j % 8)
+            for t in range(first, nt, grid):
+                row, col = divmod(t, tx)
+                colr = (col + row) % tx
+                seen.add((row, colr))
+                plain[b] += col in (0, tx - 1)
+                rot[b] += colr in (0, tx - 1)
+        assert len(seen) == nt                       # the rotated walk visits every tile exactly once
+        return tx, max(plain), max(rot)
+
+    for n, want in ((5000, 1), (2500, 1), (10848, 0), (2712, 0)):
+        out = (C.c_int * 3)()
+        got = L.octane_vof_row_rotation(n, n, 512, 4, out)
+        assert got == want and tuple(out) == replica(n, n, 512), (n, got, tuple(out), replica(n, n, 512))
+    out = (C.c_int * 3)()
+    assert L.octane_vof_row_rotation(5000, 5000, 512, 4, out) == 1 and tuple(out) == (40, 5, 2)     # 64 workgroups own all left-border tiles; rotated: two at most
+    assert L.octane_vof_row_rotation(2000, 2000, 512, 4, out) == 0        # 16 columns divide the grid: the kernel rotates by ROUND there (Q_ROT)
+    assert L.octane_vof_row_rotation(5000, 5000, 512, 2, out) == 0        # walks the count does not model are left alone
+    assert L.octane_vof_row_rotation(0, 5, 512, 4, out) < 0
 
 
 def test_default_params_are_the_reference_cli_defaults(capi):
