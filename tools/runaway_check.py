@@ -19,8 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from octane_amd import capi, synth
-capi = capi.dev()      # tune / probe / self-tests: the DIAGNOSTIC library's binding (the product library does not export them)
+from octane_amd import capi, synth          # the default plan and the row bands run on the PRODUCT library ...
+dcapi = capi.dev()                            # ... only the leg with the persistent solve switched off needs the diagnostic one (octane_vof_tune)
 from oracle import oct_oracle as oo          # a tool, not the product: the oracle is the checker here
 
 
@@ -49,8 +49,10 @@ def main():
     print(f"{n} x {n}, seed {seed}, {prm}", flush=True)
     res = {}
     for name, persist in (("HIP, default plan", 1), ("HIP, persistent solve off", 0)):
-        pl = capi.Plan(n, n, 1, capi.FlowParams(**prm))
-        pl.tune("persist", persist)
+        lib = capi if persist else dcapi
+        pl = lib.Plan(n, n, 1, lib.FlowParams(**prm))
+        if not persist:
+            pl.tune("persist", 0)
         t = time.time()
         u, v = pl.run_host(a, b)
         describe(name, u, v, tu, tv, pl.last_iterations(), time.time() - t)
