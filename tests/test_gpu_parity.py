@@ -684,3 +684,47 @@ def test_lds_dma_kernel_with_rotated_tile_columns_agrees_with_the_register_stage
     d = rel_l2(outs[1][0], outs[1][1], outs[0][0], outs[0][1])
     print(f"PARITY case=q_dma_rotated {nx}x{ny} {prm}: rel-L2 {d:.3e}, iterations {its}")
     assert its[0] == its[1] and d < 1e-5
+
+
+def test_tile_walks_of_the_lds_dma_kernel_on_random_large_shapes(capi_diag):
+    """Round 6: the LDS-DMA PCG kernel walks its tiles backwards on odd launches, stores the tail of a long walk allocating, and rotates
+    the tile columns of tile row r by r where the host's count says that spreads the border-column tiles (octane_vof_row_rotation) --
+    three re-orderings of WHO does WHICH tile WHEN.  Every one of them has to be a permutation of the tiles (the arena is poisoned with
+    NaNs: a tile done twice or not at all shows) and may change nothing but the grouping of the fp64 partial sums.  A seeded sweep over
+    frames whose only level runs that kernel -- 2 to 13 rounds of tiles, 17 ... 44 tile columns, ragged right / bottom edges, odd and even launch
+    counts, shapes on which the rotation is on and shapes on which it is off -- against the register-staged kernel (tune "q_dma" 0:
+    always the forward, unrotated walk): same iteration count, flows within 1e-5 (measured: bit-identical in nearly every case)."""
+    import ctypes as C
+    capi = capi_diag
+    L = capi.lib()
+    rng = np.random.RandomState(20261005)
+    # the BASELINE widths' column counts (40: 13 rounds of tiles, so the allocating tail is on too; 20), a ragged 40th column, a small frame
+    shapes = [(5000, 2700), (2500, 2500), (4993, 1400), (3196, 705)]
+    while len(shapes) < 14:
+        nx, ny = int(rng.randint(2100, 6000)), int(rng.randint(400, 2800))
+        if nx * ny >= (2 << 20) + 4096 and nx * ny < 14_000_000:
+            shapes.append((nx, ny))
+    rotated = 0
+    for i, (nx, ny) in enumerate(shapes):
+        out3 = (C.c_int * 3)()
+        rot = L.octane_vof_row_rotation(nx, ny, 512, 4, out3)
+        rotated += rot
+        prm = dict(kiters=1, liters=1, cgiters=5 + i % 4)
+        a, b = synth.lattice_scene(nx, ny, seed=1000 + i)
+        outs, its = {}, {}
+        for dma in (0, 1):
+            pl = capi.Plan(nx, ny, 1, capi.FlowParams(**prm))
+            try:
+                pl.tune("q_dma", dma)
+                outs[dma] = pl.run_host(a, b)
+                its[dma] = pl.last_iterations()
+            finally:
+                pl.tune("q_dma", 1)
+                pl.close()
+        ndiff = int((outs[0][0] != outs[1][0]).sum() + (outs[0][1] != outs[1][1]).sum())
+        d = rel_l2(outs[1][0], outs[1][1], outs[0][0], outs[0][1])
+        print(f"PARITY case=tile_walks {nx}x{ny} ({out3[0]} tile columns, border tiles per workgroup {out3[1]} plain / {out3[2]} rotated -> rotation "
+              f"{'ON' if rot else 'off'}) {prm}: {ndiff} values differ, rel-L2 {d:.2e}, iterations {its[1]}")
+        assert np.isfinite(outs[1][0]).all() and np.isfinite(outs[1][1]).all()
+        assert its[0] == its[1] == 3 * prm["cgiters"] and d < 1e-5
+    assert 2 <= rotated < len(shapes)                                   # both branches of the host's rule were walked
