@@ -113,8 +113,10 @@ class _Prefetch:
             return
         for n in names:
             self.events[n] = threading.Event()
-        # two cores are left to the foreground tests (their own small oracle runs, numpy, the HIP runtime's host threads)
-        nthreads = max(1, oracle.host_cpu_share() - 2)
+        # all the cores: the oracle scales almost linearly to 16 threads (tools/oracle_scaling.py on a GPU box: 3000^2 in 10.9 / 6.9 / 6.1 s on
+        # 8 / 14 / 16 threads; two cases side by side on 7 threads each 12.3 s against 13.3 s one after the other on 14) and the suite's end is
+        # oracle-bound; the foreground tests' own small oracle runs and numpy share them with it
+        nthreads = max(1, oracle.host_cpu_share())
 
         def work():
             for n in names:
